@@ -1,0 +1,186 @@
+/*
+ * p2s_hip.h -- C ABI of the MI355X-native Points2Surf SDF-inference engine (libp2s_hip.so).
+ *
+ * The reference (ErlerPhilipp/points2surf) is pure Python and has no FFI; its boundary for
+ * this path is the Python API
+ *     source/points_to_surf_eval.py:297-404   points_to_surf_eval(eval_opt)
+ *     source/points_to_surf_model.py:237-352  PointsToSurfModel(**kw).forward(dict) -> [B,2]
+ * Each entry point below names the reference call it replaces underneath that API.  The
+ * host-side mirror of the Python API (points2surf_amd/dropin/source/...) binds these symbols
+ * with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative
+ * P2S_E* code (message via p2s_last_error(), thread-local).  All "dev" pointers are device
+ * (HBM) pointers owned by the caller (e.g. PyTorch-ROCm tensor storage).  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous on `stream`
+ * unless documented otherwise; handles are owned by the library until *_destroy.
+ */
+#ifndef P2S_HIP_H
+#define P2S_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2S_ABI_VERSION 1
+
+#define P2S_OK            0
+#define P2S_EINVAL       -1   /* bad argument / unsupported configuration */
+#define P2S_EHIP         -2   /* HIP runtime error (see p2s_last_error) */
+#define P2S_ENOMEM       -3
+#define P2S_ECAPACITY    -4   /* caller-provided output buffer too small */
+#define P2S_ENODEVICE    -5   /* no gfx950 device visible */
+
+typedef struct p2s_model_s *p2s_model_t;
+typedef struct p2s_cloud_s *p2s_cloud_t;
+typedef struct p2s_rng_s   *p2s_rng_t;
+
+int         p2s_abi_version(void);
+const char *p2s_last_error(void);
+/* number of visible HIP devices (0 if none); never fails */
+int         p2s_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Model  (replaces make_regressor: PointsToSurfModel(...).cuda(); load_state_dict(); eval(),
+ *         reference source/points_to_surf_eval.py:150-171)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t net_size;            /* 1024 (train --net_size)                                    */
+    int32_t points_per_patch;    /* 300  (train --points_per_patch)                            */
+    int32_t sub_sample_size;     /* 1000 (train --sub_sample_size)                             */
+    int32_t output_dim;          /* 2: [|d| logit, sign logit]                                 */
+    int32_t use_point_stn;       /* QSTN present (p2s_vanilla)                                 */
+    int32_t shared_transformer;  /* one QSTN over cat(patch, sub-sample) (p2s_vanilla)         */
+    int32_t reserved[10];
+} p2s_model_cfg;
+
+/* Offsets (in floats) into the weight blob.  The blob holds BatchNorm-folded fp32 weights,
+ * GEMM operands pre-packed in MFMA B-fragment order ([N/32][K/8][64 lanes][4]); it is produced
+ * by points2surf_amd/weights.py from a reference state_dict.  enc[0] = feat_local (kNN patch),
+ * enc[1] = feat_global (sub-sample).  See DESIGN.md "weight blob". */
+typedef struct {
+    uint64_t w0a, b0a;           /* conv0a+bn0a: [3][64] plain, [64]                           */
+    uint64_t w0b, b0b;           /* conv0b+bn0b: packed K=64 N=64                              */
+    uint64_t s1, sb1;            /* stn2.conv1+bn1 packed 64x64                                */
+    uint64_t s2, sb2;            /* stn2.conv2+bn2 packed 64x128                               */
+    uint64_t s3, sb3;            /* stn2.conv3+bn3 packed 128x1024                             */
+    uint64_t sf1, sfb1;          /* stn2.fc1+bn4 packed 1024x512                               */
+    uint64_t sf2, sfb2;          /* stn2.fc2+bn5 packed 512x256                                */
+    uint64_t sf3, sfb3;          /* stn2.fc3 (+identity in bias) packed 256x4096               */
+    uint64_t m1t, mb1;           /* conv1+bn1, transposed & packed as B operand of the fold    */
+    uint64_t m2, mb2;            /* conv2+bn2 packed 64x128                                    */
+    uint64_t m3, mb3;            /* conv3+bn3 packed 128x1024                                  */
+} p2s_encoder_offsets;
+
+typedef struct {
+    uint64_t c1, cb1;            /* conv1+bn1: [3][64] plain                                   */
+    uint64_t c2, cb2;            /* conv2+bn2 packed 64x128                                    */
+    uint64_t c3, cb3;            /* conv3+bn3 packed 128x1024                                  */
+    uint64_t f1, fb1;            /* fc1+bn4 packed 1024x512                                    */
+    uint64_t f2, fb2;            /* fc2+bn5 packed 512x256                                     */
+    uint64_t f3, fb3;            /* fc3 (+[1,0,0,0] in bias): plain [256][4], [4]              */
+} p2s_qstn_offsets;
+
+typedef struct {
+    p2s_encoder_offsets enc[2];
+    p2s_qstn_offsets    qstn;    /* valid iff cfg.use_point_stn                                */
+    uint64_t d1l, db1l;          /* fc1_local+bn1_local   packed 1024x512                      */
+    uint64_t d1g, db1g;          /* fc1_global+bn1_global packed 1024x512                      */
+    uint64_t d2, db2;            /* fc2+bn2 packed 1024x256                                    */
+    uint64_t d3, db3;            /* fc3+bn3 packed 256x128                                     */
+    uint64_t d4, db4;            /* fc4: plain [128][2], [2]                                   */
+} p2s_weight_offsets;
+
+int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_floats,
+                     const p2s_weight_offsets *offs, int device, p2s_model_t *out);
+int p2s_model_destroy(p2s_model_t m);
+
+/* a8 + a9: PointsToSurfModel.forward (reference source/points_to_surf_model.py:296-352) followed
+ * by post_process (source/points_to_surf_eval.py:174-196, source/sdf_nn.py:11-21) and the
+ * magnitude*sign / NaN->1 of save_evaluation (:263-273, :205-207).
+ *   patch_ps_dev [B][points_per_patch][3]   kNN patch in patch space
+ *   sub_ms_dev   [B][sub_sample_size][3]    global sub-sample in MODEL space (NOT translated; the
+ *                                           kernel subtracts the query point; input is not modified)
+ *   query_dev    [B][3], radius_dev [B] (may be NULL iff sdf_out_dev is NULL)
+ *   logits_out_dev [B][output_dim] (may be NULL), sdf_out_dev [B] (may be NULL)
+ * Work buffers are owned by the model and grown on demand (not thread-safe per model). */
+int p2s_encode_decode(p2s_model_t m, const float *patch_ps_dev, const float *sub_ms_dev,
+                      const float *query_dev, const float *radius_dev, int B,
+                      float *logits_out_dev, float *sdf_out_dev, void *stream);
+
+/* stage-wise access for parity tests: encoder features of both branches
+ * (feat_local / feat_global outputs, reference points_to_surf_model.py:333,341), [B][net_size] each */
+int p2s_encode_features(p2s_model_t m, const float *patch_ps_dev, const float *sub_ms_dev,
+                        const float *query_dev, int B, float *feat_local_dev, float *feat_global_dev,
+                        void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cloud  (replaces load_shape: cKDTree(pts, leaf_size=1000), reference source/data_loader.py:16-68)
+ * ------------------------------------------------------------------------------------------ */
+int p2s_cloud_create(const float *pts_dev, int n_points, int device, void *stream, p2s_cloud_t *out);
+int p2s_cloud_destroy(p2s_cloud_t c);
+int p2s_cloud_num_points(p2s_cloud_t c);
+
+/* a1: get_voxel_centers_grid_smaller_pc (reference source/sdf.py:46-79).  Writes up to `capacity`
+ * query points (C order of the voxel index) to q_out_dev [capacity][3]; *n_queries receives the
+ * full count (synchronises `stream`).  Returns P2S_ECAPACITY if capacity is too small (count is
+ * still reported) -- call once with capacity 0 to size the buffer. */
+int p2s_query_grid(p2s_cloud_t c, int grid_resolution, int epsilon, float *q_out_dev,
+                   int64_t capacity, int64_t *n_queries, void *stream);
+
+/* a4 + a5: get_patch_kdtree (kdtree.query(k), fp64 ranking; reference source/base/point_cloud.py:170-175)
+ * + get_patch_radii / model_space_to_patch_space (source/base/utils.py:62-69,80-88;
+ * source/data_loader.py:341-350).  ids sorted by ascending distance.
+ *   ids_out_dev [Q][k] int32 (may be NULL), patch_ps_out_dev [Q][k][3] (may be NULL),
+ *   radius_out_dev [Q] (may be NULL) */
+int p2s_knn_patch(p2s_cloud_t c, const float *query_dev, int64_t n_queries, int k,
+                  int32_t *ids_out_dev, float *patch_ps_out_dev, float *radius_out_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a6: global sub-sample (reference source/base/utils.py:196-227 with the dataset-wide
+ *     np.random.RandomState of source/data_loader.py:274-277)
+ * ------------------------------------------------------------------------------------------ */
+int p2s_rng_create(uint32_t seed, int device, p2s_rng_t *out);   /* RandomState(seed) */
+int p2s_rng_destroy(p2s_rng_t r);
+/* copy the 624-word MT19937 state + position out / in (host memory); for sharding + tests */
+int p2s_rng_get_state(p2s_rng_t r, uint32_t *mt624_host, int32_t *pos_host, void *stream);
+int p2s_rng_set_state(p2s_rng_t r, const uint32_t *mt624_host, int32_t pos, void *stream);
+
+/* uniform mode (p2s_max, uniform_subsample=1): ids = rng.randint(0, N, n) per query, consumed in
+ * query order from one continuous stream.  ids_out_dev [Q][n] int32 (may be NULL),
+ * pts_out_dev [Q][n][3] gathered points in model space (may be NULL). */
+int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t n_queries, int n,
+                          int32_t *ids_out_dev, float *pts_out_dev, void *stream);
+/* given-ids mode (p2s_vanilla parity mode: ids from the host's legacy choice(p, replace=False)) */
+int p2s_gather_points(p2s_cloud_t c, const int32_t *ids_dev, int64_t n_ids, float *pts_out_dev,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused per-shape pipeline: what the batch loop of points_to_surf_eval does for one shape in
+ * reconstruction mode (reference source/points_to_surf_eval.py:358-404), queries [q_begin, q_end)
+ * of the shape's query list (pass 0, -1 for all).  The RNG stream is consumed for exactly the
+ * processed queries.  sdf_out_dev [q_end-q_begin]; q_out_dev [q_end-q_begin][3] (may be NULL).
+ * chunk = queries per internal batch (0 = default).
+ * ------------------------------------------------------------------------------------------ */
+int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int grid_resolution, int epsilon,
+                    int64_t q_begin, int64_t q_end, int chunk, float *sdf_out_dev, float *q_out_dev,
+                    int64_t *n_done, void *stream);
+
+/* per-stage counters of the last p2s_encode_decode / p2s_infer_shape on this model
+ * (HIP-event milliseconds on the launch stream; valid after the stream is synchronised) */
+typedef struct {
+    double  ms_chain_stn, ms_stn_head, ms_chain_main, ms_decoder, ms_knn, ms_subsample, ms_grid;
+    int64_t queries;
+    int64_t launches_chain;      /* number of point-chain kernel launches (2 per chunk) */
+    double  reserved[8];
+} p2s_counters;
+int p2s_set_profiling(p2s_model_t m, int enabled);
+int p2s_get_counters(p2s_model_t m, p2s_counters *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2S_HIP_H */

@@ -1,0 +1,184 @@
+"""TEST INFRASTRUCTURE ONLY -- generate tests/golden/* by running the UNMODIFIED reference.
+
+Run in the build container only (needs /root/reference):
+
+    python -m oracle.make_golden
+
+What it does (everything through the reference's own code, CPU, --workers 0):
+  * writes seeded synthetic ``<model>_model.pth`` / ``<model>_params.pth`` (no pretrained
+    weights exist offline) in the layout the reference saves/loads
+    (points_to_surf_train.py:420,513 / points_to_surf_eval.py:150-171,316);
+  * runs ``source.points_to_surf_eval.points_to_surf_eval`` in reconstruction mode on the
+    ``abc_minimal`` test shape at grid 32, eps 3 -> full-shape SDF + query points;
+  * re-creates the reference dataset and records, for the first NQ queries, the tensors
+    the reference feeds to the network (kNN ids, radius, sub-sample ids) and the raw
+    logits of the reference ``PointsToSurfModel``;
+  * records query-grid sizes/hashes for larger resolutions.
+The fixture cloud is copied (data, not source) so the GPU box can use it.
+"""
+import argparse
+import hashlib
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+
+from oracle import ref_shims  # noqa: E402
+from points2surf_amd import synth  # noqa: E402
+
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+SHAPE = '00994122_57d9d4755722f9d2d7436f0a_trimesh_000'
+SEED_DATA = 40938661   # reference default --seed (points_to_surf_eval.py:54)
+NQ = 64
+
+
+def train_namespace(cfg, batch=500):
+    return argparse.Namespace(
+        outputs=['imp_surf_magnitude', 'imp_surf_sign', 'patch_pts_ids', 'p_index'],
+        points_per_patch=300, patch_center='mean', sub_sample_size=1000, patch_radius=0.0,
+        uniform_subsample=int(cfg['uniform_subsample']), fixed_subsample=0, net_size=1024,
+        use_point_stn=int(cfg['use_point_stn']), use_feat_stn=1, sym_op='max',
+        single_transformer=0, shared_transformer=int(cfg['shared_transformer']), batchSize=batch)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def ids_from_points(cloud, pts):
+    """recover row indices of ``pts`` in ``cloud`` (fixture clouds have no duplicate rows)."""
+    key = {}
+    for i, row in enumerate(cloud):
+        key[row.tobytes()] = i
+    flat = pts.reshape(-1, 3)
+    return np.array([key[np.ascontiguousarray(r).tobytes()] for r in flat], dtype=np.int32).reshape(pts.shape[:-1])
+
+
+def main():
+    import torch
+    os.makedirs(GOLDEN, exist_ok=True)
+    ref_shims.install()
+    from source import points_to_surf_eval as ref_eval
+    from source import data_loader as ref_dl
+    from source import sdf as ref_sdf
+    from source.points_to_surf_model import PointsToSurfModel as RefModel
+
+    ds_root = os.path.join(ref_shims.REFERENCE_ROOT, 'datasets', 'abc_minimal')
+    cloud = np.load(os.path.join(ds_root, '04_pts', SHAPE + '.xyz.npy'))
+    np.save(os.path.join(GOLDEN, 'cloud_abc_00994122.npy'), cloud)
+    meta = {'shape': SHAPE, 'n_points': int(cloud.shape[0]), 'seed_data': SEED_DATA, 'nq': NQ,
+            'torch': torch.__version__, 'numpy': np.__version__}
+
+    # ---- a1: query grids through the reference function ------------------------------
+    grids = {}
+    for res, eps in ((32, 3), (64, 3), (128, 3), (256, 3), (64, 4), (32, 5)):
+        q = ref_sdf.get_voxel_centers_grid_smaller_pc(pts=cloud, grid_resolution=res, distance_threshold_vs=eps)
+        grids['%d_%d' % (res, eps)] = {'count': int(q.shape[0]), 'sha256': sha(q)}
+        if (res, eps) == (32, 3):
+            np.save(os.path.join(GOLDEN, 'query_grid_32_3.npy'), q)
+    meta['query_grids'] = grids
+
+    torch.set_num_threads(os.cpu_count())
+    for model in ('p2s_max', 'p2s_vanilla'):
+        w, cfg = synth.make_weights(model, seed=1234)
+        tmp = tempfile.mkdtemp(prefix='p2s_golden_')
+        try:
+            modeldir = os.path.join(tmp, 'models')
+            os.makedirs(modeldir)
+            torch.save(synth.to_torch_state_dict(w), os.path.join(modeldir, model + '_model.pth'))
+            torch.save(train_namespace(cfg), os.path.join(modeldir, model + '_params.pth'))
+            outdir = os.path.join(tmp, 'out')
+            opt = ref_eval.parse_arguments([
+                '--indir', ds_root, '--outdir', outdir, '--dataset', 'testset.txt',
+                '--modeldir', modeldir, '--models', model, '--query_grid_resolution', '32',
+                '--epsilon', '3', '--certainty_threshold', '13', '--sigma', '5', '--gpu_idx', '-1',
+                '--workers', '0', '--batchSize', '500', '--cache_capacity', '5'])
+            opt.reconstruction = True
+            ref_eval.points_to_surf_eval(opt)          # <- the reference's hot path, unmodified
+            sdf_full = np.load(os.path.join(outdir, 'rec', 'dist_ms', SHAPE + '.xyz.npy'))
+            q_full = np.load(os.path.join(outdir, 'rec', 'query_pts_ms', SHAPE + '.xyz.npy'))
+            assert sha(q_full) == grids['32_3']['sha256']
+
+            # ---- per-stage tensors of the first NQ queries ------------------------------
+            train_opt = torch.load(os.path.join(modeldir, model + '_params.pth'))
+            dataset = ref_eval.make_dataset(train_opt=train_opt, eval_opt=opt)
+            items = [dataset[i] for i in range(NQ)]
+            patch_ps = torch.stack([it['patch_pts_ps'] for it in items])
+            radius = torch.stack([it['patch_radius_ms'] for it in items])
+            sub_ms = torch.stack([it['pts_sub_sample_ms'] for it in items])
+            qpt = torch.stack([it['imp_surf_query_point_ms'] for it in items])
+            # kNN ids through the reference helper (same call as data_loader.py:336-339)
+            from source.base import point_cloud as ref_pc
+            shape0 = dataset.shape_cache.get(0)
+            knn = np.stack([ref_pc.get_patch_kdtree(
+                kdtree=shape0.kdtree, rng=dataset.rng, query_point=qpt[i].numpy(), patch_radius=0.0,
+                points_per_patch=300, n_jobs=1) for i in range(NQ)]).astype(np.int32)
+            sub_ids = ids_from_points(cloud, sub_ms.numpy())
+
+            pred_dim, _ = ref_eval.get_output_dimensions(train_opt)
+            ref_model = RefModel(
+                net_size_max=1024, num_points=300, output_dim=pred_dim,
+                use_point_stn=train_opt.use_point_stn, use_feat_stn=train_opt.use_feat_stn,
+                sym_op='max', use_query_point=True, sub_sample_size=1000, do_augmentation=False,
+                single_transformer=train_opt.single_transformer,
+                shared_transformation=train_opt.shared_transformer)
+            ref_model = torch.nn.DataParallel(ref_model)
+            ref_model.load_state_dict(torch.load(os.path.join(modeldir, model + '_model.pth')))  # strict
+            ref_model.eval()
+            with torch.no_grad():
+                batch = {'patch_pts_ps': patch_ps.clone(), 'pts_sub_sample_ms': sub_ms.clone(),
+                         'imp_surf_query_point_ms': qpt.clone()}
+                logits = ref_model.module(batch).numpy()
+                # encoder features of the reference (for stage-wise kernel parity)
+                shape_t = (sub_ms - qpt.unsqueeze(1)).transpose(1, 2).contiguous()
+                patch_t = patch_ps.transpose(1, 2).contiguous()
+                m = ref_model.module
+                if train_opt.use_point_stn and train_opt.shared_transformer:
+                    feats = torch.cat((patch_t, shape_t), dim=2)
+                    trans, _ = m.point_stn(feats)
+                    shape_t = torch.bmm(trans, shape_t)
+                    patch_t = torch.bmm(trans, patch_t)
+                feat_g = m.feat_global(shape_t)[0].numpy()
+                feat_l = m.feat_local(patch_t)[0].numpy()
+
+            np.savez_compressed(
+                os.path.join(GOLDEN, 'ref_%s_grid32.npz' % model),
+                sdf_full=sdf_full.astype(np.float32),
+                knn_ids=knn, radius=radius.numpy().astype(np.float32),
+                patch_ps_head=patch_ps.numpy()[:4].astype(np.float32),
+                sub_ids=sub_ids, logits=logits.astype(np.float32),
+                feat_local=feat_l.astype(np.float32), feat_global=feat_g.astype(np.float32))
+            meta[model] = {
+                'queries': int(sdf_full.shape[0]),
+                'sdf_pos_frac': float((sdf_full > 0).mean()),
+                'logit0_range': [float(logits[:, 0].min()), float(logits[:, 0].max())],
+                'logit1_range': [float(logits[:, 1].min()), float(logits[:, 1].max())],
+                'n_state_keys': len(ref_model.state_dict()),
+            }
+            print(model, meta[model])
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+    # ---- RNG known-answer vectors straight from numpy's legacy RandomState ------------------
+    rs = np.random.RandomState(SEED_DATA)
+    kat = {'randint_34693': rs.randint(0, 34693, 2000).astype(np.int64)}
+    rs = np.random.RandomState(SEED_DATA)
+    kat['rand'] = rs.rand(1000)
+    rs = np.random.RandomState(12345)
+    kat['randint_150000'] = rs.randint(0, 150000, 3000).astype(np.int64)
+    np.savez_compressed(os.path.join(GOLDEN, 'numpy_legacy_rng_kat.npz'), **kat)
+
+    with open(os.path.join(GOLDEN, 'meta.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print('golden vectors written to', GOLDEN)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,460 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU (numpy) restatement of the Points2Surf SDF-inference path.
+
+This is the *oracle* for the MI355X engine: a plain numpy restatement of what the
+reference (ErlerPhilipp/points2surf) computes on the path named by
+BASELINE.json's north_star.  It is NOT part of the product; only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+
+Pinning status: PINNED.  ``oracle/make_golden.py`` executes the unmodified
+reference (through ``oracle/ref_shims.py``) in the build container on seeded
+synthetic weights + the ``abc_minimal`` fixture cloud and commits the outputs to
+``tests/golden/``; ``tests/test_oracle_golden.py`` checks every function below
+against those vectors (query grid, kNN ids, radius, patch, sub-sample ids,
+logits, SDF).  Not pinned (not on the path, third-party code absent): marching
+cubes (scikit-image) and trimesh mesh export -- see DESIGN.md.
+
+Each function cites the reference file:line it follows (paths relative to the
+reference root).
+"""
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# a6 prerequisite: NumPy legacy MT19937 stream (numpy/random/_mt19937 + legacy RandomState)
+# Reference call sites: source/data_loader.py:272-277 (RandomState(seed)),
+#                       source/base/utils.py:211,216,219,224 (seed/randint/choice/shuffle)
+# Third-party algorithm restated: MT19937 (Matsumoto & Nishimura 1998) as frozen by
+# NumPy's legacy-RandomState policy (requirements.txt:1 numpy>=1.18, un-pinned).
+# --------------------------------------------------------------------------------------
+
+_U = np.uint32
+_MATRIX_A = _U(0x9908b0df)
+_UPPER = _U(0x80000000)
+_LOWER = _U(0x7fffffff)
+
+
+def _mix(u, v):
+    y = (u & _UPPER) | (v & _LOWER)
+    return (y >> _U(1)) ^ np.where((y & _U(1)) != 0, _MATRIX_A, _U(0))
+
+
+class LegacyMT19937:
+    """Bit-exact model of ``np.random.RandomState(seed)``'s raw uint32 stream."""
+
+    N = 624
+    M = 397
+
+    def __init__(self, seed):
+        self.seed(seed)
+
+    def seed(self, seed):
+        # init_genrand (numpy _legacy_seeding with an integer seed)
+        mt = np.empty(self.N, dtype=np.uint64)
+        mt[0] = int(seed) & 0xffffffff
+        for i in range(1, self.N):
+            prev = int(mt[i - 1])
+            mt[i] = (1812433253 * (prev ^ (prev >> 30)) + i) & 0xffffffff
+        self.mt = mt.astype(np.uint32)
+        self.pos = self.N  # "needs twist before first draw"
+        self._tempered = None
+
+    def _twist(self):
+        mt = self.mt
+        new = np.empty_like(mt)
+        n, m = self.N, self.M
+        # the recurrence has three dependent, internally-parallel phases
+        new[0:n - m] = mt[m:n] ^ _mix(mt[0:n - m], mt[1:n - m + 1])                       # i in [0,227)
+        new[n - m:2 * (n - m)] = new[0:n - m] ^ _mix(mt[n - m:2 * (n - m)],
+                                                       mt[n - m + 1:2 * (n - m) + 1])       # [227,454)
+        new[2 * (n - m):n - 1] = new[n - m:m - 1] ^ _mix(mt[2 * (n - m):n - 1],
+                                                           mt[2 * (n - m) + 1:n])           # [454,623)
+        new[n - 1] = new[m - 1] ^ _mix(mt[n - 1:n], new[0:1])[0]
+        self.mt = new
+        y = new.copy()
+        y ^= y >> _U(11)
+        y ^= (y << _U(7)) & _U(0x9d2c5680)
+        y ^= (y << _U(15)) & _U(0xefc60000)
+        y ^= y >> _U(18)
+        self._tempered = y
+        self.pos = 0
+
+    def raw(self, count):
+        """next ``count`` tempered uint32 words."""
+        out = np.empty(count, dtype=np.uint32)
+        done = 0
+        while done < count:
+            if self.pos >= self.N:
+                self._twist()
+            take = min(count - done, self.N - self.pos)
+            out[done:done + take] = self._tempered[self.pos:self.pos + take]
+            self.pos += take
+            done += take
+        return out
+
+    def _unread(self, k):
+        """push back the last k words (only within the current block)."""
+        assert 0 <= k <= self.pos
+        self.pos -= k
+
+    # -- legacy RandomState.randint(0, high, size) for high-1 < 2**32 ------------------
+    def randint(self, high, size):
+        """``RandomState.randint(low=0, high=high, size=size)`` (dtype int64):
+        masked rejection on successive 32-bit words (numpy _bounded_integers,
+        legacy ``use_masked=True`` path).  Call site: source/base/utils.py:216."""
+        rng = int(high) - 1
+        if rng == 0:
+            return np.zeros(size, dtype=np.int64)
+        assert 0 < rng <= 0xffffffff
+        mask = rng
+        for s in (1, 2, 4, 8, 16):
+            mask |= mask >> s
+        out = np.empty(size, dtype=np.int64)
+        done = 0
+        while done < size:
+            need = size - done
+            # draw with head-room, keep the accepted prefix, push back the unread tail
+            want = min(self.N, max(16, int(need * (mask + 1) / (rng + 1) * 1.1) + 8))
+            if self.pos >= self.N:
+                self._twist()
+            want = min(want, self.N - self.pos)
+            w = self._tempered[self.pos:self.pos + want] & _U(mask)
+            ok = np.nonzero(w <= rng)[0]
+            if ok.size >= need:
+                used = int(ok[need - 1]) + 1
+                out[done:] = w[ok[:need]]
+                self.pos += used
+                done = size
+            else:
+                out[done:done + ok.size] = w[ok]
+                done += ok.size
+                self.pos += want
+        return out
+
+    # -- legacy RandomState.rand / random_sample ---------------------------------------
+    def rand(self, size):
+        w = self.raw(2 * size).astype(np.uint64)
+        a = w[0::2] >> np.uint64(5)
+        b = w[1::2] >> np.uint64(6)
+        return (a * np.float64(67108864.0) + b) / np.float64(9007199254740992.0)
+
+    # -- legacy RandomState.choice(a, size, replace=False, p) ---------------------------
+    def choice_noreplace(self, n, size, p):
+        """Call site: source/base/utils.py:219 (distance-weighted sub-sample, p2s_vanilla)."""
+        p = np.array(p, dtype=np.float64, copy=True)
+        found = np.zeros(size, dtype=np.int64)
+        n_uniq = 0
+        while n_uniq < size:
+            x = self.rand(size - n_uniq)
+            if n_uniq > 0:
+                p[found[0:n_uniq]] = 0
+            cdf = np.cumsum(p)
+            cdf /= cdf[-1]
+            new = cdf.searchsorted(x, side='right')
+            _, unique_indices = np.unique(new, return_index=True)
+            unique_indices.sort()
+            new = new.take(unique_indices)
+            found[n_uniq:n_uniq + new.size] = new
+            n_uniq += new.size
+        return found
+
+
+# --------------------------------------------------------------------------------------
+# a1: near-surface query grid
+# --------------------------------------------------------------------------------------
+
+def model_space_to_volume_space(pts_ms, vol_res):
+    """source/sdf.py:73-75 (fp32 arithmetic when pts is fp32, floor, integer cast)."""
+    pts = np.asarray(pts_ms)
+    pos = (pts + 1.0) / 2.0
+    return np.floor(pos * vol_res).astype(np.int64)
+
+
+def volume_space_to_model_space(pts_vs, vol_res):
+    """source/sdf.py:78-79 (float64 arithmetic on integer indices)."""
+    return ((pts_vs + 0.5) / vol_res) * 2.0 - 1.0
+
+
+def _box_offsets(size):
+    # scipy.ndimage.convolve(kernel of ones, origin 0): out[i] = sum_j in[i + size//2 - j], j=0..size-1
+    return [size // 2 - j for j in range(size)]
+
+
+def query_grid(pts, grid_resolution, epsilon):
+    """source/sdf.py:46-70 ``get_voxel_centers_grid_smaller_pc``.
+
+    occupancy volume -> box filter of ones(eps^3), mode='nearest' -> nonzero of
+    ``[:-1,:-1,:-1]`` (C order) -> voxel centres as float32.
+    Returns (q [Q,3] float32, vox [Q,3] int64)."""
+    res = int(grid_resolution)
+    pts = np.asarray(pts, dtype=np.float32)
+    vs = model_space_to_volume_space(pts, res)
+    occ = np.zeros((res, res, res), dtype=bool)
+    occ[vs[:, 0], vs[:, 1], vs[:, 2]] = True          # numpy semantics incl. IndexError when outside
+    # a box filter of a 0/1 volume with edge replication is non-zero exactly where the
+    # OR over the (index-clamped) neighbourhood is set; separable per axis.
+    near = occ
+    for axis in range(3):
+        acc = np.zeros_like(near)
+        idx = np.arange(res)
+        for o in _box_offsets(int(epsilon)):
+            src = np.clip(idx + o, 0, res - 1)
+            acc |= np.take(near, src, axis=axis)
+        near = acc
+    vox = np.stack(np.nonzero(near[:-1, :-1, :-1]), axis=1)
+    q = volume_space_to_model_space(vox, res).astype(np.float32)
+    return q, vox
+
+
+# --------------------------------------------------------------------------------------
+# a4 / a5: kNN patch, radius, patch space
+# --------------------------------------------------------------------------------------
+
+def knn_ids(pts, queries, k, chunk=256):
+    """source/base/point_cloud.py:170-175 ``kdtree.query(x, k)`` restated as an exact
+    brute-force search: float64 squared distances on the float64 copy of the float32
+    cloud (cKDTree stores float64, source/data_loader.py:40-42), ascending by distance.
+    Returns ids [Q,k] int32 (sorted by distance)."""
+    p64 = np.asarray(pts, dtype=np.float64)
+    q64 = np.asarray(queries, dtype=np.float64).reshape(-1, 3)
+    n = p64.shape[0]
+    if n < k:
+        raise IndexError('cloud has fewer points (%d) than points_per_patch (%d)' % (n, k))
+    out = np.empty((q64.shape[0], k), dtype=np.int32)
+    for s in range(0, q64.shape[0], chunk):
+        qq = q64[s:s + chunk]
+        d0 = qq[:, None, 0] - p64[None, :, 0]
+        d2 = d0 * d0
+        d1 = qq[:, None, 1] - p64[None, :, 1]
+        d2 += d1 * d1
+        d1 = qq[:, None, 2] - p64[None, :, 2]
+        d2 += d1 * d1
+        part = np.argpartition(d2, k - 1, axis=1)[:, :k]
+        dd = np.take_along_axis(d2, part, axis=1)
+        order = np.argsort(dd, axis=1, kind='stable')
+        out[s:s + chunk] = np.take_along_axis(part, order, axis=1)
+    return out
+
+
+def patch_radius_and_ps(pts, ids, query):
+    """source/data_loader.py:341-350 + source/base/utils.py:62-69,80-88 (all float32):
+    r = max_i ||q - p_i||_2  (norm = sqrt((dx*dx + dy*dy) + dz*dz), each op rounded to fp32)
+    patch_ps = (p_i - q) / r."""
+    pts = np.asarray(pts, dtype=np.float32)
+    q = np.asarray(query, dtype=np.float32)
+    p = pts[ids]                                   # [..., k, 3]
+    d = q[..., None, :] - p
+    s = d * d
+    dist = np.sqrt((s[..., 0] + s[..., 1]) + s[..., 2])
+    r = dist.max(axis=-1)
+    ps = (p - q[..., None, :]) / r[..., None, None]
+    return r.astype(np.float32), ps.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# a6: global sub-sample
+# --------------------------------------------------------------------------------------
+
+def dist_prob(pts, query):
+    """source/base/utils.py:200-208 (float32 throughout; np.sum pairwise)."""
+    pts = np.asarray(pts, dtype=np.float32)
+    qp = np.broadcast_to(np.asarray(query, dtype=np.float32), pts.shape)
+    dist = np.linalg.norm(qp - pts, axis=1)
+    dn = dist / np.max(dist)
+    prob = 1.0 - 1.5 * dn
+    pc = np.clip(prob, 0.05, 1.0)
+    return pc / np.sum(pc)
+
+
+def subsample_ids(rng, pts, query, sub_sample_size, uniform, fixed=False):
+    """source/base/utils.py:196-219: ids of the global sub-sample for ONE query.
+    ``rng`` is a LegacyMT19937 shared by all queries of all shapes
+    (source/data_loader.py:274-277)."""
+    n = pts.shape[0]
+    if n < sub_sample_size:
+        raise NotImplementedError('N < sub_sample_size (shuffle + zero padding, utils.py:221-226)')
+    if fixed:
+        rng.seed(42)
+    if uniform:
+        return rng.randint(n, sub_sample_size)
+    return rng.choice_noreplace(n, sub_sample_size, dist_prob(pts, query))
+
+
+# --------------------------------------------------------------------------------------
+# a8: the network (eval mode), a9: post-processing
+# --------------------------------------------------------------------------------------
+
+_BN_EPS = np.float32(1e-5)
+
+
+def _bn(x, w, prefix, channel_axis):
+    """torch BatchNorm1d in eval mode: (x - mean) / sqrt(var + eps) * gamma + beta."""
+    shape = [1] * x.ndim
+    shape[channel_axis] = -1
+    mean = w[prefix + '.running_mean'].reshape(shape)
+    var = w[prefix + '.running_var'].reshape(shape)
+    gamma = w[prefix + '.weight'].reshape(shape)
+    beta = w[prefix + '.bias'].reshape(shape)
+    return (x - mean) / np.sqrt(var + _BN_EPS) * gamma + beta
+
+
+def _conv(x, w, prefix):
+    """Conv1d(kernel 1) on x [B, P, Cin] (points-major layout of the reference's [B,Cin,P])."""
+    W = w[prefix + '.weight'][:, :, 0]              # [Cout, Cin]
+    return x @ W.T + w[prefix + '.bias']
+
+
+def _fc(x, w, prefix):
+    return x @ w[prefix + '.weight'].T + w[prefix + '.bias']
+
+
+def _relu(x):
+    return np.maximum(x, np.float32(0))
+
+
+def _stn_trunk(x, w, pre):
+    """shared trunk of STN/QSTN: source/points_to_surf_model.py:41-63 / :100-123."""
+    x = _relu(_bn(_conv(x, w, pre + '.conv1'), w, pre + '.bn1', 2))
+    x = _relu(_bn(_conv(x, w, pre + '.conv2'), w, pre + '.bn2', 2))
+    x = _relu(_bn(_conv(x, w, pre + '.conv3'), w, pre + '.bn3', 2))
+    x = x.max(axis=1)                               # MaxPool1d over all points
+    x = _relu(_bn(_fc(x, w, pre + '.fc1'), w, pre + '.bn4', 1))
+    x = _relu(_bn(_fc(x, w, pre + '.fc2'), w, pre + '.bn5', 1))
+    return _fc(x, w, pre + '.fc3')
+
+
+def stn_forward(x, w, pre, dim):
+    """source/points_to_surf_model.py:41-69: returns trans [B, dim, dim]."""
+    t = _stn_trunk(x, w, pre)
+    t = t + np.eye(dim, dtype=np.float32).reshape(1, dim * dim)
+    return t.reshape(-1, dim, dim)
+
+
+def quat_to_rotmat(q):
+    """source/base/utils.py:13-46 ``batch_quat_to_rotmat`` (same index pattern)."""
+    q = q.astype(np.float32)
+    s = np.float32(2) / np.sum(q * q, axis=1)
+    h = q[:, :, None] * q[:, None, :]
+    out = np.empty((q.shape[0], 3, 3), dtype=np.float32)
+    out[:, 0, 0] = 1 - (h[:, 2, 2] + h[:, 3, 3]) * s
+    out[:, 0, 1] = (h[:, 1, 2] - h[:, 3, 0]) * s
+    out[:, 0, 2] = (h[:, 1, 3] + h[:, 2, 0]) * s
+    out[:, 1, 0] = (h[:, 1, 2] + h[:, 3, 0]) * s
+    out[:, 1, 1] = 1 - (h[:, 1, 1] + h[:, 3, 3]) * s
+    out[:, 1, 2] = (h[:, 2, 3] - h[:, 1, 0]) * s
+    out[:, 2, 0] = (h[:, 1, 3] - h[:, 2, 0]) * s
+    out[:, 2, 1] = (h[:, 2, 3] + h[:, 1, 0]) * s
+    out[:, 2, 2] = 1 - (h[:, 1, 1] + h[:, 2, 2]) * s
+    return out
+
+
+def qstn_forward(x, w, pre):
+    """source/points_to_surf_model.py:100-131: returns (R [B,3,3], quat [B,4])."""
+    quat = _stn_trunk(x, w, pre) + np.array([1, 0, 0, 0], dtype=np.float32)
+    return quat_to_rotmat(quat), quat
+
+
+def pointnetfeat_forward(x, w, pre, use_point_stn, use_feat_stn=True, return_aux=False):
+    """source/points_to_surf_model.py:177-234 (num_scales=1, sym_op='max').
+    x: [B, P, 3] (points-major).  Returns feature [B, net_size] (+ trans)."""
+    trans = None
+    if use_point_stn:
+        trans, _ = qstn_forward(x, w, pre + '.stn1')
+        x = np.einsum('bij,bpj->bpi', trans, x)      # bmm(trans, x[:, :3, :])
+    x = _relu(_bn(_conv(x, w, pre + '.conv0a'), w, pre + '.bn0a', 2))
+    x = _relu(_bn(_conv(x, w, pre + '.conv0b'), w, pre + '.bn0b', 2))
+    aux = {}
+    if use_feat_stn:
+        trans2 = stn_forward(x, w, pre + '.stn2', 64)
+        if return_aux:
+            aux['trans2'] = trans2
+        x = np.einsum('bij,bpj->bpi', trans2, x)     # bmm(trans2, x)
+    x = _relu(_bn(_conv(x, w, pre + '.conv1'), w, pre + '.bn1', 2))
+    x = _relu(_bn(_conv(x, w, pre + '.conv2'), w, pre + '.bn2', 2))
+    x = _bn(_conv(x, w, pre + '.conv3'), w, pre + '.bn3', 2)     # no ReLU before the pool
+    x = x.max(axis=1)
+    if return_aux:
+        return x, trans, aux
+    return x, trans
+
+
+def model_forward(w, cfg, patch_pts_ps, pts_sub_sample_ms, query_ms, chunk=32, return_feats=False):
+    """source/points_to_surf_model.py:296-352 ``PointsToSurfModel.forward`` (eval mode).
+
+    w:   dict name -> float32 ndarray (state_dict without the ``module.`` prefix)
+    cfg: dict with use_point_stn, shared_transformer (and use_feat_stn, default True)
+    Returns logits [B, output_dim] float32.  Inputs are not modified (the reference
+    translates pts_sub_sample_ms in place, :303)."""
+    w = {k: np.asarray(v, dtype=np.float32) for k, v in w.items()}
+    B = patch_pts_ps.shape[0]
+    use_point_stn = bool(cfg.get('use_point_stn', False))
+    shared = bool(cfg.get('shared_transformer', False))
+    use_feat_stn = bool(cfg.get('use_feat_stn', True))
+    if cfg.get('single_transformer', False):
+        raise NotImplementedError('single_transformer ablation')
+    out = []
+    feats = []
+    for s in range(0, B, chunk):
+        patch = np.asarray(patch_pts_ps[s:s + chunk], dtype=np.float32)
+        shape = np.asarray(pts_sub_sample_ms[s:s + chunk], dtype=np.float32) \
+            - np.asarray(query_ms[s:s + chunk], dtype=np.float32)[:, None, :]      # :303
+        if use_point_stn and shared:                                              # :325-331
+            both = np.concatenate([patch, shape], axis=1)
+            trans, _ = qstn_forward(both, w, 'point_stn')
+            shape = np.einsum('bij,bpj->bpi', trans, shape)
+            patch = np.einsum('bij,bpj->bpi', trans, patch)
+        g, trans_g = pointnetfeat_forward(shape, w, 'feat_global',
+                                          use_point_stn and not shared, use_feat_stn)   # :333
+        gfc = _relu(_bn(_fc(g, w, 'fc1_global'), w, 'bn1_global', 1))                   # :335
+        if use_point_stn and not shared:                                                # :337-339
+            patch = np.einsum('bij,bpj->bpi', trans_g, patch)
+        l, _ = pointnetfeat_forward(patch, w, 'feat_local', False, use_feat_stn)        # :341
+        lfc = _relu(_bn(_fc(l, w, 'fc1_local'), w, 'bn1_local', 1))                     # :343
+        f = np.concatenate([lfc, gfc], axis=1)                                          # :346
+        f = _relu(_bn(_fc(f, w, 'fc2'), w, 'bn2', 1))
+        f = _relu(_bn(_fc(f, w, 'fc3'), w, 'bn3', 1))
+        out.append(_fc(f, w, 'fc4'))
+        if return_feats:
+            feats.append((l, g))
+    logits = np.concatenate(out, axis=0).astype(np.float32)
+    if return_feats:
+        return logits, np.concatenate([f[0] for f in feats]), np.concatenate([f[1] for f in feats])
+    return logits
+
+
+def post_process(logits, patch_radius):
+    """source/points_to_surf_eval.py:184-196 + source/sdf_nn.py:11-21 + :263-273,205-207:
+    sdf = tanh(l0)^2 * r * (l1 >= 0 ? +1 : -1); NaN -> 1.0."""
+    logits = np.asarray(logits, dtype=np.float32)
+    mag = np.tanh(logits[:, 0]) ** 2 * np.asarray(patch_radius, dtype=np.float32)
+    sign = np.where(logits[:, 1] >= 0, np.float32(1), np.float32(-1))
+    sdf = (mag * sign).astype(np.float32)
+    sdf[np.isnan(sdf)] = 1.0
+    return sdf
+
+
+# --------------------------------------------------------------------------------------
+# end to end (a1..a10 minus file IO) for one shape
+# --------------------------------------------------------------------------------------
+
+def infer_shape(w, cfg, pts, grid_resolution, epsilon, rng, points_per_patch=300,
+                sub_sample_size=1000, query_range=None, chunk=32, return_all=False):
+    """What source/points_to_surf_eval.py:358-404 computes for one shape in
+    reconstruction mode with --workers 0.  ``rng`` = LegacyMT19937 carried across shapes.
+    ``query_range`` = (q0, q1) restricts to a prefix/sub-range of the query list (the RNG
+    is then only advanced for those queries -- use a prefix for stream parity)."""
+    pts = np.asarray(pts, dtype=np.float32)
+    q_all, _ = query_grid(pts, grid_resolution, epsilon)
+    q0, q1 = (0, q_all.shape[0]) if query_range is None else query_range
+    q = q_all[q0:q1]
+    ids = knn_ids(pts, q, points_per_patch)
+    r, patch_ps = patch_radius_and_ps(pts, ids, q)
+    uniform = bool(cfg.get('uniform_subsample', False))
+    fixed = bool(cfg.get('fixed_subsample', False))
+    sub_ids = np.stack([subsample_ids(rng, pts, q[i], sub_sample_size, uniform, fixed)
+                        for i in range(q.shape[0])]) if q.shape[0] else np.zeros((0, sub_sample_size), np.int64)
+    sub = pts[sub_ids]
+    logits = model_forward(w, cfg, patch_ps, sub, q, chunk=chunk)
+    sdf = post_process(logits, r)
+    if return_all:
+        return dict(q=q, knn_ids=ids, radius=r, patch_ps=patch_ps, sub_ids=sub_ids, logits=logits, sdf=sdf,
+                    q_total=q_all.shape[0])
+    return q, sdf

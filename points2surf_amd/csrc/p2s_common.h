@@ -1,0 +1,86 @@
+// Internal shared declarations of libp2s_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include "../../include/p2s_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void p2s_set_error(const char *fmt, ...);
+
+#define P2S_HIP_CHECK(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            p2s_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                          __LINE__);                                                          \
+            return P2S_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+#define P2S_LAUNCH_CHECK(name)                                                                \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess) {                                                               \
+            p2s_set_error("launch of %s failed: %s", name, hipGetErrorString(_e));            \
+            return P2S_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Fused point-wise MLP chain + symmetric max-pool (p2s_chain.hip)
+// ---------------------------------------------------------------------------------------------
+struct ChainBranch {
+    const float *ptsA;       // [n_items][P1][3]  first P1 points of every item (no centre)
+    const float *ptsB;       // [n_items][P-P1][3] remaining points (centre subtracted), may be null
+    const float *center;     // [n_items][3] or null
+    const float *rot;        // [n_items][9] row-major 3x3 applied to every point, or null
+    const float *w0a, *b0a;  // first (K=3) layer: [3][64], [64]
+    const float *w0b, *b0b;  // packed 64x64 (full chain only)
+    const float *w1, *b1;    // packed 64x64 (full chain only); per item if w1_item_stride != 0
+    long long w1_item_stride;
+    const float *w2, *b2;    // packed 64x128
+    const float *w3, *b3;    // packed 128x1024
+    float *out;              // [n_items][1024]
+    int P, P1;
+    int n_items;
+    int relu_out;            // ReLU after the pooled affine (STN trunks) or not (PointNetfeat.conv3)
+    int short_chain;         // 1: 3->64->128->1024 (QSTN trunk), 0: 3->64->64->64->128->1024
+};
+struct ChainArgs {
+    ChainBranch br[2];       // br[0] items come first in the grid
+};
+int p2s_launch_chain(const ChainArgs &args, hipStream_t stream);
+
+// W1' = (BN-folded conv1) . trans2, written in packed B-fragment order.  grid.y = encoder
+struct FoldArgs {
+    const float *T[2];       // [n_items][64*64]   (I + fc3 output), row-major T[i][j]
+    const float *m1t[2];     // packed conv1 weights
+    float *out[2];           // [n_items][4096] packed
+    int n_items;
+};
+int p2s_launch_fold(const FoldArgs &args, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// Dense FC layers, M = batch of queries (p2s_gemm.hip)
+// C[z][M][N] = act(A[z][M][K] . W[z] + bias[z]);  W packed [N/32][K/8][64][4]
+// ---------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float *A; long long lda; long long a_z;
+    const float *W[2];
+    const float *bias[2];
+    float *C; long long ldc; long long c_z;
+    int M, N, K, Z;
+    int relu;
+};
+int p2s_launch_gemm(const GemmArgs &args, hipStream_t stream);
+
+// fc4 (128 -> 2) + tanh^2 * r * sign + NaN->1
+int p2s_launch_decoder_tail(const float *h3, const float *w4, const float *b4, const float *radius,
+                            float *logits_out, float *sdf_out, int B, int K, hipStream_t stream);
+// QSTN tail: fc3 (256 -> 4) + identity quaternion (in bias) -> rotation matrix [B][9]
+int p2s_launch_qstn_tail(const float *h2, const float *w3, const float *b3, float *rot_out, int B, int K,
+                         hipStream_t stream);

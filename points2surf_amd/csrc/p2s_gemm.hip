@@ -1,0 +1,180 @@
+// Dense per-query layers with M = batch of queries, fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the reference's nn.Linear + BatchNorm1d + ReLU stacks:
+//   STN head   fc1,bn4,relu / fc2,bn5,relu / fc3 (+identity)   source/points_to_surf_model.py:62-68
+//   decoder    fc1_{local,global},bn1_*,relu / fc2,bn2,relu / fc3,bn3,relu / fc4   :335-350
+// BatchNorm (eval) is folded into W/bias on the host; W is packed in B-fragment order so that
+// each wave streams its own 32-column panel from L2 with coalesced 16-byte loads (no LDS for W);
+// the activation tile [64 rows x 128 k] is staged in LDS once per k-chunk and shared by 4 waves.
+#include "p2s_common.h"
+
+namespace {
+
+constexpr int GM = 64;     // rows per workgroup
+constexpr int GK = 128;    // k chunk staged in LDS
+constexpr int GS = 132;    // LDS row stride
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// grid: (ceil(M/64), N/128, Z); block 256: wave w -> column tile (blockIdx.y*4 + w), 2 row tiles
+__global__ __launch_bounds__(256) void p2s_gemm_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[GM * GS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int z = blockIdx.z;
+    const int m0 = blockIdx.x * GM;
+    const int nt = blockIdx.y * 4 + wave;
+    const int KG = g.K / 8;
+    const float *__restrict__ A = g.A + (long long)z * g.a_z;
+    const float *__restrict__ Wp = g.W[z] + (long long)nt * KG * 256 + lane * 4;
+    const float *__restrict__ bias = g.bias[z];
+    float *__restrict__ C = g.C + (long long)z * g.c_z;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    const float *a0p = As + (lane & 31) * GS + 4 * (lane >> 5);
+    const float *a1p = a0p + 32 * GS;
+
+    for (int kc = 0; kc < g.K; kc += GK) {
+        __syncthreads();
+        // stage A[m0:m0+64][kc:kc+128]: 8 rows per pass, 32 lanes x 16 B per row (coalesced)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = (tid >> 5) + 8 * i;
+            int m = m0 + r;
+            if (m >= g.M) m = g.M - 1;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(A + (long long)m * g.lda + kc + 4 * (tid & 31));
+            *reinterpret_cast<f32x4 *>(As + r * GS + 4 * (tid & 31)) = v;
+        }
+        __syncthreads();
+        const float *wk = Wp + (long long)(kc / 8) * 256;
+        f32x4 b = *reinterpret_cast<const f32x4 *>(wk);
+#pragma unroll
+        for (int kg = 0; kg < GK / 8; ++kg) {
+            f32x4 nb = b;
+            if (kg < GK / 8 - 1) nb = *reinterpret_cast<const f32x4 *>(wk + (kg + 1) * 256);
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p + 8 * kg);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(a1p + 8 * kg);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc0 = mfma32(a0[t], b[t], acc0);
+                acc1 = mfma32(a1[t], b[t], acc1);
+            }
+            b = nb;
+        }
+    }
+    const int col = nt * 32 + (lane & 31);
+    const float bv = bias[col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        float v0 = acc0[reg] + bv, v1 = acc1[reg] + bv;
+        if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        if (m0 + r < g.M) C[(long long)(m0 + r) * g.ldc + col] = v0;
+        if (m0 + 32 + r < g.M) C[(long long)(m0 + 32 + r) * g.ldc + col] = v1;
+    }
+}
+
+// fc4 (K -> 2, no BN) + post-processing.  One thread per query.
+//   reference: source/points_to_surf_model.py:350, source/sdf_nn.py:11-21,
+//              source/points_to_surf_eval.py:184-196,263-273,205-207
+__global__ __launch_bounds__(256) void p2s_decoder_tail_kernel(const float *__restrict__ h3,
+                                                               const float *__restrict__ w4,
+                                                               const float *__restrict__ b4,
+                                                               const float *__restrict__ radius,
+                                                               float *__restrict__ logits_out,
+                                                               float *__restrict__ sdf_out, int B, int K) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= B) return;
+    const float *h = h3 + (long long)q * K;
+    float l0 = b4[0], l1 = b4[1];
+    for (int k = 0; k < K; k += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(h + k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            l0 = fmaf(v[t], w4[2 * (k + t) + 0], l0);
+            l1 = fmaf(v[t], w4[2 * (k + t) + 1], l1);
+        }
+    }
+    if (logits_out) {
+        logits_out[2 * q + 0] = l0;
+        logits_out[2 * q + 1] = l1;
+    }
+    if (sdf_out) {
+        const float th = tanhf(l0);
+        const float mag = (th * th) * radius[q];
+        float sdf = (l1 >= 0.0f) ? mag : -mag;
+        if (sdf != sdf) sdf = 1.0f;
+        sdf_out[q] = sdf;
+    }
+}
+
+// QSTN tail: fc3 (K -> 4) with the identity quaternion folded into the bias, then
+// batch_quat_to_rotmat (reference source/base/utils.py:13-46, same index pattern).
+__global__ __launch_bounds__(256) void p2s_qstn_tail_kernel(const float *__restrict__ h2,
+                                                            const float *__restrict__ w3,
+                                                            const float *__restrict__ b3,
+                                                            float *__restrict__ rot_out, int B, int K) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= B) return;
+    const float *h = h2 + (long long)q * K;
+    float qa = b3[0], qb = b3[1], qc = b3[2], qd = b3[3];
+    for (int k = 0; k < K; ++k) {
+        const float v = h[k];
+        qa = fmaf(v, w3[4 * k + 0], qa);
+        qb = fmaf(v, w3[4 * k + 1], qb);
+        qc = fmaf(v, w3[4 * k + 2], qc);
+        qd = fmaf(v, w3[4 * k + 3], qd);
+    }
+    const float qq[4] = {qa, qb, qc, qd};
+    const float s = 2.0f / (__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(qa, qa), __fmul_rn(qb, qb)), __fmul_rn(qc, qc)),
+                                      __fmul_rn(qd, qd)));
+#define H(i, j) __fmul_rn(qq[i], qq[j])
+    float *R = rot_out + (long long)q * 9;
+    R[0] = 1.0f - __fmul_rn(__fadd_rn(H(2, 2), H(3, 3)), s);
+    R[1] = __fmul_rn(__fsub_rn(H(1, 2), H(3, 0)), s);
+    R[2] = __fmul_rn(__fadd_rn(H(1, 3), H(2, 0)), s);
+    R[3] = __fmul_rn(__fadd_rn(H(1, 2), H(3, 0)), s);
+    R[4] = 1.0f - __fmul_rn(__fadd_rn(H(1, 1), H(3, 3)), s);
+    R[5] = __fmul_rn(__fsub_rn(H(2, 3), H(1, 0)), s);
+    R[6] = __fmul_rn(__fsub_rn(H(1, 3), H(2, 0)), s);
+    R[7] = __fmul_rn(__fadd_rn(H(2, 3), H(1, 0)), s);
+    R[8] = 1.0f - __fmul_rn(__fadd_rn(H(1, 1), H(2, 2)), s);
+#undef H
+}
+
+}  // namespace
+
+int p2s_launch_gemm(const GemmArgs &g, hipStream_t stream) {
+    if (g.M <= 0) return P2S_OK;
+    if (g.N % 128 != 0 || g.K % GK != 0 || g.Z < 1 || g.Z > 2) {
+        p2s_set_error("gemm: unsupported shape M=%d N=%d K=%d Z=%d", g.M, g.N, g.K, g.Z);
+        return P2S_EINVAL;
+    }
+    dim3 grid((g.M + GM - 1) / GM, g.N / 128, g.Z);
+    hipLaunchKernelGGL(p2s_gemm_kernel, grid, dim3(256), 0, stream, g);
+    P2S_LAUNCH_CHECK("p2s_gemm_kernel");
+    return P2S_OK;
+}
+
+int p2s_launch_decoder_tail(const float *h3, const float *w4, const float *b4, const float *radius,
+                            float *logits_out, float *sdf_out, int B, int K, hipStream_t stream) {
+    if (B <= 0) return P2S_OK;
+    hipLaunchKernelGGL(p2s_decoder_tail_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, h3, w4, b4, radius,
+                       logits_out, sdf_out, B, K);
+    P2S_LAUNCH_CHECK("p2s_decoder_tail_kernel");
+    return P2S_OK;
+}
+
+int p2s_launch_qstn_tail(const float *h2, const float *w3, const float *b3, float *rot_out, int B, int K,
+                         hipStream_t stream) {
+    if (B <= 0) return P2S_OK;
+    hipLaunchKernelGGL(p2s_qstn_tail_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, h2, w3, b3, rot_out, B, K);
+    P2S_LAUNCH_CHECK("p2s_qstn_tail_kernel");
+    return P2S_OK;
+}

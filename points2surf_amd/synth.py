@@ -1,0 +1,102 @@
+"""Seeded synthetic stand-ins for what cannot be downloaded offline.
+
+* ``make_weights``: random-init weights of the reference architecture (pretrained
+  ``p2s_*_model_*.pth`` files need the network, reference models/download_models_*.py).
+  Variance-preserving uniform init + randomised BatchNorm running statistics (so BN
+  folding is exercised) + near-identity feature transforms; logits come out O(1) with
+  mixed signs, which makes sign/SDF parity meaningful.
+* ``make_cloud``: a noisy scan-like point cloud of an analytic solid inside the unit
+  cube (the reference normalises clouds to [-0.5,0.5]^3, make_pc_dataset.py:20-36).
+
+Both are numpy-only and bit-reproducible from the seed on any box with this image.
+"""
+import numpy as np
+
+from .model_spec import state_shapes, NAMED_MODELS
+
+
+_FC4_BIAS_SHIFT = {'p2s_max': (6.289174, 2.416443), 'p2s_vanilla': (2.6854432, 4.523528)}
+
+
+def make_weights(model='p2s_max', seed=1234, net_size_max=1024, output_dim=2):
+    """Returns ({name: float32 ndarray} without ``module.`` prefix, cfg dict)."""
+    cfg = dict(NAMED_MODELS[model]) if isinstance(model, str) else dict(model)
+    shapes = state_shapes(net_size_max=net_size_max, output_dim=output_dim,
+                          use_point_stn=cfg.get('use_point_stn', False),
+                          shared_transformation=cfg.get('shared_transformation', False),
+                          use_feat_stn=cfg.get('use_feat_stn', True))
+    rng = np.random.default_rng(seed)
+    w = {}
+    for name, shape in shapes.items():
+        leaf = name.rsplit('.', 1)[1]
+        layer = name.rsplit('.', 1)[0].rsplit('.', 1)[-1]
+        is_bn = layer.startswith('bn')
+        if leaf == 'num_batches_tracked':
+            w[name] = np.array(1000, dtype=np.int64)
+        elif is_bn and leaf == 'weight':
+            w[name] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif is_bn and leaf == 'bias':
+            w[name] = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        elif leaf == 'running_mean':
+            w[name] = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        elif leaf == 'running_var':
+            w[name] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif leaf == 'weight':
+            fan_in = shape[1]
+            a = np.sqrt(6.0 / fan_in)
+            w[name] = rng.uniform(-a, a, shape).astype(np.float32)
+        elif leaf == 'bias':
+            w[name] = rng.uniform(-0.1, 0.1, shape).astype(np.float32)
+        else:
+            raise AssertionError(name)
+    # transforms close to identity (as trained spatial transformers are)
+    for name in list(w):
+        if name.endswith('stn2.fc3.weight') or name.endswith('stn2.fc3.bias'):
+            w[name] = (w[name] * np.float32(0.05)).astype(np.float32)
+        if name.endswith('stn1.fc3.weight') or name.endswith('stn1.fc3.bias') \
+                or name.startswith('point_stn.fc3.'):
+            w[name] = (w[name] * np.float32(0.2)).astype(np.float32)
+    # centre the two output logits (the random decoder has a data-dependent offset much larger than
+    # its spread; measured once on the abc_minimal fixture) so that tanh is not saturated and the
+    # sign logit changes sign across queries
+    shift = _FC4_BIAS_SHIFT.get(model if isinstance(model, str) else None)
+    if shift is not None and seed == 1234 and output_dim == 2 and net_size_max == 1024:
+        w['fc4.bias'] = (w['fc4.bias'] + np.asarray(shift, dtype=np.float32)).astype(np.float32)
+    cfg_out = dict(
+        use_point_stn=bool(cfg.get('use_point_stn', False)),
+        shared_transformer=bool(cfg.get('shared_transformation', False)),
+        use_feat_stn=True, single_transformer=False,
+        uniform_subsample=bool(cfg.get('uniform_subsample', False)), fixed_subsample=False,
+        net_size=net_size_max, points_per_patch=300, sub_sample_size=1000, output_dim=output_dim)
+    return w, cfg_out
+
+
+def to_torch_state_dict(w, module_prefix=True):
+    import torch
+    pre = 'module.' if module_prefix else ''
+    return {pre + k: torch.from_numpy(np.array(v)) for k, v in w.items()}
+
+
+def make_cloud(n_points=50000, seed=0, noise=0.004, kind='blob'):
+    """Noisy surface samples of an analytic solid, float32 [N,3], inside [-0.5,0.5]^3."""
+    rng = np.random.default_rng(seed)
+    if kind == 'sphere':
+        d = rng.standard_normal((n_points, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        p = 0.4 * d
+    else:
+        # star-shaped "blob": radius modulated by low-order harmonics (seeded), scan-like density
+        d = rng.standard_normal((n_points, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        ph = rng.uniform(0, 2 * np.pi, 6)
+        rad = 0.33 + 0.05 * np.sin(3 * np.arctan2(d[:, 1], d[:, 0]) + ph[0]) \
+            + 0.04 * np.cos(4 * np.arccos(np.clip(d[:, 2], -1, 1)) + ph[1]) \
+            + 0.03 * np.sin(5 * d[:, 0] + ph[2]) * np.cos(3 * d[:, 1] + ph[3])
+        p = d * rad[:, None]
+        p[:, 0] *= 1.15
+        p[:, 2] *= 0.85
+    p = p + noise * rng.standard_normal(p.shape)
+    # unit-cube normalisation like make_pc_dataset._to_unit_cube (bbox centre, max extent -> 1)
+    lo, hi = p.min(0), p.max(0)
+    p = (p - (lo + hi) / 2) / (hi - lo).max()
+    return np.ascontiguousarray(p.astype(np.float32))

@@ -1,0 +1,114 @@
+"""The numpy oracle (oracle/p2s_oracle.py) against vectors produced by the UNMODIFIED reference
+(oracle/make_golden.py -> tests/golden/).  CPU only."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import p2s_oracle as O
+from points2surf_amd import synth
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope='module')
+def meta(golden_dir):
+    with open(os.path.join(golden_dir, 'meta.json')) as f:
+        return json.load(f)
+
+
+def test_mt19937_matches_numpy_legacy_kat(golden_dir):
+    kat = np.load(os.path.join(golden_dir, 'numpy_legacy_rng_kat.npz'))
+    r = O.LegacyMT19937(40938661)
+    assert np.array_equal(r.randint(34693, 2000), kat['randint_34693'])
+    r = O.LegacyMT19937(40938661)
+    assert np.array_equal(r.rand(1000), kat['rand'])
+    r = O.LegacyMT19937(12345)
+    assert np.array_equal(r.randint(150000, 3000), kat['randint_150000'])
+
+
+def test_mt19937_matches_installed_numpy():
+    for seed, n in ((0, 1000), (42, 65536), (40938661, 65537), (2**32 - 1, 7)):
+        a = O.LegacyMT19937(seed)
+        b = np.random.RandomState(seed)
+        for size in (1, 1000, 13, 5000):
+            assert np.array_equal(a.randint(n, size), b.randint(0, n, size))
+    # chunk invariance: the stream is a pure function of the number of accepted draws
+    a = O.LegacyMT19937(7)
+    b = O.LegacyMT19937(7)
+    x = np.concatenate([a.randint(34693, 1000) for _ in range(5)])
+    assert np.array_equal(x, b.randint(34693, 5000))
+
+
+def test_choice_noreplace_matches_installed_numpy(fixture_cloud):
+    pts = fixture_cloud
+    q = np.array([0.1, -0.2, 0.05], dtype=np.float32)
+    p = O.dist_prob(pts, q)
+    a = O.LegacyMT19937(99)
+    b = np.random.RandomState(99)
+    for _ in range(2):
+        assert np.array_equal(a.choice_noreplace(pts.shape[0], 1000, p),
+                              b.choice(pts.shape[0], size=1000, replace=False, p=p))
+
+
+@pytest.mark.parametrize('res,eps', [(32, 3), (64, 3), (128, 3), (64, 4), (32, 5)])
+def test_query_grid_matches_reference(meta, fixture_cloud, res, eps):
+    q, vox = O.query_grid(fixture_cloud, res, eps)
+    g = meta['query_grids']['%d_%d' % (res, eps)]
+    assert q.shape[0] == g['count']
+    assert _sha(q) == g['sha256']
+    assert q.dtype == np.float32
+
+
+def test_query_grid_32_values(golden_dir, fixture_cloud):
+    q, _ = O.query_grid(fixture_cloud, 32, 3)
+    assert np.array_equal(q, np.load(os.path.join(golden_dir, 'query_grid_32_3.npy')))
+
+
+@pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
+def test_data_path_matches_reference(golden_dir, fixture_cloud, meta, model):
+    g = np.load(os.path.join(golden_dir, 'ref_%s_grid32.npz' % model))
+    nq = meta['nq']
+    q, _ = O.query_grid(fixture_cloud, 32, 3)
+    ids = O.knn_ids(fixture_cloud, q[:nq], 300)
+    assert np.array_equal(ids, g['knn_ids'])                      # same ids in the same (distance) order
+    r, ps = O.patch_radius_and_ps(fixture_cloud, ids, q[:nq])
+    assert np.array_equal(r, g['radius'])                         # bit-exact fp32
+    assert np.array_equal(ps[:4], g['patch_ps_head'])
+    w, cfg = synth.make_weights(model)
+    rng = O.LegacyMT19937(meta['seed_data'])
+    sub = np.stack([O.subsample_ids(rng, fixture_cloud, q[i], 1000, cfg['uniform_subsample']) for i in range(nq)])
+    assert np.array_equal(sub, g['sub_ids'])
+
+
+@pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
+def test_forward_matches_reference(golden_dir, fixture_cloud, meta, model):
+    g = np.load(os.path.join(golden_dir, 'ref_%s_grid32.npz' % model))
+    nq = 32
+    q, _ = O.query_grid(fixture_cloud, 32, 3)
+    w, cfg = synth.make_weights(model)
+    r, ps = O.patch_radius_and_ps(fixture_cloud, g['knn_ids'][:nq], q[:nq])
+    sub = fixture_cloud[g['sub_ids'][:nq]]
+    logits, fl, fg = O.model_forward(w, cfg, ps, sub, q[:nq], return_feats=True)
+    # fp32 summation order differs between numpy/BLAS and torch/oneDNN
+    assert np.abs(fl - g['feat_local'][:nq]).max() < 2e-4 * max(1.0, np.abs(g['feat_local']).max())
+    assert np.abs(fg - g['feat_global'][:nq]).max() < 2e-4 * max(1.0, np.abs(g['feat_global']).max())
+    assert np.abs(logits - g['logits'][:nq]).max() < 5e-5
+    sdf = O.post_process(logits, r)
+    # contractual bound is 1e-4 (BASELINE.json); fp32 re-association noise is ~2e-6 at this weight scale
+    assert np.abs(sdf - g['sdf_full'][:nq]).max() < 1e-5
+
+
+def test_end_to_end_prefix_matches_reference(golden_dir, fixture_cloud, meta):
+    """whole path a1..a9 incl. the RNG stream, first 96 queries of the shape (p2s_max)."""
+    g = np.load(os.path.join(golden_dir, 'ref_p2s_max_grid32.npz'))
+    w, cfg = synth.make_weights('p2s_max')
+    rng = O.LegacyMT19937(meta['seed_data'])
+    q, sdf = O.infer_shape(w, cfg, fixture_cloud, 32, 3, rng, query_range=(0, 96))
+    ref = g['sdf_full'][:96]
+    assert np.abs(sdf - ref).max() < 1e-5
+    assert np.array_equal(np.sign(sdf), np.sign(ref))
