@@ -1,0 +1,88 @@
+"""ctypes binding of libp2s_hip.so (include/p2s_hip.h).  There is NO fallback: if the library is
+missing or a call fails, an exception is raised."""
+import ctypes
+import os
+
+from .weights import ModelCfg, WeightOffsets
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libp2s_hip.so')
+
+P2S_OK = 0
+P2S_ECAPACITY = -4
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_int64 = ctypes.c_int64
+
+
+class Counters(ctypes.Structure):
+    """mirror of ``p2s_counters``"""
+    _fields_ = [('ms_chain_stn', ctypes.c_double), ('ms_stn_head', ctypes.c_double),
+                ('ms_chain_main', ctypes.c_double), ('ms_decoder', ctypes.c_double),
+                ('ms_knn', ctypes.c_double), ('ms_subsample', ctypes.c_double), ('ms_grid', ctypes.c_double),
+                ('queries', ctypes.c_int64), ('launches_chain', ctypes.c_int64),
+                ('reserved', ctypes.c_double * 8)]
+
+
+# name -> (restype, argtypes): every symbol include/p2s_hip.h declares
+PROTOTYPES = {
+    'p2s_abi_version': (c_int, []),
+    'p2s_last_error': (ctypes.c_char_p, []),
+    'p2s_device_count': (c_int, []),
+    'p2s_model_create': (c_int, [ctypes.POINTER(ModelCfg), c_void_p, ctypes.c_size_t,
+                                 ctypes.POINTER(WeightOffsets), c_int, ctypes.POINTER(c_void_p)]),
+    'p2s_model_destroy': (c_int, [c_void_p]),
+    'p2s_encode_decode': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                  c_void_p]),
+    'p2s_encode_features': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'p2s_cloud_create': (c_int, [c_void_p, c_int, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
+    'p2s_cloud_destroy': (c_int, [c_void_p]),
+    'p2s_cloud_num_points': (c_int, [c_void_p]),
+    'p2s_query_grid': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
+    'p2s_knn_patch': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'p2s_rng_create': (c_int, [ctypes.c_uint32, c_int, ctypes.POINTER(c_void_p)]),
+    'p2s_rng_destroy': (c_int, [c_void_p]),
+    'p2s_rng_get_state': (c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_int32), c_void_p]),
+    'p2s_rng_set_state': (c_int, [c_void_p, c_void_p, ctypes.c_int32, c_void_p]),
+    'p2s_subsample_uniform': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    'p2s_gather_points': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    'p2s_infer_shape': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_void_p,
+                                c_void_p, ctypes.POINTER(c_int64), c_void_p]),
+    'p2s_set_profiling': (c_int, [c_void_p, c_int]),
+    'p2s_get_counters': (c_int, [c_void_p, ctypes.POINTER(Counters)]),
+}
+
+
+class P2SError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('libp2s_hip error %d: %s' % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP engine.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            'libp2s_hip.so not found at %s -- build it with `python -m points2surf_amd.build` '
+            '(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)        # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, allow=()):
+    if rc != P2S_OK and rc not in allow:
+        msg = load().p2s_last_error()
+        raise P2SError(rc, msg.decode('utf-8', 'replace') if msg else '')
+    return rc

@@ -1,0 +1,357 @@
+// C-ABI glue: error reporting, model handle, workspace, the encoder/decoder pipeline.
+#include "p2s_common.h"
+#include "p2s_internal.h"
+#include <cstring>
+#include <algorithm>
+
+static thread_local char g_err[512] = "";
+
+void p2s_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int p2s_abi_version(void) { return P2S_ABI_VERSION; }
+const char *p2s_last_error(void) { return g_err; }
+
+int p2s_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_floats,
+                     const p2s_weight_offsets *offs, int device, p2s_model_t *out) {
+    if (!cfg || !blob_host || !offs || !out || n_floats == 0) {
+        p2s_set_error("p2s_model_create: null argument");
+        return P2S_EINVAL;
+    }
+    if (cfg->net_size != 1024 || cfg->output_dim != 2 || cfg->points_per_patch < 1 || cfg->sub_sample_size < 1) {
+        p2s_set_error("p2s_model_create: unsupported cfg (net_size=%d output_dim=%d)", cfg->net_size, cfg->output_dim);
+        return P2S_EINVAL;
+    }
+    if (cfg->use_point_stn && !cfg->shared_transformer) {
+        p2s_set_error("p2s_model_create: per-branch QSTN (use_point_stn without shared_transformer) unsupported");
+        return P2S_EINVAL;
+    }
+    if (p2s_device_count() <= device || device < 0) {
+        p2s_set_error("p2s_model_create: no HIP device %d", device);
+        return P2S_ENODEVICE;
+    }
+    P2S_HIP_CHECK(hipSetDevice(device));
+    p2s_model_s *m = new p2s_model_s();
+    m->cfg = *cfg;
+    m->offs = *offs;
+    m->device = device;
+    m->n_floats = n_floats;
+    hipError_t e = hipMalloc(&m->blob, n_floats * sizeof(float));
+    if (e != hipSuccess) {
+        delete m;
+        p2s_set_error("hipMalloc(weights) failed: %s", hipGetErrorString(e));
+        return P2S_ENOMEM;
+    }
+    e = hipMemcpy(m->blob, blob_host, n_floats * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(m->blob);
+        delete m;
+        p2s_set_error("hipMemcpy(weights) failed: %s", hipGetErrorString(e));
+        return P2S_EHIP;
+    }
+    for (auto &ev : m->ev) {
+        if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+    }
+    *out = m;
+    return P2S_OK;
+}
+
+int p2s_model_destroy(p2s_model_t m) {
+    if (!m) return P2S_OK;
+    (void)hipSetDevice(m->device);
+    if (m->ws) (void)hipFree(m->ws);
+    if (m->blob) (void)hipFree(m->blob);
+    for (auto &ev : m->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    delete m;
+    return P2S_OK;
+}
+
+int p2s_set_profiling(p2s_model_t m, int enabled) {
+    if (!m) return P2S_EINVAL;
+    m->profiling = enabled != 0;
+    return P2S_OK;
+}
+
+int p2s_get_counters(p2s_model_t m, p2s_counters *out) {
+    if (!m || !out) return P2S_EINVAL;
+    *out = m->counters;
+    return P2S_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+
+static size_t ws_floats_per_query(const p2s_model_s *m) {
+    size_t n = 2 * 1024 + 2 * 512 + 2 * 256 + 2 * 4096 + 2 * 4096 + 2 * 1024 + 1024 + 256 + 128;
+    if (m->cfg.use_point_stn) n += 1024 + 512 + 256 + 16;
+    return n;
+}
+
+int p2s_model_reserve(p2s_model_s *m, int chunk) {
+    if (chunk <= m->ws_chunk) return P2S_OK;
+    if (m->ws) {
+        P2S_HIP_CHECK(hipDeviceSynchronize());
+        (void)hipFree(m->ws);
+        m->ws = nullptr;
+        m->ws_chunk = 0;
+    }
+    const size_t n = ws_floats_per_query(m) * (size_t)chunk;
+    hipError_t e = hipMalloc(&m->ws, n * sizeof(float));
+    if (e != hipSuccess) {
+        p2s_set_error("hipMalloc(workspace %zu MB) failed: %s", n * 4 >> 20, hipGetErrorString(e));
+        return P2S_ENOMEM;
+    }
+    m->ws_chunk = chunk;
+    return P2S_OK;
+}
+
+namespace {
+
+struct Ws {
+    float *g_stn, *h1, *h2, *T, *w1p, *feat, *d1, *d2, *d3, *qg, *qh1, *qh2, *rot;
+};
+
+Ws carve(const p2s_model_s *m, int C) {
+    Ws w;
+    float *p = m->ws;
+    auto take = [&](size_t n) { float *r = p; p += n; return r; };
+    w.g_stn = take((size_t)2 * C * 1024);
+    w.h1 = take((size_t)2 * C * 512);
+    w.h2 = take((size_t)2 * C * 256);
+    w.T = take((size_t)2 * C * 4096);
+    w.w1p = take((size_t)2 * C * 4096);
+    w.feat = take((size_t)2 * C * 1024);
+    w.d1 = take((size_t)C * 1024);
+    w.d2 = take((size_t)C * 256);
+    w.d3 = take((size_t)C * 128);
+    w.qg = w.qh1 = w.qh2 = w.rot = nullptr;
+    if (m->cfg.use_point_stn) {
+        w.qg = take((size_t)C * 1024);
+        w.qh1 = take((size_t)C * 512);
+        w.qh2 = take((size_t)C * 256);
+        w.rot = take((size_t)C * 16);
+    }
+    return w;
+}
+
+struct StageTimer {
+    p2s_model_s *m;
+    hipStream_t s;
+    int idx = 0;
+    void mark() {
+        if (m->profiling && idx < (int)(sizeof(m->ev) / sizeof(m->ev[0])) && m->ev[idx]) (void)hipEventRecord(m->ev[idx], s);
+        ++idx;
+    }
+};
+
+}  // namespace
+
+// One chunk (C <= ws_chunk queries) through encoders (+ decoder if want_decode).
+int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const float *query, const float *radius,
+                  int C, float *logits_out, float *sdf_out, float *feat_local_out, float *feat_global_out,
+                  hipStream_t s) {
+    const p2s_weight_offsets &o = m->offs;
+    const float *W = m->blob;
+    const int PL = m->cfg.points_per_patch, PG = m->cfg.sub_sample_size;
+    Ws w = carve(m, C);
+    int rc;
+    StageTimer tm{m, s};
+    tm.mark();   // ev0
+
+    const float *rot = nullptr;
+    if (m->cfg.use_point_stn) {
+        // shared QSTN over cat(patch, sub-sample - q): reference points_to_surf_model.py:325-331, :100-131
+        ChainArgs a;
+        memset(&a, 0, sizeof(a));
+        ChainBranch &b = a.br[0];
+        b.ptsA = patch; b.ptsB = sub; b.center = query; b.rot = nullptr;
+        b.w0a = W + o.qstn.c1; b.b0a = W + o.qstn.cb1;
+        b.w0b = b.b0b = nullptr; b.w1 = W; b.b1 = nullptr; b.w1_item_stride = 0;
+        b.w2 = W + o.qstn.c2; b.b2 = W + o.qstn.cb2;
+        b.w3 = W + o.qstn.c3; b.b3 = W + o.qstn.cb3;
+        b.out = w.qg; b.P = PL + PG; b.P1 = PL; b.n_items = C; b.relu_out = 1; b.short_chain = 1;
+        a.br[1] = b;
+        a.br[1].n_items = 0;
+        if ((rc = p2s_launch_chain(a, s))) return rc;
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.A = w.qg; g.lda = 1024; g.a_z = 0; g.W[0] = g.W[1] = W + o.qstn.f1; g.bias[0] = g.bias[1] = W + o.qstn.fb1;
+        g.C = w.qh1; g.ldc = 512; g.c_z = 0; g.M = C; g.N = 512; g.K = 1024; g.Z = 1; g.relu = 1;
+        if ((rc = p2s_launch_gemm(g, s))) return rc;
+        g.A = w.qh1; g.lda = 512; g.W[0] = g.W[1] = W + o.qstn.f2; g.bias[0] = g.bias[1] = W + o.qstn.fb2;
+        g.C = w.qh2; g.ldc = 256; g.N = 256; g.K = 512;
+        if ((rc = p2s_launch_gemm(g, s))) return rc;
+        if ((rc = p2s_launch_qstn_tail(w.qh2, W + o.qstn.f3, W + o.qstn.fb3, w.rot, C, 256, s))) return rc;
+        rot = w.rot;
+    }
+
+    // ---- pass 1: stem + STN trunk + max-pool, both encoders (global items first: longest first) ----
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int slot = 0; slot < 2; ++slot) {
+        const int e = 1 - slot;   // slot 0 = feat_global (e=1), slot 1 = feat_local (e=0)
+        const p2s_encoder_offsets &eo = o.enc[e];
+        ChainBranch &b = a.br[slot];
+        if (e == 1) { b.ptsA = nullptr; b.ptsB = sub; b.center = query; b.P = PG; b.P1 = 0; }
+        else        { b.ptsA = patch; b.ptsB = nullptr; b.center = nullptr; b.P = PL; b.P1 = PL; }
+        b.rot = rot;
+        b.w0a = W + eo.w0a; b.b0a = W + eo.b0a; b.w0b = W + eo.w0b; b.b0b = W + eo.b0b;
+        b.w1 = W + eo.s1; b.b1 = W + eo.sb1; b.w1_item_stride = 0;
+        b.w2 = W + eo.s2; b.b2 = W + eo.sb2; b.w3 = W + eo.s3; b.b3 = W + eo.sb3;
+        b.out = w.g_stn + (size_t)e * C * 1024;
+        b.n_items = C; b.relu_out = 1; b.short_chain = 0;
+    }
+    if ((rc = p2s_launch_chain(a, s))) return rc;
+    tm.mark();   // ev1
+
+    // ---- STN head: 1024 -> 512 -> 256 -> 4096 (+I), then W1' = W1 . trans2 -------------------------
+    {
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.M = C; g.Z = 2; g.relu = 1;
+        g.A = w.g_stn; g.lda = 1024; g.a_z = (long long)C * 1024;
+        g.W[0] = W + o.enc[0].sf1; g.W[1] = W + o.enc[1].sf1; g.bias[0] = W + o.enc[0].sfb1; g.bias[1] = W + o.enc[1].sfb1;
+        g.C = w.h1; g.ldc = 512; g.c_z = (long long)C * 512; g.N = 512; g.K = 1024;
+        if ((rc = p2s_launch_gemm(g, s))) return rc;
+        g.A = w.h1; g.lda = 512; g.a_z = (long long)C * 512;
+        g.W[0] = W + o.enc[0].sf2; g.W[1] = W + o.enc[1].sf2; g.bias[0] = W + o.enc[0].sfb2; g.bias[1] = W + o.enc[1].sfb2;
+        g.C = w.h2; g.ldc = 256; g.c_z = (long long)C * 256; g.N = 256; g.K = 512;
+        if ((rc = p2s_launch_gemm(g, s))) return rc;
+        g.A = w.h2; g.lda = 256; g.a_z = (long long)C * 256; g.relu = 0;
+        g.W[0] = W + o.enc[0].sf3; g.W[1] = W + o.enc[1].sf3; g.bias[0] = W + o.enc[0].sfb3; g.bias[1] = W + o.enc[1].sfb3;
+        g.C = w.T; g.ldc = 4096; g.c_z = (long long)C * 4096; g.N = 4096; g.K = 256;
+        if ((rc = p2s_launch_gemm(g, s))) return rc;
+        FoldArgs f;
+        for (int e = 0; e < 2; ++e) {
+            f.T[e] = w.T + (size_t)e * C * 4096;
+            f.m1t[e] = W + o.enc[e].m1t;
+            f.out[e] = w.w1p + (size_t)e * C * 4096;
+        }
+        f.n_items = C;
+        if ((rc = p2s_launch_fold(f, s))) return rc;
+    }
+    tm.mark();   // ev2
+
+    // ---- pass 2: stem (recomputed) + transformed conv1 + conv2 + conv3 + max-pool -------------------
+    for (int slot = 0; slot < 2; ++slot) {
+        const int e = 1 - slot;
+        const p2s_encoder_offsets &eo = o.enc[e];
+        ChainBranch &b = a.br[slot];
+        b.w1 = w.w1p + (size_t)e * C * 4096; b.b1 = W + eo.mb1; b.w1_item_stride = 4096;
+        b.w2 = W + eo.m2; b.b2 = W + eo.mb2; b.w3 = W + eo.m3; b.b3 = W + eo.mb3;
+        b.out = w.feat + (size_t)e * C * 1024;
+        b.relu_out = 0;
+    }
+    if ((rc = p2s_launch_chain(a, s))) return rc;
+    tm.mark();   // ev3
+    m->counters.launches_chain += 2;
+
+    if (feat_local_out) P2S_HIP_CHECK(hipMemcpyAsync(feat_local_out, w.feat, (size_t)C * 1024 * 4, hipMemcpyDeviceToDevice, s));
+    if (feat_global_out)
+        P2S_HIP_CHECK(hipMemcpyAsync(feat_global_out, w.feat + (size_t)C * 1024, (size_t)C * 1024 * 4, hipMemcpyDeviceToDevice, s));
+
+    if (logits_out || sdf_out) {
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.M = C; g.relu = 1;
+        // fc1_local | fc1_global -> cat (local first): reference points_to_surf_model.py:335,343,346
+        g.Z = 2; g.A = w.feat; g.lda = 1024; g.a_z = (long long)C * 1024;
+        g.W[0] = W + o.d1l; g.W[1] = W + o.d1g; g.bias[0] = W + o.db1l; g.bias[1] = W + o.db1g;
+        g.C = w.d1; g.ldc = 1024; g.c_z = 512; g.N = 512; g.K = 1024;
+        if ((rc = p2s_launch_gemm(g, s))) return rc;
+        g.Z = 1; g.A = w.d1; g.lda = 1024; g.a_z = 0; g.W[0] = g.W[1] = W + o.d2; g.bias[0] = g.bias[1] = W + o.db2;
+        g.C = w.d2; g.ldc = 256; g.c_z = 0; g.N = 256; g.K = 1024;
+        if ((rc = p2s_launch_gemm(g, s))) return rc;
+        g.A = w.d2; g.lda = 256; g.W[0] = g.W[1] = W + o.d3; g.bias[0] = g.bias[1] = W + o.db3;
+        g.C = w.d3; g.ldc = 128; g.N = 128; g.K = 256;
+        if ((rc = p2s_launch_gemm(g, s))) return rc;
+        if ((rc = p2s_launch_decoder_tail(w.d3, W + o.d4, W + o.db4, radius, logits_out, sdf_out, C, 128, s))) return rc;
+    }
+    tm.mark();   // ev4
+    m->prof_pending = m->profiling;
+    return P2S_OK;
+}
+
+void p2s_collect_profile(p2s_model_s *m) {
+    if (!m->prof_pending) return;
+    m->prof_pending = false;
+    float ms = 0.f;
+    if (m->ev[4] && hipEventSynchronize(m->ev[4]) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, m->ev[0], m->ev[1]) == hipSuccess) m->counters.ms_chain_stn += ms;
+        if (hipEventElapsedTime(&ms, m->ev[1], m->ev[2]) == hipSuccess) m->counters.ms_stn_head += ms;
+        if (hipEventElapsedTime(&ms, m->ev[2], m->ev[3]) == hipSuccess) m->counters.ms_chain_main += ms;
+        if (hipEventElapsedTime(&ms, m->ev[3], m->ev[4]) == hipSuccess) m->counters.ms_decoder += ms;
+    }
+    (void)hipGetLastError();
+}
+
+static int run_batched(p2s_model_s *m, const float *patch, const float *sub, const float *query, const float *radius,
+                       int B, float *logits, float *sdf, float *fl, float *fg, hipStream_t s) {
+    if (!m || B < 0 || !patch || !sub || !query) {
+        p2s_set_error("encode: null argument");
+        return P2S_EINVAL;
+    }
+    if (sdf && !radius) {
+        p2s_set_error("encode: sdf_out requested without radius");
+        return P2S_EINVAL;
+    }
+    P2S_HIP_CHECK(hipSetDevice(m->device));
+    const int chunk = std::min(B, m->max_chunk);
+    int rc = p2s_model_reserve(m, chunk);
+    if (rc) return rc;
+    const int PL = m->cfg.points_per_patch, PG = m->cfg.sub_sample_size;
+    if (m->profiling) memset(&m->counters, 0, sizeof(m->counters));
+    for (int q0 = 0; q0 < B; q0 += chunk) {
+        const int C = std::min(chunk, B - q0);
+        if (m->profiling && q0 > 0) p2s_collect_profile(m);   // events are reused per chunk
+        rc = p2s_run_chunk(m, patch + (size_t)q0 * PL * 3, sub + (size_t)q0 * PG * 3, query + (size_t)q0 * 3,
+                           radius ? radius + q0 : nullptr, C, logits ? logits + (size_t)q0 * 2 : nullptr,
+                           sdf ? sdf + q0 : nullptr, fl ? fl + (size_t)q0 * 1024 : nullptr,
+                           fg ? fg + (size_t)q0 * 1024 : nullptr, s);
+        if (rc) return rc;
+    }
+    if (m->profiling) p2s_collect_profile(m);
+    m->counters.queries += B;
+    return P2S_OK;
+}
+
+extern "C" {
+
+int p2s_encode_decode(p2s_model_t m, const float *patch_ps_dev, const float *sub_ms_dev, const float *query_dev,
+                      const float *radius_dev, int B, float *logits_out_dev, float *sdf_out_dev, void *stream) {
+    if (!logits_out_dev && !sdf_out_dev) {
+        p2s_set_error("p2s_encode_decode: no output requested");
+        return P2S_EINVAL;
+    }
+    return run_batched(m, patch_ps_dev, sub_ms_dev, query_dev, radius_dev, B, logits_out_dev, sdf_out_dev, nullptr,
+                       nullptr, (hipStream_t)stream);
+}
+
+int p2s_encode_features(p2s_model_t m, const float *patch_ps_dev, const float *sub_ms_dev, const float *query_dev,
+                        int B, float *feat_local_dev, float *feat_global_dev, void *stream) {
+    if (!feat_local_dev && !feat_global_dev) {
+        p2s_set_error("p2s_encode_features: no output requested");
+        return P2S_EINVAL;
+    }
+    return run_batched(m, patch_ps_dev, sub_ms_dev, query_dev, nullptr, B, nullptr, nullptr, feat_local_dev,
+                       feat_global_dev, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -200,26 +200,40 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
                 const float *wb0 = w3 + (long long)((8 * wave + 2 * pr) * 16) * 256 + lane * 4;
                 const float *wb1 = wb0 + 16 * 256;
                 f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
-                f32x4 b0 = ldg4(wb0), b1 = ldg4(wb1);
-#pragma unroll
-                for (int kg = 0; kg < 16; ++kg) {
-                    f32x4 nb0 = b0, nb1 = b1;
-                    if (kg < 15) {
-                        nb0 = ldg4(wb0 + (kg + 1) * 256);
-                        nb1 = ldg4(wb1 + (kg + 1) * 256);
-                    }
-                    const f32x4 a0 = lds4(a0p + 8 * kg);
-                    const f32x4 a1 = lds4(a1p + 8 * kg);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        c00 = mfma32(a0[t], b0[t], c00);
-                        c01 = mfma32(a0[t], b1[t], c01);
-                        c10 = mfma32(a1[t], b0[t], c10);
-                        c11 = mfma32(a1[t], b1[t], c11);
-                    }
-                    b0 = nb0;
-                    b1 = nb1;
+                // explicit ping-pong pipeline: the operands of the next k-group are in flight while the
+                // 16 MFMAs (1024 cycles) of the current one issue (2x unrolled, two register sets).
+#define P2S_MFMA16(A0, A1, B0, B1)                                   \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                  \
+        c00 = mfma32(A0[t], B0[t], c00);                             \
+        c01 = mfma32(A0[t], B1[t], c01);                             \
+        c10 = mfma32(A1[t], B0[t], c10);                             \
+        c11 = mfma32(A1[t], B1[t], c11);                             \
+    }
+                f32x4 bA0 = ldg4(wb0), bA1 = ldg4(wb1);
+                f32x4 aA0 = lds4(a0p), aA1 = lds4(a1p);
+#pragma unroll 1
+                for (int kg = 0; kg < 16; kg += 2) {
+                    f32x4 bB0 = ldg4(wb0 + (kg + 1) * 256);
+                    f32x4 bB1 = ldg4(wb1 + (kg + 1) * 256);
+                    f32x4 aB0 = lds4(a0p + 8 * (kg + 1));
+                    f32x4 aB1 = lds4(a1p + 8 * (kg + 1));
+                    P2S_MFMA16(aA0, aA1, bA0, bA1)
+                    const int kn = (kg + 2 < 16) ? kg + 2 : kg;   // last: harmless re-load
+                    bA0 = ldg4(wb0 + kn * 256);
+                    bA1 = ldg4(wb1 + kn * 256);
+                    aA0 = lds4(a0p + 8 * kn);
+                    aA1 = lds4(a1p + 8 * kn);
+                    P2S_MFMA16(aB0, aB1, bB0, bB1)
+                    // pin the issue order: next operands first, then the MFMA block that hides them
+                    // (the default scheduler sinks every load to just before its first use)
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // 2 VMEM reads
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // 16 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
                 }
+#undef P2S_MFMA16
                 float m0 = tile_colmax(c00, c10);
                 float m1 = tile_colmax(c01, c11);
                 m0 = fmaxf(m0, __shfl_xor(m0, 32));

@@ -1,0 +1,792 @@
+// Data path of the SDF inference on the device (gfx950): everything the reference does on CPU worker
+// processes per query (source/data_loader.py:322-421) runs here from the HBM-resident cloud.
+//
+//   a1  query grid        source/sdf.py:46-79           voxel bitmask -> box dilation -> ordered compaction
+//   a2  cell index        source/data_loader.py:40-42   uniform cell grid + 3-D summed-area table
+//                                                       (replaces cKDTree(leaf_size=1000))
+//   a4  kNN (fp64 rank)   source/base/point_cloud.py:170-175
+//   a5  radius / patch    source/base/utils.py:62-69,80-88; source/data_loader.py:341-350 (fp32, no FMA)
+//   a6  uniform subsample source/base/utils.py:196-227 + numpy legacy MT19937 masked rejection
+//
+// These stages are integer / select / gather work bound by L2 + LDS latency (the cloud, <= 1.8 MB, is
+// L2/MALL resident); they are deliberately NOT reshaped into GEMMs.
+#include "p2s_common.h"
+#include "p2s_internal.h"
+#include <vector>
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+
+// ---------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------
+struct CloudDev {
+    const float *pts;        // [n][3] original order (owned copy)
+    const float4 *spts;      // [n] sorted by cell: xyz + original id (bit cast)
+    const int *cell_start;   // [G^3 + 1]
+    const int *sat;          // [(G+1)^3] inclusive 3-D prefix sums of the per-cell counts
+    float lo[3];
+    float inv_cell;
+    int G;
+    int n;
+};
+
+struct p2s_cloud_s {
+    int device = 0;
+    CloudDev d = {};
+    float *pts = nullptr;
+    float4 *spts = nullptr;
+    int *cell_start = nullptr;
+    int *sat = nullptr;
+    // query-grid scratch (grown on demand)
+    uint32_t *occ = nullptr;
+    size_t occ_words = 0;
+    int *blk_cnt = nullptr;
+    size_t blk_cap = 0;
+    long long *totals = nullptr;   // [2] device: total count, error flag
+};
+
+struct p2s_rng_s {
+    int device = 0;
+    uint32_t *state = nullptr;   // [624] mt + [1] pos
+};
+
+namespace {
+
+__host__ __device__ inline int cell_coord(float x, float lo, float inv, int G) {
+    // monotone non-decreasing in x (needed for the conservative range computation below)
+    float f = floorf((x - lo) * inv);
+    int c = (f < 0.f) ? 0 : (f > (float)(G - 1) ? G - 1 : (int)f);
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a1: query grid
+// ---------------------------------------------------------------------------------------------
+__global__ void p2s_voxelize_kernel(const float *__restrict__ pts, int n, int res, uint32_t *__restrict__ occ,
+                                    long long *__restrict__ totals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int v[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        // fp32 exactly as numpy: floor(((p + 1.0) / 2.0) * res)   (source/sdf.py:73-75)
+        const float t = __fdiv_rn(__fadd_rn(pts[3 * i + a], 1.0f), 2.0f);
+        v[a] = (int)floorf(__fmul_rn(t, (float)res));
+    }
+    if (v[0] < 0 || v[1] < 0 || v[2] < 0 || v[0] >= res || v[1] >= res || v[2] >= res) {
+        totals[1] = 1;   // numpy would raise IndexError (or wrap a negative index)
+        return;
+    }
+    const long long lin = ((long long)v[0] * res + v[1]) * res + v[2];
+    atomicOr(&occ[lin >> 5], 1u << (lin & 31));
+}
+
+struct GridOffsets {
+    int n;
+    int o[16];
+};
+
+__device__ __forceinline__ bool near_surface(const uint32_t *__restrict__ occ, int res, int x, int y, int z,
+                                             const GridOffsets &go) {
+    // box filter of a 0/1 volume with edge replication == OR over the index-clamped neighbourhood
+    for (int ix = 0; ix < go.n; ++ix) {
+        const int xx = min(max(x + go.o[ix], 0), res - 1);
+        for (int iy = 0; iy < go.n; ++iy) {
+            const int yy = min(max(y + go.o[iy], 0), res - 1);
+            const long long row = ((long long)xx * res + yy) * res;
+            for (int iz = 0; iz < go.n; ++iz) {
+                const int zz = min(max(z + go.o[iz], 0), res - 1);
+                const long long lin = row + zz;
+                if ((occ[lin >> 5] >> (lin & 31)) & 1u) return true;
+            }
+        }
+    }
+    return false;
+}
+
+// pass 0: per-block counts; pass 1: ordered write using the scanned block offsets
+template <int PASS>
+__global__ __launch_bounds__(256) void p2s_grid_compact_kernel(const uint32_t *__restrict__ occ, int res,
+                                                               GridOffsets go, int *__restrict__ blk_cnt,
+                                                               const long long *__restrict__ blk_off,
+                                                               float *__restrict__ q_out, long long capacity) {
+    __shared__ int wsum[4];
+    const int rm = res - 1;                                   // the reference drops the last slab: [:-1,:-1,:-1]
+    const long long total = (long long)rm * rm * rm;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    bool flag = false;
+    int x = 0, y = 0, z = 0;
+    if (i < total) {
+        z = (int)(i % rm);
+        const long long t = i / rm;
+        y = (int)(t % rm);
+        x = (int)(t / rm);
+        flag = near_surface(occ, res, x, y, z, go);
+    }
+    const unsigned long long m = __ballot(flag);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    if (PASS == 0) {
+        if (threadIdx.x == 0) blk_cnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        return;
+    }
+    if (!flag) return;
+    int before = __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    const long long dst = blk_off[blockIdx.x] + before;
+    if (dst >= capacity) return;
+    // centre: float32(((idx + 0.5) / res) * 2 - 1) evaluated in float64 (source/sdf.py:78-79,70)
+    q_out[3 * dst + 0] = (float)((((double)x + 0.5) / (double)res) * 2.0 - 1.0);
+    q_out[3 * dst + 1] = (float)((((double)y + 0.5) / (double)res) * 2.0 - 1.0);
+    q_out[3 * dst + 2] = (float)((((double)z + 0.5) / (double)res) * 2.0 - 1.0);
+}
+
+// exclusive scan of the block counts (one workgroup, sequential over chunks of 1024)
+__global__ __launch_bounds__(1024) void p2s_scan_blocks_kernel(const int *__restrict__ cnt, long long nblk,
+                                                               long long *__restrict__ off,
+                                                               long long *__restrict__ totals) {
+    __shared__ long long part[16];
+    __shared__ long long carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (long long base = 0; base < nblk; base += 1024) {
+        const long long i = base + threadIdx.x;
+        const long long v = (i < nblk) ? cnt[i] : 0;
+        long long s = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long t = __shfl_up(s, d);
+            if (lane >= d) s += t;
+        }
+        if (lane == 63) part[wave] = s;
+        __syncthreads();
+        long long wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += part[w];
+        if (i < nblk) off[i] = carry + wbase + s - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += wbase + s;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[0] = carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a4/a5: exact k-nearest neighbours (float64 ranking) + radius + patch space, one wave per query
+// ---------------------------------------------------------------------------------------------
+constexpr int KNN_CAP = 2048;
+
+__device__ __forceinline__ int sat_at(const CloudDev &c, int x, int y, int z) {
+    const int G1 = c.G + 1;
+    return c.sat[(x * G1 + y) * G1 + z];
+}
+// number of points in cells [lo, hi] (inclusive)
+__device__ __forceinline__ int box_count(const CloudDev &c, const int lo[3], const int hi[3]) {
+    const int x0 = lo[0], y0 = lo[1], z0 = lo[2], x1 = hi[0] + 1, y1 = hi[1] + 1, z1 = hi[2] + 1;
+    return sat_at(c, x1, y1, z1) - sat_at(c, x0, y1, z1) - sat_at(c, x1, y0, z1) - sat_at(c, x1, y1, z0) +
+           sat_at(c, x0, y0, z1) + sat_at(c, x0, y1, z0) + sat_at(c, x1, y0, z0) - sat_at(c, x0, y0, z0);
+}
+
+// single-wave bitonic sort of (key, id) pairs in LDS; n2 = power of two
+__device__ void wave_bitonic_sort(unsigned long long *keys, int *ids, int n2, int lane) {
+    for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = lane; i < (n2 >> 1); i += 64) {
+                const int a = 2 * i - (i & (stride - 1));
+                const int b = a + stride;
+                const bool up = (a & size) == 0;
+                const unsigned long long ka = keys[a], kb = keys[b];
+                const int ia = ids[a], ib = ids[b];
+                const bool gt = (ka > kb) || (ka == kb && ia > ib);
+                if (gt == up) {
+                    keys[a] = kb; keys[b] = ka;
+                    ids[a] = ib; ids[b] = ia;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+struct KnnList {
+    unsigned long long *keys;
+    int *ids;
+    int len;
+    double thr2;
+    int k;
+};
+
+// sort the list; keep the k smallest; tighten the acceptance threshold
+__device__ void knn_prune(KnnList &L, int lane) {
+    int n2 = 64;
+    while (n2 < L.len) n2 <<= 1;
+    __syncthreads();
+    for (int i = L.len + lane; i < n2; i += 64) {
+        L.keys[i] = ~0ull;
+        L.ids[i] = 0x7fffffff;
+    }
+    wave_bitonic_sort(L.keys, L.ids, n2, lane);
+    if (L.len >= L.k) {
+        L.len = L.k;
+        L.thr2 = __longlong_as_double((long long)L.keys[L.k - 1]);
+    }
+}
+
+// scan cells [lo, hi]; if has_ex, cells inside [exlo, exhi] were scanned before and are skipped
+__device__ void knn_scan(const CloudDev &c, KnnList &L, const int lo[3], const int hi[3], bool has_ex,
+                         const int exlo[3], const int exhi[3], double qx, double qy, double qz, int lane) {
+    const int G = c.G;
+    for (int cx = lo[0]; cx <= hi[0]; ++cx) {
+        for (int cy = lo[1]; cy <= hi[1]; ++cy) {
+            const bool inside_xy = has_ex && cx >= exlo[0] && cx <= exhi[0] && cy >= exlo[1] && cy <= exhi[1];
+            const int nseg = inside_xy ? 2 : 1;
+            for (int sgi = 0; sgi < nseg; ++sgi) {
+                int za, zb;
+                if (!inside_xy) { za = lo[2]; zb = hi[2]; }
+                else if (sgi == 0) { za = lo[2]; zb = exlo[2] - 1; }
+                else { za = exhi[2] + 1; zb = hi[2]; }
+                if (za > zb) continue;
+                const int rowbase = (cx * G + cy) * G;
+                const int start = c.cell_start[rowbase + za];
+                const int end = c.cell_start[rowbase + zb + 1];
+                for (int base = start; base < end; base += 64) {
+                    const int i = base + lane;
+                    bool keep = false;
+                    unsigned long long key = 0;
+                    int id = 0;
+                    if (i < end) {
+                        const float4 p = c.spts[i];
+                        const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
+                        const double d2 = dx * dx + dy * dy + dz * dz;
+                        keep = d2 <= L.thr2;
+                        key = (unsigned long long)__double_as_longlong(d2);
+                        id = __float_as_int(p.w);
+                    }
+                    const unsigned long long m = __ballot(keep);
+                    if (keep) {
+                        const int off = L.len + __popcll(m & ((1ull << lane) - 1ull));
+                        L.keys[off] = key;
+                        L.ids[off] = id;
+                    }
+                    L.len += __popcll(m);
+                    if (L.len > KNN_CAP - 64) knn_prune(L, lane);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void p2s_knn_kernel(CloudDev c, const float *__restrict__ queries, long long nq,
+                                                     int k, int *__restrict__ ids_out,
+                                                     float *__restrict__ patch_out,
+                                                     float *__restrict__ radius_out) {
+    __shared__ unsigned long long keys[KNN_CAP];
+    __shared__ int lids[KNN_CAP];
+    const int lane = threadIdx.x;
+    const int G = c.G;
+    for (long long qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+        const float qxf = queries[3 * qi + 0], qyf = queries[3 * qi + 1], qzf = queries[3 * qi + 2];
+        const double qx = qxf, qy = qyf, qz = qzf;
+        const int cq[3] = {cell_coord(qxf, c.lo[0], c.inv_cell, G), cell_coord(qyf, c.lo[1], c.inv_cell, G),
+                           cell_coord(qzf, c.lo[2], c.inv_cell, G)};
+        // smallest cube of cells around the query's cell that holds >= k points (O(1) per try via the SAT)
+        int lo[3], hi[3];
+        for (int rho = 0;; ++rho) {
+            bool all = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = max(cq[a] - rho, 0);
+                hi[a] = min(cq[a] + rho, G - 1);
+                all = all && lo[a] == 0 && hi[a] == G - 1;
+            }
+            if (all || box_count(c, lo, hi) >= k) break;
+        }
+        KnnList L{keys, lids, 0, INFINITY, k};
+        __syncthreads();
+        knn_scan(c, L, lo, hi, false, lo, hi, qx, qy, qz, lane);
+        knn_prune(L, lane);   // exact k-th distance among the cube's points: an upper bound of the true one
+        // every point within sqrt(thr2) of q lies in cells [lo2, hi2] (conservative: radius rounded up, and
+        // cell_coord is monotone)
+        const float r = (float)sqrt(L.thr2) * 1.00001f + 1e-30f;
+        int lo2[3], hi2[3];
+        const float qf[3] = {qxf, qyf, qzf};
+        bool grow = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo2[a] = min(lo[a], cell_coord(qf[a] - r, c.lo[a], c.inv_cell, G));
+            hi2[a] = max(hi[a], cell_coord(qf[a] + r, c.lo[a], c.inv_cell, G));
+            grow = grow || lo2[a] != lo[a] || hi2[a] != hi[a];
+        }
+        if (grow) {
+            const int before = L.len;
+            knn_scan(c, L, lo2, hi2, true, lo, hi, qx, qy, qz, lane);
+            if (L.len != before) knn_prune(L, lane);
+        }
+        __syncthreads();
+        // ---- outputs: ids (ascending distance), r = max ||q - p||_2 (fp32, numpy op order), (p - q) / r ----
+        float smax = 0.0f;
+        for (int j = lane; j < k; j += 64) {
+            const int id = lids[j];
+            if (ids_out) ids_out[qi * k + j] = id;
+            const float dx = __fsub_rn(qxf, c.pts[3 * id + 0]);
+            const float dy = __fsub_rn(qyf, c.pts[3 * id + 1]);
+            const float dz = __fsub_rn(qzf, c.pts[3 * id + 2]);
+            const float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            smax = fmaxf(smax, s);
+        }
+        for (int d = 32; d > 0; d >>= 1) smax = fmaxf(smax, __shfl_xor(smax, d));
+        const float rad = __fsqrt_rn(smax);   // sqrt is monotone: max_i sqrt(s_i) == sqrt(max_i s_i)
+        if (radius_out && lane == 0) radius_out[qi] = rad;
+        if (patch_out) {
+            for (int j = lane; j < k; j += 64) {
+                const int id = lids[j];
+                float *dst = patch_out + (qi * k + j) * 3;
+                dst[0] = __fdiv_rn(__fsub_rn(c.pts[3 * id + 0], qxf), rad);
+                dst[1] = __fdiv_rn(__fsub_rn(c.pts[3 * id + 1], qyf), rad);
+                dst[2] = __fdiv_rn(__fsub_rn(c.pts[3 * id + 2], qzf), rad);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a6: numpy legacy RandomState.randint(0, N, size) on the device: MT19937 + masked rejection +
+// ordered compaction.  One workgroup walks the stream block by block (the recurrence is serial
+// across 624-word blocks; inside a block it has three internally parallel phases).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mt_mix(uint32_t u, uint32_t v) {
+    const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+__global__ __launch_bounds__(256) void p2s_mt_randint_kernel(uint32_t *__restrict__ state, uint32_t rng,
+                                                             uint32_t mask, long long target,
+                                                             int32_t *__restrict__ out) {
+    __shared__ uint32_t mt[624];
+    __shared__ int wcnt[4];
+    __shared__ int s_newpos;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 624; i += 256) mt[i] = state[i];
+    int pos = (int)state[624];
+    __syncthreads();
+    long long produced = 0;
+    bool first = true;
+    while (produced < target) {
+        int start = 0;
+        if (first && pos < 624) {
+            start = pos;
+        } else {
+            // ---- twist: three dependent phases, each "read operands, barrier, write" ------------------
+            uint32_t v = 0;
+            if (tid < 227) v = mt[tid + 397] ^ mt_mix(mt[tid], mt[tid + 1]);
+            __syncthreads();
+            if (tid < 227) mt[tid] = v;
+            __syncthreads();
+            if (tid < 227) v = mt[tid] ^ mt_mix(mt[tid + 227], mt[tid + 228]);
+            __syncthreads();
+            if (tid < 227) mt[tid + 227] = v;
+            __syncthreads();
+            if (tid < 169) v = mt[tid + 227] ^ mt_mix(mt[tid + 454], mt[tid + 455]);
+            __syncthreads();
+            if (tid < 169) mt[tid + 454] = v;
+            __syncthreads();
+            if (tid == 0) mt[623] = mt[396] ^ mt_mix(mt[623], mt[0]);
+            __syncthreads();
+        }
+        first = false;
+        // ---- temper + masked rejection; thread t owns words 3t..3t+2 (t < 208) -----------------------
+        uint32_t w[3];
+        bool ok[3];
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = 3 * tid + j;
+            ok[j] = false;
+            w[j] = 0;
+            if (idx < 624 && idx >= start) {
+                w[j] = mt_temper(mt[idx]) & mask;
+                ok[j] = w[j] <= rng;
+            }
+            c += ok[j] ? 1 : 0;
+        }
+        int incl = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wcnt[wave] = incl;
+        if (tid == 0) s_newpos = 624;
+        __syncthreads();
+        int wbase = 0, total = 0;
+        for (int wv = 0; wv < 4; ++wv) {
+            if (wv < wave) wbase += wcnt[wv];
+            total += wcnt[wv];
+        }
+        const long long need = target - produced;            // > 0
+        int rank = wbase + incl - c;                         // exclusive rank of this thread's first accept
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (ok[j]) {
+                if (rank < need) {
+                    out[produced + rank] = (int32_t)w[j];
+                    if (rank == need - 1) s_newpos = 3 * tid + j + 1;   // stream resumes after this word
+                }
+                ++rank;
+            }
+        }
+        __syncthreads();
+        if (total >= need) {
+            pos = s_newpos;
+            produced = target;
+        } else {
+            pos = 624;
+            produced += total;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < 624; i += 256) state[i] = mt[i];
+    if (tid == 0) state[624] = (uint32_t)pos;
+}
+
+__global__ void p2s_gather_kernel(const float *__restrict__ pts, const int32_t *__restrict__ ids, long long n,
+                                  int n_points, float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int id = ids[i];
+    id = min(max(id, 0), n_points - 1);
+    out[3 * i + 0] = pts[3 * id + 0];
+    out[3 * i + 1] = pts[3 * id + 1];
+    out[3 * i + 2] = pts[3 * id + 2];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int p2s_cloud_create(const float *pts_dev, int n, int device, void *stream, p2s_cloud_t *out) {
+    if (!pts_dev || n < 1 || !out) {
+        p2s_set_error("p2s_cloud_create: bad argument (n=%d)", n);
+        return P2S_EINVAL;
+    }
+    if (p2s_device_count() <= device || device < 0) {
+        p2s_set_error("p2s_cloud_create: no HIP device %d", device);
+        return P2S_ENODEVICE;
+    }
+    P2S_HIP_CHECK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<float> h((size_t)n * 3);
+    P2S_HIP_CHECK(hipMemcpyAsync(h.data(), pts_dev, h.size() * 4, hipMemcpyDeviceToHost, s));
+    P2S_HIP_CHECK(hipStreamSynchronize(s));
+
+    // uniform cell grid over the bounding box; ~10 points per occupied cell for surface-like clouds
+    float lo[3] = {h[0], h[1], h[2]}, hi[3] = {h[0], h[1], h[2]};
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const float v = h[3 * (size_t)i + a];
+            if (!(v == v) || std::isinf(v)) {
+                p2s_set_error("p2s_cloud_create: non-finite coordinate at point %d", i);
+                return P2S_EINVAL;
+            }
+            lo[a] = std::min(lo[a], v);
+            hi[a] = std::max(hi[a], v);
+        }
+    int G = (int)std::ceil(std::sqrt((double)n / 32.0));
+    G = std::max(4, std::min(G, 128));
+    float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+    if (!(ext > 0.f)) ext = 1.0f;
+    const float cell = ext / (float)G * 1.0001f;
+    const float inv = 1.0f / cell;
+
+    const size_t ncell = (size_t)G * G * G;
+    std::vector<int> cnt(ncell + 1, 0), cid((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const int cx = cell_coord(h[3 * (size_t)i + 0], lo[0], inv, G);
+        const int cy = cell_coord(h[3 * (size_t)i + 1], lo[1], inv, G);
+        const int cz = cell_coord(h[3 * (size_t)i + 2], lo[2], inv, G);
+        cid[i] = (cx * G + cy) * G + cz;
+        cnt[cid[i]]++;
+    }
+    const int G1 = G + 1;
+    std::vector<int> sat((size_t)G1 * G1 * G1, 0);
+    for (int x = 1; x <= G; ++x)
+        for (int y = 1; y <= G; ++y) {
+            int run = 0;
+            for (int z = 1; z <= G; ++z) {
+                run += cnt[((size_t)(x - 1) * G + (y - 1)) * G + (z - 1)];
+                sat[((size_t)x * G1 + y) * G1 + z] = run + sat[((size_t)(x - 1) * G1 + y) * G1 + z] +
+                                                     sat[((size_t)x * G1 + (y - 1)) * G1 + z] -
+                                                     sat[((size_t)(x - 1) * G1 + (y - 1)) * G1 + z];
+            }
+        }
+    std::vector<int> start(ncell + 1);
+    {
+        int acc = 0;
+        for (size_t c = 0; c < ncell; ++c) {
+            start[c] = acc;
+            acc += cnt[c];
+        }
+        start[ncell] = acc;
+    }
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    std::vector<float4> sp((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const int dst = fill[cid[i]]++;
+        float4 v;
+        v.x = h[3 * (size_t)i + 0];
+        v.y = h[3 * (size_t)i + 1];
+        v.z = h[3 * (size_t)i + 2];
+        int id = i;
+        memcpy(&v.w, &id, 4);
+        sp[dst] = v;
+    }
+
+    p2s_cloud_s *c = new p2s_cloud_s();
+    c->device = device;
+    bool ok = hipMalloc(&c->pts, (size_t)n * 12) == hipSuccess && hipMalloc(&c->spts, (size_t)n * 16) == hipSuccess &&
+              hipMalloc(&c->cell_start, (ncell + 1) * 4) == hipSuccess &&
+              hipMalloc(&c->sat, sat.size() * 4) == hipSuccess && hipMalloc(&c->totals, 16) == hipSuccess;
+    if (ok) {
+        ok = hipMemcpy(c->pts, h.data(), (size_t)n * 12, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(c->spts, sp.data(), (size_t)n * 16, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(c->cell_start, start.data(), (ncell + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(c->sat, sat.data(), sat.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) {
+        p2s_set_error("p2s_cloud_create: device allocation/copy failed: %s", hipGetErrorString(hipGetLastError()));
+        p2s_cloud_destroy(c);
+        return P2S_ENOMEM;
+    }
+    c->d.pts = c->pts;
+    c->d.spts = c->spts;
+    c->d.cell_start = c->cell_start;
+    c->d.sat = c->sat;
+    for (int a = 0; a < 3; ++a) c->d.lo[a] = lo[a];
+    c->d.inv_cell = inv;
+    c->d.G = G;
+    c->d.n = n;
+    *out = c;
+    return P2S_OK;
+}
+
+int p2s_cloud_destroy(p2s_cloud_t c) {
+    if (!c) return P2S_OK;
+    (void)hipSetDevice(c->device);
+    if (c->pts) (void)hipFree(c->pts);
+    if (c->spts) (void)hipFree(c->spts);
+    if (c->cell_start) (void)hipFree(c->cell_start);
+    if (c->sat) (void)hipFree(c->sat);
+    if (c->occ) (void)hipFree(c->occ);
+    if (c->blk_cnt) (void)hipFree(c->blk_cnt);
+    if (c->totals) (void)hipFree(c->totals);
+    delete c;
+    return P2S_OK;
+}
+
+int p2s_cloud_num_points(p2s_cloud_t c) { return c ? c->d.n : P2S_EINVAL; }
+
+int p2s_query_grid(p2s_cloud_t c, int res, int eps, float *q_out_dev, int64_t capacity, int64_t *n_queries,
+                   void *stream) {
+    if (!c || res < 2 || res > 1024 || eps < 1 || eps > 16 || !n_queries || (capacity > 0 && !q_out_dev)) {
+        p2s_set_error("p2s_query_grid: bad argument (res=%d eps=%d)", res, eps);
+        return P2S_EINVAL;
+    }
+    P2S_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t vox = (size_t)res * res * res;
+    const size_t words = (vox + 31) / 32;
+    const long long rm = res - 1;
+    const long long nblk = (rm * rm * rm + 255) / 256;
+    if (words > c->occ_words) {
+        if (c->occ) (void)hipFree(c->occ);
+        c->occ = nullptr;
+        c->occ_words = 0;
+        if (hipMalloc(&c->occ, words * 4) != hipSuccess) {
+            p2s_set_error("p2s_query_grid: hipMalloc(%zu bytes) failed", words * 4);
+            return P2S_ENOMEM;
+        }
+        c->occ_words = words;
+    }
+    if ((size_t)nblk > c->blk_cap) {
+        if (c->blk_cnt) (void)hipFree(c->blk_cnt);
+        c->blk_cnt = nullptr;
+        c->blk_cap = 0;
+        // counts (int) followed by offsets (long long)
+        if (hipMalloc(&c->blk_cnt, (size_t)nblk * 4 + (size_t)nblk * 8 + 64) != hipSuccess) {
+            p2s_set_error("p2s_query_grid: hipMalloc(block scan) failed");
+            return P2S_ENOMEM;
+        }
+        c->blk_cap = (size_t)nblk;
+    }
+    long long *blk_off = reinterpret_cast<long long *>(reinterpret_cast<char *>(c->blk_cnt) +
+                                                       ((c->blk_cap * 4 + 63) / 64) * 64);
+    P2S_HIP_CHECK(hipMemsetAsync(c->occ, 0, words * 4, s));
+    P2S_HIP_CHECK(hipMemsetAsync(c->totals, 0, 16, s));
+    hipLaunchKernelGGL(p2s_voxelize_kernel, dim3((c->d.n + 255) / 256), dim3(256), 0, s, c->d.pts, c->d.n, res, c->occ,
+                       c->totals);
+    P2S_LAUNCH_CHECK("p2s_voxelize_kernel");
+    GridOffsets go;
+    go.n = eps;
+    for (int j = 0; j < eps; ++j) go.o[j] = eps / 2 - j;   // scipy.ndimage.convolve, origin 0
+    hipLaunchKernelGGL(p2s_grid_compact_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, s, c->occ, res, go, c->blk_cnt,
+                       blk_off, q_out_dev, (long long)capacity);
+    P2S_LAUNCH_CHECK("p2s_grid_compact_kernel<0>");
+    hipLaunchKernelGGL(p2s_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, c->blk_cnt, nblk, blk_off, c->totals);
+    P2S_LAUNCH_CHECK("p2s_scan_blocks_kernel");
+    long long host_tot[2] = {0, 0};
+    P2S_HIP_CHECK(hipMemcpyAsync(host_tot, c->totals, 16, hipMemcpyDeviceToHost, s));
+    P2S_HIP_CHECK(hipStreamSynchronize(s));
+    if (host_tot[1]) {
+        p2s_set_error("p2s_query_grid: point outside the [-1,1) volume (IndexError in the reference)");
+        return P2S_EINVAL;
+    }
+    *n_queries = host_tot[0];
+    if (capacity <= 0) return host_tot[0] > 0 ? P2S_ECAPACITY : P2S_OK;
+    hipLaunchKernelGGL(p2s_grid_compact_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, c->occ, res, go, c->blk_cnt,
+                       blk_off, q_out_dev, (long long)capacity);
+    P2S_LAUNCH_CHECK("p2s_grid_compact_kernel<1>");
+    if (host_tot[0] > capacity) {
+        p2s_set_error("p2s_query_grid: capacity %lld < %lld queries", (long long)capacity, host_tot[0]);
+        return P2S_ECAPACITY;
+    }
+    return P2S_OK;
+}
+
+int p2s_knn_patch(p2s_cloud_t c, const float *query_dev, int64_t nq, int k, int32_t *ids_out_dev,
+                  float *patch_ps_out_dev, float *radius_out_dev, void *stream) {
+    if (!c || !query_dev || nq < 0 || k < 1) {
+        p2s_set_error("p2s_knn_patch: bad argument");
+        return P2S_EINVAL;
+    }
+    if (k > c->d.n) {
+        // the reference fails too: cKDTree returns index N -> IndexError
+        p2s_set_error("p2s_knn_patch: cloud has %d points < k=%d", c->d.n, k);
+        return P2S_EINVAL;
+    }
+    if (k > KNN_CAP - 128) {
+        p2s_set_error("p2s_knn_patch: k=%d exceeds the supported maximum %d", k, KNN_CAP - 128);
+        return P2S_EINVAL;
+    }
+    if (nq == 0) return P2S_OK;
+    P2S_HIP_CHECK(hipSetDevice(c->device));
+    const unsigned grid = (unsigned)std::min<int64_t>(nq, 256 * 64);
+    hipLaunchKernelGGL(p2s_knn_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, c->d, query_dev, (long long)nq, k,
+                       ids_out_dev, patch_ps_out_dev, radius_out_dev);
+    P2S_LAUNCH_CHECK("p2s_knn_kernel");
+    return P2S_OK;
+}
+
+int p2s_gather_points(p2s_cloud_t c, const int32_t *ids_dev, int64_t n_ids, float *pts_out_dev, void *stream) {
+    if (!c || !ids_dev || !pts_out_dev || n_ids < 0) {
+        p2s_set_error("p2s_gather_points: bad argument");
+        return P2S_EINVAL;
+    }
+    if (n_ids == 0) return P2S_OK;
+    P2S_HIP_CHECK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(p2s_gather_kernel, dim3((unsigned)((n_ids + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       c->d.pts, ids_dev, (long long)n_ids, c->d.n, pts_out_dev);
+    P2S_LAUNCH_CHECK("p2s_gather_kernel");
+    return P2S_OK;
+}
+
+// ---- RNG -----------------------------------------------------------------------------------------
+int p2s_rng_create(uint32_t seed, int device, p2s_rng_t *out) {
+    if (!out) return P2S_EINVAL;
+    if (p2s_device_count() <= device || device < 0) {
+        p2s_set_error("p2s_rng_create: no HIP device %d", device);
+        return P2S_ENODEVICE;
+    }
+    P2S_HIP_CHECK(hipSetDevice(device));
+    // init_genrand(seed): numpy legacy seeding with an integer seed
+    uint32_t st[625];
+    st[0] = seed;
+    for (int i = 1; i < 624; ++i) st[i] = 1812433253u * (st[i - 1] ^ (st[i - 1] >> 30)) + (uint32_t)i;
+    st[624] = 624;
+    p2s_rng_s *r = new p2s_rng_s();
+    r->device = device;
+    if (hipMalloc(&r->state, sizeof(st)) != hipSuccess) {
+        delete r;
+        p2s_set_error("p2s_rng_create: hipMalloc failed");
+        return P2S_ENOMEM;
+    }
+    if (hipMemcpy(r->state, st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(r->state);
+        delete r;
+        p2s_set_error("p2s_rng_create: hipMemcpy failed");
+        return P2S_EHIP;
+    }
+    *out = r;
+    return P2S_OK;
+}
+
+int p2s_rng_destroy(p2s_rng_t r) {
+    if (!r) return P2S_OK;
+    (void)hipSetDevice(r->device);
+    if (r->state) (void)hipFree(r->state);
+    delete r;
+    return P2S_OK;
+}
+
+int p2s_rng_get_state(p2s_rng_t r, uint32_t *mt624_host, int32_t *pos_host, void *stream) {
+    if (!r || !mt624_host || !pos_host) return P2S_EINVAL;
+    P2S_HIP_CHECK(hipSetDevice(r->device));
+    uint32_t st[625];
+    P2S_HIP_CHECK(hipMemcpyAsync(st, r->state, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    P2S_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    memcpy(mt624_host, st, 624 * 4);
+    *pos_host = (int32_t)st[624];
+    return P2S_OK;
+}
+
+int p2s_rng_set_state(p2s_rng_t r, const uint32_t *mt624_host, int32_t pos, void *stream) {
+    if (!r || !mt624_host || pos < 0 || pos > 624) return P2S_EINVAL;
+    P2S_HIP_CHECK(hipSetDevice(r->device));
+    uint32_t st[625];
+    memcpy(st, mt624_host, 624 * 4);
+    st[624] = (uint32_t)pos;
+    P2S_HIP_CHECK(hipMemcpyAsync(r->state, st, sizeof(st), hipMemcpyHostToDevice, (hipStream_t)stream));
+    P2S_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return P2S_OK;
+}
+
+int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t nq, int n, int32_t *ids_out_dev, float *pts_out_dev,
+                          void *stream) {
+    if (!r || !c || nq < 0 || n < 1 || !ids_out_dev) {
+        p2s_set_error("p2s_subsample_uniform: bad argument (ids_out_dev is required)");
+        return P2S_EINVAL;
+    }
+    if (c->d.n < n) {
+        p2s_set_error("p2s_subsample_uniform: cloud has %d points < sub_sample_size %d (shuffle+pad path unsupported)",
+                      c->d.n, n);
+        return P2S_EINVAL;
+    }
+    if (nq == 0) return P2S_OK;
+    P2S_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t rng = (uint32_t)(c->d.n - 1);
+    const long long target = (long long)nq * n;
+    if (rng == 0) {
+        P2S_HIP_CHECK(hipMemsetAsync(ids_out_dev, 0, (size_t)target * 4, s));   // numpy consumes no randomness
+    } else {
+        uint32_t mask = rng;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        hipLaunchKernelGGL(p2s_mt_randint_kernel, dim3(1), dim3(256), 0, s, r->state, rng, mask, target, ids_out_dev);
+        P2S_LAUNCH_CHECK("p2s_mt_randint_kernel");
+    }
+    if (pts_out_dev) return p2s_gather_points(c, ids_out_dev, target, pts_out_dev, stream);
+    return P2S_OK;
+}
+
+}  // extern "C"

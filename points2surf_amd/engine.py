@@ -1,0 +1,239 @@
+"""Python face of the HIP engine: thin, typed wrappers over the C ABI.
+
+PyTorch-ROCm tensors are used only as containers (device memory + streams); all compute
+happens in libp2s_hip.so.  Nothing here computes on the CPU and nothing falls back.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import build_blob
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f32c(t, device):
+    if t.device != device:
+        raise ValueError('tensor on %s, engine on %s' % (t.device, device))
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class Model:
+    """Engine-side model: BN-folded, MFMA-packed weights resident in HBM.
+
+    Replaces ``make_regressor`` (reference source/points_to_surf_eval.py:150-171)."""
+
+    def __init__(self, state_dict, cfg, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('points2surf_amd needs a ROCm GPU (gfx950); no CPU fallback exists')
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.cfg = dict(cfg)
+        blob, offs, mc = build_blob(state_dict, cfg)
+        self._blob = np.ascontiguousarray(blob)
+        self.points_per_patch = mc.points_per_patch
+        self.sub_sample_size = mc.sub_sample_size
+        self.uniform_subsample = bool(cfg.get('uniform_subsample', False))
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.p2s_model_create(
+            ctypes.byref(mc), self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.size, ctypes.byref(offs),
+            self.device.index, ctypes.byref(self.handle)))
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.p2s_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, patch_pts_ps, pts_sub_sample_ms, query_ms, radius=None, want_logits=True, want_sdf=False):
+        """a8 (+a9).  Returns (logits [B,2] or None, sdf [B] or None).  Inputs are not modified."""
+        dev = self.device
+        patch = _f32c(patch_pts_ps, dev)
+        sub = _f32c(pts_sub_sample_ms, dev)
+        q = _f32c(query_ms, dev)
+        B = patch.shape[0]
+        if patch.shape != (B, self.points_per_patch, 3) or sub.shape != (B, self.sub_sample_size, 3) or q.shape != (B, 3):
+            raise ValueError('bad input shapes %s %s %s' % (tuple(patch.shape), tuple(sub.shape), tuple(q.shape)))
+        logits = torch.empty((B, 2), dtype=torch.float32, device=dev) if want_logits else None
+        sdf = torch.empty((B,), dtype=torch.float32, device=dev) if want_sdf else None
+        rad = _f32c(radius.reshape(-1), dev) if radius is not None else None
+        if want_sdf and rad is None:
+            raise ValueError('radius is required for the SDF output')
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.p2s_encode_decode(self.handle, _ptr(patch), _ptr(sub), _ptr(q), _ptr(rad), B,
+                                                  _ptr(logits), _ptr(sdf), _stream_ptr(dev)))
+        return logits, sdf
+
+    def features(self, patch_pts_ps, pts_sub_sample_ms, query_ms):
+        dev = self.device
+        patch = _f32c(patch_pts_ps, dev)
+        sub = _f32c(pts_sub_sample_ms, dev)
+        q = _f32c(query_ms, dev)
+        B = patch.shape[0]
+        fl = torch.empty((B, 1024), dtype=torch.float32, device=dev)
+        fg = torch.empty((B, 1024), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.p2s_encode_features(self.handle, _ptr(patch), _ptr(sub), _ptr(q), B, _ptr(fl), _ptr(fg),
+                                                    _stream_ptr(dev)))
+        return fl, fg
+
+    def set_profiling(self, on):
+        _lib.check(self.lib.p2s_set_profiling(self.handle, int(bool(on))))
+
+    def counters(self):
+        c = _lib.Counters()
+        _lib.check(self.lib.p2s_get_counters(self.handle, ctypes.byref(c)))
+        return {n: getattr(c, n) for n, _ in c._fields_ if n != 'reserved'}
+
+
+class Cloud:
+    """Device-resident point cloud + cell index.  Replaces ``load_shape`` / cKDTree
+    (reference source/data_loader.py:16-68)."""
+
+    def __init__(self, pts, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('points2surf_amd needs a ROCm GPU (gfx950); no CPU fallback exists')
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        if isinstance(pts, np.ndarray):
+            pts = torch.from_numpy(np.ascontiguousarray(pts[:, :3], dtype=np.float32))
+        self.pts = pts[:, :3].to(self.device, torch.float32).contiguous()
+        self.n = int(self.pts.shape[0])
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_cloud_create(_ptr(self.pts), self.n, self.device.index, _stream_ptr(self.device),
+                                                 ctypes.byref(self.handle)))
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.p2s_cloud_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def query_grid(self, grid_resolution, epsilon):
+        """a1 -> q [Q,3] float32 on the device (C order of the voxel index)."""
+        n = ctypes.c_int64(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_query_grid(self.handle, int(grid_resolution), int(epsilon), None, 0,
+                                               ctypes.byref(n), _stream_ptr(self.device)), allow=(_lib.P2S_ECAPACITY,))
+            q = torch.empty((max(n.value, 1), 3), dtype=torch.float32, device=self.device)
+            if n.value > 0:
+                _lib.check(self.lib.p2s_query_grid(self.handle, int(grid_resolution), int(epsilon), _ptr(q), n.value,
+                                                   ctypes.byref(n), _stream_ptr(self.device)))
+        return q[:n.value]
+
+    def knn_patch(self, queries, k, want_ids=True, want_patch=True):
+        """a4+a5 -> (ids [Q,k] int32, patch_ps [Q,k,3], radius [Q])"""
+        q = _f32c(queries, self.device)
+        Q = q.shape[0]
+        ids = torch.empty((Q, k), dtype=torch.int32, device=self.device) if want_ids else None
+        patch = torch.empty((Q, k, 3), dtype=torch.float32, device=self.device) if want_patch else None
+        rad = torch.empty((Q,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_knn_patch(self.handle, _ptr(q), Q, int(k), _ptr(ids), _ptr(patch), _ptr(rad),
+                                              _stream_ptr(self.device)))
+        return ids, patch, rad
+
+    def gather(self, ids):
+        ids = ids.to(self.device, torch.int32).contiguous()
+        out = torch.empty(tuple(ids.shape) + (3,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_gather_points(self.handle, _ptr(ids), ids.numel(), _ptr(out),
+                                                  _stream_ptr(self.device)))
+        return out
+
+
+class Rng:
+    """Device twin of the dataset-wide ``np.random.RandomState(seed)`` used for the global
+    sub-sample (reference source/data_loader.py:274-277)."""
+
+    def __init__(self, seed, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('points2surf_amd needs a ROCm GPU (gfx950); no CPU fallback exists')
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_rng_create(ctypes.c_uint32(int(seed) & 0xffffffff), self.device.index,
+                                               ctypes.byref(self.handle)))
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.p2s_rng_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get_state(self):
+        mt = np.zeros(624, dtype=np.uint32)
+        pos = ctypes.c_int32(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_rng_get_state(self.handle, mt.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos),
+                                                  _stream_ptr(self.device)))
+        return mt, int(pos.value)
+
+    def set_state(self, mt, pos):
+        mt = np.ascontiguousarray(mt, dtype=np.uint32)
+        assert mt.shape == (624,)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_rng_set_state(self.handle, mt.ctypes.data_as(ctypes.c_void_p), int(pos),
+                                                  _stream_ptr(self.device)))
+
+    def subsample_uniform(self, cloud, n_queries, n, want_pts=True):
+        """a6 (uniform): ids [Q,n] int32 (+ gathered points [Q,n,3])"""
+        ids = torch.empty((n_queries, n), dtype=torch.int32, device=self.device)
+        pts = torch.empty((n_queries, n, 3), dtype=torch.float32, device=self.device) if want_pts else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_subsample_uniform(self.handle, cloud.handle, n_queries, int(n), _ptr(ids), _ptr(pts),
+                                                      _stream_ptr(self.device)))
+        return ids, pts
+
+
+def infer_shape(model, cloud, rng, grid_resolution, epsilon, q_begin=0, q_end=-1, chunk=0, want_queries=True):
+    """Fused per-shape pipeline (p2s_infer_shape).  Returns (sdf [n] device tensor, q [n,3] or None)."""
+    dev = model.device
+    lib = model.lib
+    n = ctypes.c_int64(0)
+    with torch.cuda.device(dev):
+        _lib.check(lib.p2s_query_grid(cloud.handle, int(grid_resolution), int(epsilon), None, 0, ctypes.byref(n),
+                                      _stream_ptr(dev)), allow=(_lib.P2S_ECAPACITY,))
+        Q = n.value
+        qe = Q if q_end < 0 else q_end
+        nq = max(qe - q_begin, 0)
+        sdf = torch.empty((max(nq, 1),), dtype=torch.float32, device=dev)
+        q = torch.empty((max(nq, 1), 3), dtype=torch.float32, device=dev) if want_queries else None
+        done = ctypes.c_int64(0)
+        _lib.check(lib.p2s_infer_shape(model.handle, cloud.handle, rng.handle, int(grid_resolution), int(epsilon),
+                                       int(q_begin), int(qe), int(chunk), _ptr(sdf), _ptr(q), ctypes.byref(done),
+                                       _stream_ptr(dev)))
+    return sdf[:nq], (q[:nq] if q is not None else None)

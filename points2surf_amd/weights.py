@@ -1,0 +1,180 @@
+"""Reference ``state_dict`` -> engine weight blob (one-time, host side).
+
+* BatchNorm1d (eval: y = (x-mean)/sqrt(var+1e-5)*gamma+beta) is folded into the preceding
+  Conv1d(k=1)/Linear in float64 and rounded once to float32.  Order in the reference is
+  conv -> BN -> ReLU everywhere except PointNetfeat.conv3 (conv -> BN -> max, reference
+  source/points_to_surf_model.py:201-203); gamma may be negative, hence the engine pools
+  AFTER the folded affine.
+* GEMM operands are packed in the B-fragment order of v_mfma_f32_32x32x2_f32 with the
+  k-permutation the kernels use:  packed[n/32][k/8][lane][t] = W[k = 8*(k/8) + 4*(lane>>5) + t][n = 32*(n/32) + (lane&31)]
+* the STN identity (``x + eye(64)``, :66-67) and the QSTN identity quaternion (:125-126) are
+  folded into the fc3 bias.
+"""
+import ctypes
+
+import numpy as np
+
+from .model_spec import strip_module_prefix
+
+BN_EPS = 1e-5
+
+_ENC_FIELDS = ['w0a', 'b0a', 'w0b', 'b0b', 's1', 'sb1', 's2', 'sb2', 's3', 'sb3', 'sf1', 'sfb1', 'sf2', 'sfb2',
+               'sf3', 'sfb3', 'm1t', 'mb1', 'm2', 'mb2', 'm3', 'mb3']
+_QSTN_FIELDS = ['c1', 'cb1', 'c2', 'cb2', 'c3', 'cb3', 'f1', 'fb1', 'f2', 'fb2', 'f3', 'fb3']
+_DEC_FIELDS = ['d1l', 'db1l', 'd1g', 'db1g', 'd2', 'db2', 'd3', 'db3', 'd4', 'db4']
+
+
+class EncoderOffsets(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in _ENC_FIELDS]
+
+
+class QstnOffsets(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in _QSTN_FIELDS]
+
+
+class WeightOffsets(ctypes.Structure):
+    """mirror of ``p2s_weight_offsets`` (include/p2s_hip.h)"""
+    _fields_ = [('enc', EncoderOffsets * 2), ('qstn', QstnOffsets)] + [(n, ctypes.c_uint64) for n in _DEC_FIELDS]
+
+
+class ModelCfg(ctypes.Structure):
+    """mirror of ``p2s_model_cfg`` (include/p2s_hip.h)"""
+    _fields_ = [('net_size', ctypes.c_int32), ('points_per_patch', ctypes.c_int32),
+                ('sub_sample_size', ctypes.c_int32), ('output_dim', ctypes.c_int32),
+                ('use_point_stn', ctypes.c_int32), ('shared_transformer', ctypes.c_int32),
+                ('reserved', ctypes.c_int32 * 10)]
+
+
+def _np(v):
+    if hasattr(v, 'detach'):
+        v = v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+def fold_affine(w, lin, bn=None):
+    """returns (W [out,in] float64, b [out] float64) of ``bn(lin(x))``."""
+    W = _np(w[lin + '.weight']).astype(np.float64)
+    if W.ndim == 3:
+        W = W[:, :, 0]
+    b = _np(w[lin + '.bias']).astype(np.float64)
+    if bn is not None:
+        gamma = _np(w[bn + '.weight']).astype(np.float64)
+        beta = _np(w[bn + '.bias']).astype(np.float64)
+        mean = _np(w[bn + '.running_mean']).astype(np.float64)
+        var = _np(w[bn + '.running_var']).astype(np.float64)
+        s = gamma / np.sqrt(var + BN_EPS)
+        W = W * s[:, None]
+        b = (b - mean) * s + beta
+    return W, b
+
+
+def pack_b(Wkn):
+    """[K, N] -> flat packed B fragments [N/32][K/8][64][4] (float32)."""
+    Wkn = np.asarray(Wkn, dtype=np.float32)
+    K, N = Wkn.shape
+    assert K % 8 == 0 and N % 32 == 0, (K, N)
+    # k = 8*kg + 4*kk + t ; n = 32*nt + j ; lane = 32*kk + j
+    a = Wkn.reshape(K // 8, 2, 4, N // 32, 32)          # [kg, kk, t, nt, j]
+    a = a.transpose(3, 0, 1, 4, 2)                      # [nt, kg, kk, j, t]
+    return np.ascontiguousarray(a).reshape(-1)
+
+
+def unpack_b(packed, K, N):
+    """inverse of pack_b (tests)."""
+    a = np.asarray(packed, dtype=np.float32).reshape(N // 32, K // 8, 2, 32, 4)
+    return np.ascontiguousarray(a.transpose(1, 2, 4, 0, 3)).reshape(K, N)
+
+
+class _Blob:
+    def __init__(self):
+        self.parts = []
+        self.n = 0
+
+    def add(self, arr):
+        arr = np.ascontiguousarray(np.asarray(arr, dtype=np.float32).reshape(-1))
+        off = self.n
+        self.parts.append(arr)
+        pad = (-arr.size) % 64                       # keep every tensor 256-byte aligned
+        if pad:
+            self.parts.append(np.zeros(pad, dtype=np.float32))
+        self.n += arr.size + pad
+        return off
+
+    def finish(self):
+        return np.concatenate(self.parts) if self.parts else np.zeros(0, np.float32)
+
+
+def _add_gemm(blob, w, lin, bn, extra_bias=None):
+    W, b = fold_affine(w, lin, bn)
+    if extra_bias is not None:
+        b = b + extra_bias
+    return blob.add(pack_b(W.T)), blob.add(b)
+
+
+def _add_plain(blob, w, lin, bn, extra_bias=None):
+    """small layers kept as plain [K][N] (first K=3 conv, fc4, QSTN fc3)."""
+    W, b = fold_affine(w, lin, bn)
+    if extra_bias is not None:
+        b = b + extra_bias
+    return blob.add(W.T), blob.add(b)
+
+
+def build_blob(state_dict, cfg):
+    """state_dict (reference key layout, with or without ``module.``) + cfg dict ->
+    (blob float32 [n], WeightOffsets, ModelCfg)."""
+    w = strip_module_prefix(state_dict)
+    n = int(cfg.get('net_size', 1024))
+    if n != 1024:
+        raise ValueError('engine is specialised for net_size 1024 (got %d)' % n)
+    use_point_stn = bool(cfg.get('use_point_stn', False))
+    shared = bool(cfg.get('shared_transformer', False))
+    if not bool(cfg.get('use_feat_stn', True)):
+        raise ValueError('use_feat_stn=0 ablation is not on the accelerated path')
+    if bool(cfg.get('single_transformer', False)):
+        raise ValueError('single_transformer ablation is not on the accelerated path')
+    if use_point_stn and not shared:
+        raise ValueError('per-branch QSTN ablation is not on the accelerated path')
+    if cfg.get('sym_op', 'max') != 'max':
+        raise ValueError("Unsupported symmetric operation: %s" % cfg.get('sym_op'))
+
+    blob = _Blob()
+    offs = WeightOffsets()
+    for e, pre in enumerate(('feat_local', 'feat_global')):
+        o = offs.enc[e]
+        o.w0a, o.b0a = _add_plain(blob, w, pre + '.conv0a', pre + '.bn0a')
+        o.w0b, o.b0b = _add_gemm(blob, w, pre + '.conv0b', pre + '.bn0b')
+        s = pre + '.stn2'
+        o.s1, o.sb1 = _add_gemm(blob, w, s + '.conv1', s + '.bn1')
+        o.s2, o.sb2 = _add_gemm(blob, w, s + '.conv2', s + '.bn2')
+        o.s3, o.sb3 = _add_gemm(blob, w, s + '.conv3', s + '.bn3')
+        o.sf1, o.sfb1 = _add_gemm(blob, w, s + '.fc1', s + '.bn4')
+        o.sf2, o.sfb2 = _add_gemm(blob, w, s + '.fc2', s + '.bn5')
+        o.sf3, o.sfb3 = _add_gemm(blob, w, s + '.fc3', None, extra_bias=np.eye(64).reshape(-1))
+        o.m1t, o.mb1 = _add_gemm(blob, w, pre + '.conv1', pre + '.bn1')
+        o.m2, o.mb2 = _add_gemm(blob, w, pre + '.conv2', pre + '.bn2')
+        o.m3, o.mb3 = _add_gemm(blob, w, pre + '.conv3', pre + '.bn3')
+    if use_point_stn:
+        q = offs.qstn
+        s = 'point_stn'
+        q.c1, q.cb1 = _add_plain(blob, w, s + '.conv1', s + '.bn1')
+        q.c2, q.cb2 = _add_gemm(blob, w, s + '.conv2', s + '.bn2')
+        q.c3, q.cb3 = _add_gemm(blob, w, s + '.conv3', s + '.bn3')
+        q.f1, q.fb1 = _add_gemm(blob, w, s + '.fc1', s + '.bn4')
+        q.f2, q.fb2 = _add_gemm(blob, w, s + '.fc2', s + '.bn5')
+        q.f3, q.fb3 = _add_plain(blob, w, s + '.fc3', None, extra_bias=np.array([1.0, 0, 0, 0]))
+    offs.d1l, offs.db1l = _add_gemm(blob, w, 'fc1_local', 'bn1_local')
+    offs.d1g, offs.db1g = _add_gemm(blob, w, 'fc1_global', 'bn1_global')
+    offs.d2, offs.db2 = _add_gemm(blob, w, 'fc2', 'bn2')
+    offs.d3, offs.db3 = _add_gemm(blob, w, 'fc3', 'bn3')
+    offs.d4, offs.db4 = _add_plain(blob, w, 'fc4', None)
+
+    mc = ModelCfg()
+    mc.net_size = n
+    mc.points_per_patch = int(cfg.get('points_per_patch', 300))
+    mc.sub_sample_size = int(cfg.get('sub_sample_size', 1000))
+    mc.output_dim = int(cfg.get('output_dim', 2))
+    mc.use_point_stn = int(use_point_stn)
+    mc.shared_transformer = int(shared)
+    if mc.output_dim != 2:
+        raise ValueError('engine supports outputs imp_surf_magnitude + imp_surf_sign (pred_dim 2)')
+    return blob.finish(), offs, mc

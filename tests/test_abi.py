@@ -1,0 +1,63 @@
+"""The C-ABI shared library loads and exports every symbol include/p2s_hip.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(REPO, 'include', 'p2s_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(p2s_[a-z0-9_]+)\s*\(', src)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from points2surf_amd import build, _lib
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    from points2surf_amd import _lib
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), 'symbol %s declared in include/p2s_hip.h is not exported' % s
+    # the ctypes prototype table covers exactly the header
+    assert sorted(_lib.PROTOTYPES) == syms
+
+
+def test_abi_version_and_error_string(lib):
+    assert lib.p2s_abi_version() == 1
+    assert isinstance(lib.p2s_last_error(), bytes)
+    assert lib.p2s_device_count() >= 0
+
+
+def test_struct_sizes_match_header():
+    from points2surf_amd import weights, _lib
+    assert ctypes.sizeof(weights.ModelCfg) == 16 * 4
+    assert ctypes.sizeof(weights.EncoderOffsets) == 22 * 8
+    assert ctypes.sizeof(weights.QstnOffsets) == 12 * 8
+    assert ctypes.sizeof(weights.WeightOffsets) == (2 * 22 + 12 + 10) * 8
+    assert ctypes.sizeof(_lib.Counters) == 7 * 8 + 2 * 8 + 8 * 8
+
+
+def test_no_device_is_a_loud_error(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from points2surf_amd import engine, synth
+    w, cfg = synth.make_weights('p2s_max')
+    with pytest.raises(RuntimeError):
+        engine.Model(w, cfg)
+    # straight through the C ABI as well: an error code, not a crash / silent CPU path
+    from points2surf_amd import weights
+    blob, offs, mc = weights.build_blob(w, cfg)
+    h = ctypes.c_void_p()
+    rc = lib.p2s_model_create(ctypes.byref(mc), blob.ctypes.data_as(ctypes.c_void_p), blob.size, ctypes.byref(offs), 0,
+                              ctypes.byref(h))
+    assert rc == -5 and b'device' in lib.p2s_last_error()

@@ -1,0 +1,48 @@
+"""Quick device timing of the encoder/decoder pipeline on synthetic inputs (development aid)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from points2surf_amd import engine, synth  # noqa: E402
+
+FLOP_PER_QUERY = {'p2s_max': 776773632, 'p2s_vanilla': 1140695432}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--model', default='p2s_max')
+    ap.add_argument('--B', type=int, default=4096)
+    ap.add_argument('--iters', type=int, default=3)
+    args = ap.parse_args()
+    w, cfg = synth.make_weights(args.model)
+    m = engine.Model(w, cfg)
+    g = torch.Generator(device='cuda').manual_seed(0)
+    B = args.B
+    patch = torch.rand((B, 300, 3), device='cuda', generator=g) * 2 - 1
+    sub = torch.rand((B, 1000, 3), device='cuda', generator=g) - 0.5
+    q = torch.rand((B, 3), device='cuda', generator=g) * 0.2
+    rad = torch.rand((B,), device='cuda', generator=g) * 0.1 + 0.05
+    m.forward(patch, sub, q, rad, want_sdf=True)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.iters):
+        m.forward(patch, sub, q, rad, want_sdf=True)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / args.iters
+    m.set_profiling(True)
+    m.forward(patch, sub, q, rad, want_sdf=True)
+    torch.cuda.synchronize()
+    c = m.counters()
+    qps = B / dt
+    print(json.dumps({'model': args.model, 'B': B, 'ms': dt * 1e3, 'qps': qps,
+                      'tflops': qps * FLOP_PER_QUERY[args.model] / 1e12, 'stages_ms': c}))
+
+
+if __name__ == '__main__':
+    main()
