@@ -64,9 +64,6 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
         p2s_set_error("hipMemcpy(weights) failed: %s", hipGetErrorString(e));
         return P2S_EHIP;
     }
-    for (auto &ev : m->ev) {
-        if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
-    }
     *out = m;
     return P2S_OK;
 }
@@ -76,7 +73,7 @@ int p2s_model_destroy(p2s_model_t m) {
     (void)hipSetDevice(m->device);
     if (m->ws) (void)hipFree(m->ws);
     if (m->blob) (void)hipFree(m->blob);
-    for (auto &ev : m->ev)
+    for (auto &ev : m->evpool)
         if (ev) (void)hipEventDestroy(ev);
     delete m;
     return P2S_OK;
@@ -151,16 +148,6 @@ Ws carve(const p2s_model_s *m, int C) {
     return w;
 }
 
-struct StageTimer {
-    p2s_model_s *m;
-    hipStream_t s;
-    int idx = 0;
-    void mark() {
-        if (m->profiling && idx < (int)(sizeof(m->ev) / sizeof(m->ev[0])) && m->ev[idx]) (void)hipEventRecord(m->ev[idx], s);
-        ++idx;
-    }
-};
-
 }  // namespace
 
 // One chunk (C <= ws_chunk queries) through encoders (+ decoder if want_decode).
@@ -172,8 +159,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
     const int PL = m->cfg.points_per_patch, PG = m->cfg.sub_sample_size;
     Ws w = carve(m, C);
     int rc;
-    StageTimer tm{m, s};
-    tm.mark();   // ev0
+    const int ev0 = p2s_prof_mark(m, s);
 
     const float *rot = nullptr;
     if (m->cfg.use_point_stn) {
@@ -219,7 +205,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         b.n_items = C; b.relu_out = 1; b.short_chain = 0;
     }
     if ((rc = p2s_launch_chain(a, s))) return rc;
-    tm.mark();   // ev1
+    const int ev1 = p2s_prof_mark(m, s);
 
     // ---- STN head: 1024 -> 512 -> 256 -> 4096 (+I), then W1' = W1 . trans2 -------------------------
     {
@@ -247,7 +233,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         f.n_items = C;
         if ((rc = p2s_launch_fold(f, s))) return rc;
     }
-    tm.mark();   // ev2
+    const int ev2 = p2s_prof_mark(m, s);
 
     // ---- pass 2: stem (recomputed) + transformed conv1 + conv2 + conv3 + max-pool -------------------
     for (int slot = 0; slot < 2; ++slot) {
@@ -260,7 +246,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         b.relu_out = 0;
     }
     if ((rc = p2s_launch_chain(a, s))) return rc;
-    tm.mark();   // ev3
+    const int ev3 = p2s_prof_mark(m, s);
     m->counters.launches_chain += 2;
 
     if (feat_local_out) P2S_HIP_CHECK(hipMemcpyAsync(feat_local_out, w.feat, (size_t)C * 1024 * 4, hipMemcpyDeviceToDevice, s));
@@ -284,22 +270,57 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         if ((rc = p2s_launch_gemm(g, s))) return rc;
         if ((rc = p2s_launch_decoder_tail(w.d3, W + o.d4, W + o.db4, radius, logits_out, sdf_out, C, 128, s))) return rc;
     }
-    tm.mark();   // ev4
-    m->prof_pending = m->profiling;
+    const int ev4 = p2s_prof_mark(m, s);
+    p2s_prof_span(m, ST_CHAIN_STN, ev0, ev1);
+    p2s_prof_span(m, ST_HEAD, ev1, ev2);
+    p2s_prof_span(m, ST_CHAIN_MAIN, ev2, ev3);
+    p2s_prof_span(m, ST_DECODER, ev3, ev4);
     return P2S_OK;
 }
 
-void p2s_collect_profile(p2s_model_s *m) {
-    if (!m->prof_pending) return;
-    m->prof_pending = false;
-    float ms = 0.f;
-    if (m->ev[4] && hipEventSynchronize(m->ev[4]) == hipSuccess) {
-        if (hipEventElapsedTime(&ms, m->ev[0], m->ev[1]) == hipSuccess) m->counters.ms_chain_stn += ms;
-        if (hipEventElapsedTime(&ms, m->ev[1], m->ev[2]) == hipSuccess) m->counters.ms_stn_head += ms;
-        if (hipEventElapsedTime(&ms, m->ev[2], m->ev[3]) == hipSuccess) m->counters.ms_chain_main += ms;
-        if (hipEventElapsedTime(&ms, m->ev[3], m->ev[4]) == hipSuccess) m->counters.ms_decoder += ms;
+int p2s_prof_mark(p2s_model_s *m, hipStream_t s) {
+    if (!m->profiling) return -1;
+    if (m->ev_used >= (int)m->evpool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        m->evpool.push_back(e);
+    }
+    const int i = m->ev_used++;
+    if (hipEventRecord(m->evpool[i], s) != hipSuccess) return -1;
+    return i;
+}
+
+void p2s_prof_span(p2s_model_s *m, int stage, int a, int b) {
+    if (a >= 0 && b >= 0) m->spans.push_back({stage, a, b});
+}
+
+void p2s_prof_reset(p2s_model_s *m) {
+    m->ev_used = 0;
+    m->spans.clear();
+    memset(&m->counters, 0, sizeof(m->counters));
+}
+
+void p2s_prof_collect(p2s_model_s *m) {
+    if (!m->profiling || m->ev_used == 0) return;
+    (void)hipEventSynchronize(m->evpool[m->ev_used - 1]);
+    for (const auto &sp : m->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, m->evpool[sp.a], m->evpool[sp.b]) != hipSuccess) continue;
+        double *dst = nullptr;
+        switch (sp.stage) {
+            case ST_CHAIN_STN: dst = &m->counters.ms_chain_stn; break;
+            case ST_HEAD: dst = &m->counters.ms_stn_head; break;
+            case ST_CHAIN_MAIN: dst = &m->counters.ms_chain_main; break;
+            case ST_DECODER: dst = &m->counters.ms_decoder; break;
+            case ST_KNN: dst = &m->counters.ms_knn; break;
+            case ST_SUB: dst = &m->counters.ms_subsample; break;
+            case ST_GRID: dst = &m->counters.ms_grid; break;
+        }
+        if (dst) *dst += ms;
     }
     (void)hipGetLastError();
+    m->ev_used = 0;
+    m->spans.clear();
 }
 
 static int run_batched(p2s_model_s *m, const float *patch, const float *sub, const float *query, const float *radius,
@@ -317,17 +338,16 @@ static int run_batched(p2s_model_s *m, const float *patch, const float *sub, con
     int rc = p2s_model_reserve(m, chunk);
     if (rc) return rc;
     const int PL = m->cfg.points_per_patch, PG = m->cfg.sub_sample_size;
-    if (m->profiling) memset(&m->counters, 0, sizeof(m->counters));
+    p2s_prof_reset(m);
     for (int q0 = 0; q0 < B; q0 += chunk) {
         const int C = std::min(chunk, B - q0);
-        if (m->profiling && q0 > 0) p2s_collect_profile(m);   // events are reused per chunk
         rc = p2s_run_chunk(m, patch + (size_t)q0 * PL * 3, sub + (size_t)q0 * PG * 3, query + (size_t)q0 * 3,
                            radius ? radius + q0 : nullptr, C, logits ? logits + (size_t)q0 * 2 : nullptr,
                            sdf ? sdf + q0 : nullptr, fl ? fl + (size_t)q0 * 1024 : nullptr,
                            fg ? fg + (size_t)q0 * 1024 : nullptr, s);
         if (rc) return rc;
     }
-    if (m->profiling) p2s_collect_profile(m);
+    p2s_prof_collect(m);
     m->counters.queries += B;
     return P2S_OK;
 }

@@ -123,6 +123,9 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
     float rmax[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) rmax[i] = -INFINITY;
+    // torch's conv/ReLU/MaxPool propagate NaN (a non-finite coordinate poisons every channel of the
+    // item); v_max_f32 does not.  Track non-finite inputs and poison the pooled output instead.
+    bool bad = false;
 
     const int ntiles = (P + MT - 1) / MT;
     for (int tile = 0; tile < ntiles; ++tile) {
@@ -143,6 +146,7 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
             const float y2 = R[6] * x0 + R[7] * x1 + R[8] * x2;
             x0 = y0; x1 = y1; x2 = y2;
         }
+        bad = bad || !(fabsf(x0) <= 3.0e38f) || !(fabsf(x1) <= 3.0e38f) || !(fabsf(x2) <= 3.0e38f);
         // ---- first layer (K = 3) on the VALU: wave w produces channels [16w, 16w+16) -------------
         {
             float *dst = bufA + lane * SA + 16 * wave;
@@ -249,6 +253,7 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
     }
 
     // ---- pooled affine epilogue: out = [relu](max + bias) ------------------------------------------
+    const bool any_bad = __ballot(bad) != 0ull;
     if (lane < 32) {
         float *out = br.out + (long long)item * 1024 + 256 * wave + lane;
         const float *b3 = br.b3 + 256 * wave + lane;
@@ -256,6 +261,7 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
         for (int t = 0; t < 8; ++t) {
             float v = rmax[t] + b3[32 * t];
             if (br.relu_out) v = fmaxf(v, 0.0f);
+            if (any_bad) v = __builtin_nanf("");
             out[32 * t] = v;
         }
     }

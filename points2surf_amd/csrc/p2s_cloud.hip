@@ -13,6 +13,12 @@
 #include "p2s_common.h"
 #include "p2s_internal.h"
 #include <vector>
+
+// a5 must reproduce numpy's fp32 results bit for bit: no FMA contraction anywhere in this file, and
+// sqrtf / operator/ (correctly rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt);
+// NOT __fsqrt_rn, which HIP maps to the approximate native sqrt.
+#pragma clang fp contract(off)
+
 #include <cmath>
 #include <cstring>
 #include <algorithm>
@@ -71,8 +77,8 @@ __global__ void p2s_voxelize_kernel(const float *__restrict__ pts, int n, int re
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         // fp32 exactly as numpy: floor(((p + 1.0) / 2.0) * res)   (source/sdf.py:73-75)
-        const float t = __fdiv_rn(__fadd_rn(pts[3 * i + a], 1.0f), 2.0f);
-        v[a] = (int)floorf(__fmul_rn(t, (float)res));
+        const float t = (pts[3 * i + a] + 1.0f) / 2.0f;
+        v[a] = (int)floorf(t * (float)res);
     }
     if (v[0] < 0 || v[1] < 0 || v[2] < 0 || v[0] >= res || v[1] >= res || v[2] >= res) {
         totals[1] = 1;   // numpy would raise IndexError (or wrap a negative index)
@@ -330,22 +336,22 @@ __global__ __launch_bounds__(64) void p2s_knn_kernel(CloudDev c, const float *__
         for (int j = lane; j < k; j += 64) {
             const int id = lids[j];
             if (ids_out) ids_out[qi * k + j] = id;
-            const float dx = __fsub_rn(qxf, c.pts[3 * id + 0]);
-            const float dy = __fsub_rn(qyf, c.pts[3 * id + 1]);
-            const float dz = __fsub_rn(qzf, c.pts[3 * id + 2]);
-            const float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            const float dx = qxf - c.pts[3 * id + 0];
+            const float dy = qyf - c.pts[3 * id + 1];
+            const float dz = qzf - c.pts[3 * id + 2];
+            const float s = (dx * dx + dy * dy) + dz * dz;      // contraction is off: three roundings + two
             smax = fmaxf(smax, s);
         }
         for (int d = 32; d > 0; d >>= 1) smax = fmaxf(smax, __shfl_xor(smax, d));
-        const float rad = __fsqrt_rn(smax);   // sqrt is monotone: max_i sqrt(s_i) == sqrt(max_i s_i)
+        const float rad = sqrtf(smax);   // sqrt is monotone: max_i sqrt(s_i) == sqrt(max_i s_i)
         if (radius_out && lane == 0) radius_out[qi] = rad;
         if (patch_out) {
             for (int j = lane; j < k; j += 64) {
                 const int id = lids[j];
                 float *dst = patch_out + (qi * k + j) * 3;
-                dst[0] = __fdiv_rn(__fsub_rn(c.pts[3 * id + 0], qxf), rad);
-                dst[1] = __fdiv_rn(__fsub_rn(c.pts[3 * id + 1], qyf), rad);
-                dst[2] = __fdiv_rn(__fsub_rn(c.pts[3 * id + 2], qzf), rad);
+                dst[0] = (c.pts[3 * id + 0] - qxf) / rad;
+                dst[1] = (c.pts[3 * id + 1] - qyf) / rad;
+                dst[2] = (c.pts[3 * id + 2] - qzf) / rad;
             }
         }
         __syncthreads();

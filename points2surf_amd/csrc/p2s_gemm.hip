@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void p2s_gemm_kernel(GemmArgs g) {
     for (int reg = 0; reg < 16; ++reg) {
         const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         float v0 = acc0[reg] + bv, v1 = acc1[reg] + bv;
-        if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        // NaN-propagating ReLU (torch.relu(NaN) = NaN; fmaxf would swallow it)
+        if (g.relu) { v0 = (v0 < 0.f) ? 0.f : v0; v1 = (v1 < 0.f) ? 0.f : v1; }
         if (m0 + r < g.M) C[(long long)(m0 + r) * g.ldc + col] = v0;
         if (m0 + 32 + r < g.M) C[(long long)(m0 + 32 + r) * g.ldc + col] = v1;
     }

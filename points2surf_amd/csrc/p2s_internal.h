@@ -1,6 +1,7 @@
 // Handle definitions shared by the API translation units.
 #pragma once
 #include "p2s_common.h"
+#include <vector>
 
 struct p2s_model_s {
     p2s_model_cfg cfg;
@@ -11,14 +12,22 @@ struct p2s_model_s {
     float *ws = nullptr;      // per-chunk workspace, grown on demand
     int ws_chunk = 0;
     int max_chunk = 4096;     // queries per internal batch
+    // profiling: HIP events recorded on the launch stream, no host synchronisation until collect
     bool profiling = false;
-    bool prof_pending = false;
-    hipEvent_t ev[8] = {};
+    std::vector<hipEvent_t> evpool;
+    int ev_used = 0;
+    struct Span { int stage, a, b; };
+    std::vector<Span> spans;
     p2s_counters counters = {};
 };
+
+enum P2SStage { ST_CHAIN_STN = 0, ST_HEAD, ST_CHAIN_MAIN, ST_DECODER, ST_KNN, ST_SUB, ST_GRID };
+int p2s_prof_mark(p2s_model_s *m, hipStream_t s);                 // event index or -1
+void p2s_prof_span(p2s_model_s *m, int stage, int a, int b);
+void p2s_prof_reset(p2s_model_s *m);
+void p2s_prof_collect(p2s_model_s *m);                            // synchronises the last event
 
 int p2s_model_reserve(p2s_model_s *m, int chunk);
 int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const float *query, const float *radius,
                   int C, float *logits_out, float *sdf_out, float *feat_local_out, float *feat_global_out,
                   hipStream_t s);
-void p2s_collect_profile(p2s_model_s *m);

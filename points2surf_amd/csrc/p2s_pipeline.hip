@@ -46,24 +46,10 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
     if (chunk <= 0) chunk = m->max_chunk;
     chunk = std::min(chunk, m->max_chunk);
 
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool prof = m->profiling;
-    if (prof) {
-        memset(&m->counters, 0, sizeof(m->counters));
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
-    }
-    auto tic = [&]() { if (prof) (void)hipEventRecord(e0, s); };
-    auto toc = [&](double &acc) {
-        if (!prof) return;
-        (void)hipEventRecord(e1, s);
-        (void)hipEventSynchronize(e1);
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) acc += ms;
-    };
+    p2s_prof_reset(m);
 
     int64_t Q = 0;
-    tic();
+    const int eg0 = p2s_prof_mark(m, s);
     int rc = p2s_query_grid(c, res, eps, nullptr, 0, &Q, stream);
     if (rc != P2S_OK && rc != P2S_ECAPACITY) return rc;
     if (q_end < 0) q_end = Q;
@@ -75,8 +61,6 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
     PipeBuffers b;
     auto fail = [&](int code) {
         free_pipe(b);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
         return code;
     };
     const int64_t nq = q_end - q_begin;
@@ -91,32 +75,32 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
     }
     rc = p2s_query_grid(c, res, eps, b.q, Q, &Q, stream);
     if (rc) return fail(rc);
-    toc(m->counters.ms_grid);
+    p2s_prof_span(m, ST_GRID, eg0, p2s_prof_mark(m, s));
     rc = p2s_model_reserve(m, C);
     if (rc) return fail(rc);
 
-    const bool prof_model = m->profiling;
     for (int64_t q0 = q_begin; q0 < q_end; q0 += C) {
         const int cur = (int)std::min<int64_t>(C, q_end - q0);
         const float *qc = b.q + (size_t)q0 * 3;
-        tic();
+        const int ek0 = p2s_prof_mark(m, s);
         rc = p2s_knn_patch(c, qc, cur, k, nullptr, b.patch, b.radius, stream);
         if (rc) return fail(rc);
-        toc(m->counters.ms_knn);
-        tic();
+        const int ek1 = p2s_prof_mark(m, s);
         rc = p2s_subsample_uniform(r, c, cur, n, b.sub_ids, b.sub, stream);
         if (rc) return fail(rc);
-        toc(m->counters.ms_subsample);
+        const int es1 = p2s_prof_mark(m, s);
+        p2s_prof_span(m, ST_KNN, ek0, ek1);
+        p2s_prof_span(m, ST_SUB, ek1, es1);
         rc = p2s_run_chunk(m, b.patch, b.sub, qc, b.radius, cur, nullptr, sdf_out_dev + (q0 - q_begin), nullptr,
                            nullptr, s);
         if (rc) return fail(rc);
-        if (prof_model) p2s_collect_profile(m);
     }
     if (q_out_dev)
         P2S_HIP_CHECK(hipMemcpyAsync(q_out_dev, b.q + (size_t)q_begin * 3, (size_t)nq * 12, hipMemcpyDeviceToDevice, s));
     m->counters.queries += nq;
     // buffers are freed below: the stream must be done with them
     P2S_HIP_CHECK(hipStreamSynchronize(s));
+    p2s_prof_collect(m);
     if (n_done) *n_done = nq;
     return fail(P2S_OK);
 }

@@ -112,3 +112,19 @@ def test_end_to_end_prefix_matches_reference(golden_dir, fixture_cloud, meta):
     ref = g['sdf_full'][:96]
     assert np.abs(sdf - ref).max() < 1e-5
     assert np.array_equal(np.sign(sdf), np.sign(ref))
+
+
+@pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
+def test_torch_port_matches_reference(golden_dir, fixture_cloud, meta, model):
+    """the torch-CPU port timed as bench.py's cpu_baseline is the same function as the reference"""
+    from oracle.torch_port import TorchPort
+    g = np.load(os.path.join(golden_dir, 'ref_%s_grid32.npz' % model))
+    w, cfg = synth.make_weights(model)
+    port = TorchPort(w, cfg)
+    q, _ = O.query_grid(fixture_cloud, 32, 3)
+    nq = 24
+    sdf = port.infer_queries(fixture_cloud, q[:nq], np.random.RandomState(meta['seed_data']), batch=10)
+    assert np.abs(sdf - g['sdf_full'][:nq]).max() < 1e-6
+    r, ps = O.patch_radius_and_ps(fixture_cloud, g['knn_ids'][:nq], q[:nq])
+    logits = port.forward(ps, fixture_cloud[g['sub_ids'][:nq]], q[:nq]).numpy()
+    assert np.abs(logits - g['logits'][:nq]).max() < 1e-5
