@@ -75,6 +75,7 @@ int p2s_model_destroy(p2s_model_t m) {
     if (m->blob) (void)hipFree(m->blob);
     for (auto &ev : m->evpool)
         if (ev) (void)hipEventDestroy(ev);
+    if (m->aux) (void)hipStreamDestroy(m->aux);
     delete m;
     return P2S_OK;
 }

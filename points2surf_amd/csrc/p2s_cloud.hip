@@ -375,93 +375,149 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-__global__ __launch_bounds__(256) void p2s_mt_randint_kernel(uint32_t *__restrict__ state, uint32_t rng,
+// Out-of-place twist of one 624-word block by ONE wave.  With lane j-mapping j = 64*it + lane the three
+// dependent phases of the recurrence chain through the lane's own registers
+//   new[j] -> new[227+j] -> new[454+j]
+// so every LDS read is from the old block (independent, issued back to back): no dependent LDS round trip.
+__device__ __forceinline__ void mt_twist_wave(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int lane) {
+    uint32_t v1[4], v2[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int j = 64 * it + lane;
+        v1[it] = 0;
+        if (j < 227) {
+            v1[it] = src[j + 397] ^ mt_mix(src[j], src[j + 1]);
+            dst[j] = v1[it];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int j = 64 * it + lane;
+        v2[it] = 0;
+        if (j < 227) {
+            v2[it] = v1[it] ^ mt_mix(src[227 + j], src[228 + j]);
+            dst[227 + j] = v2[it];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int j = 64 * it + lane;
+        if (j < 169) dst[454 + j] = v2[it] ^ mt_mix(src[454 + j], src[455 + j]);
+    }
+    // new[623] = new[396] ^ mix(old[623], new[0]);  new[396] = v2 of j = 169 (it 2, lane 41), new[0] = v1 of j = 0
+    const uint32_t n396 = __builtin_amdgcn_readlane(v2[2], 41);
+    const uint32_t n0 = __builtin_amdgcn_readlane(v1[0], 0);
+    if (lane == 0) dst[623] = n396 ^ mt_mix(src[623], n0);
+}
+
+// Two-wave pipeline: wave 0 twists block b+1 (out of place) while wave 1 tempers / mask-rejects /
+// compacts block b into the output.  One workgroup barrier per 624-word block.  The waves run at raised
+// priority: the kernel shares its CU with MFMA-saturated encoder waves and is pure latency.
+__global__ __launch_bounds__(128) void p2s_mt_randint_kernel(uint32_t *__restrict__ state, uint32_t rng,
                                                              uint32_t mask, long long target,
                                                              int32_t *__restrict__ out) {
-    __shared__ uint32_t mt[624];
-    __shared__ int wcnt[4];
-    __shared__ int s_newpos;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 624; i += 256) mt[i] = state[i];
+    __shared__ uint32_t st[2][624];
+    __shared__ uint32_t stage[640];
+    __shared__ int s_done[2];
+    __shared__ int s_pos;
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 624; i += 128) st[0][i] = state[i];
     int pos = (int)state[624];
-    __syncthreads();
-    long long produced = 0;
-    bool first = true;
-    while (produced < target) {
-        int start = 0;
-        if (first && pos < 624) {
-            start = pos;
-        } else {
-            // ---- twist: three dependent phases, each "read operands, barrier, write" ------------------
-            uint32_t v = 0;
-            if (tid < 227) v = mt[tid + 397] ^ mt_mix(mt[tid], mt[tid + 1]);
-            __syncthreads();
-            if (tid < 227) mt[tid] = v;
-            __syncthreads();
-            if (tid < 227) v = mt[tid] ^ mt_mix(mt[tid + 227], mt[tid + 228]);
-            __syncthreads();
-            if (tid < 227) mt[tid + 227] = v;
-            __syncthreads();
-            if (tid < 169) v = mt[tid + 227] ^ mt_mix(mt[tid + 454], mt[tid + 455]);
-            __syncthreads();
-            if (tid < 169) mt[tid + 454] = v;
-            __syncthreads();
-            if (tid == 0) mt[623] = mt[396] ^ mt_mix(mt[623], mt[0]);
-            __syncthreads();
-        }
-        first = false;
-        // ---- temper + masked rejection; thread t owns words 3t..3t+2 (t < 208) -----------------------
-        uint32_t w[3];
-        bool ok[3];
-        int c = 0;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int idx = 3 * tid + j;
-            ok[j] = false;
-            w[j] = 0;
-            if (idx < 624 && idx >= start) {
-                w[j] = mt_temper(mt[idx]) & mask;
-                ok[j] = w[j] <= rng;
-            }
-            c += ok[j] ? 1 : 0;
-        }
-        int incl = c;
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) wcnt[wave] = incl;
-        if (tid == 0) s_newpos = 624;
-        __syncthreads();
-        int wbase = 0, total = 0;
-        for (int wv = 0; wv < 4; ++wv) {
-            if (wv < wave) wbase += wcnt[wv];
-            total += wcnt[wv];
-        }
-        const long long need = target - produced;            // > 0
-        int rank = wbase + incl - c;                         // exclusive rank of this thread's first accept
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (ok[j]) {
-                if (rank < need) {
-                    out[produced + rank] = (int32_t)w[j];
-                    if (rank == need - 1) s_newpos = 3 * tid + j + 1;   // stream resumes after this word
-                }
-                ++rank;
-            }
-        }
-        __syncthreads();
-        if (total >= need) {
-            pos = s_newpos;
-            produced = target;
-        } else {
-            pos = 624;
-            produced += total;
-        }
-        __syncthreads();
+    if (tid == 0) {
+        s_done[0] = 0;
+        s_done[1] = 0;
+        s_pos = 624;
     }
-    for (int i = tid; i < 624; i += 256) state[i] = mt[i];
-    if (tid == 0) state[624] = (uint32_t)pos;
+    __syncthreads();
+    int cur = 0, start = pos;
+    if (pos >= 624) {                       // numpy: "needs twist before the first draw"
+        if (wave == 0) mt_twist_wave(st[0], st[1], lane);
+        __syncthreads();
+        cur = 1;
+        start = 0;
+    }
+    long long produced = 0;                 // meaningful in the consumer wave only
+    for (int iter = 0;; ++iter) {
+        if (wave == 0) {
+            mt_twist_wave(st[cur], st[cur ^ 1], lane);
+        } else {
+            // lane l owns words 10l .. 10l+9 (contiguous -> ordered compaction by an exclusive lane scan).
+            // Branch-free: all 10 LDS reads are issued back to back; accepted words are compacted through
+            // an LDS staging buffer and leave as coalesced 256-byte stores.
+            const uint32_t *src = st[cur];
+            uint32_t w[10];
+            unsigned okmask = 0;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int idx = 10 * lane + j;
+                w[j] = src[idx < 624 ? idx : 623];
+            }
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int idx = 10 * lane + j;
+                w[j] = mt_temper(w[j]) & mask;
+                const unsigned ok = (idx < 624) & (idx >= start) & (w[j] <= rng);
+                okmask |= ok << j;
+            }
+            const int c = __popc(okmask);
+            // exclusive prefix of c (<= 10, 4 bits) over the lanes without any LDS traffic: one ballot +
+            // mbcnt per bit plane (a shuffle scan would be six dependent ds_bpermute round trips)
+            int excl = 0, total = 0;
+#pragma unroll
+            for (int bit = 0; bit < 4; ++bit) {
+                const unsigned long long m = __ballot((c >> bit) & 1);
+                excl += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) << bit;
+                total += __popcll(m) << bit;
+            }
+            const long long need = target - produced;          // > 0
+            int r = excl;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                if (okmask & (1u << j)) stage[r] = w[j];
+                r += (okmask >> j) & 1u;
+            }
+            const int lim = (total < need) ? total : (int)need;
+            {
+                uint32_t sv[10];
+#pragma unroll
+                for (int it = 0; it < 10; ++it) sv[it] = stage[64 * it + lane];      // batched LDS reads
+#pragma unroll
+                for (int it = 0; it < 10; ++it)
+                    if (64 * it + lane < lim) out[produced + 64 * it + lane] = (int32_t)sv[it];
+            }
+            if (total >= need) {
+                // the stream resumes after the word holding the need-th accepted value
+                if (excl < need && need <= excl + c) {
+                    int left = (int)need - excl;
+                    int pos_end = 0;
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) {
+                        if ((okmask >> j) & 1u) {
+                            if (--left == 0) pos_end = 10 * lane + j + 1;
+                        }
+                    }
+                    s_pos = pos_end;
+                }
+                if (lane == 0) s_done[iter & 1] = 1;
+                produced = target;
+            } else {
+                produced += total;
+            }
+        }
+        // LDS-only synchronisation: __syncthreads() would add s_waitcnt vmcnt(0) and stall every block on
+        // the completion of its (fire-and-forget) id stores
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s_done[iter & 1]) break;        // parity-indexed: the consumer may already be one block ahead
+        cur ^= 1;
+        start = 0;
+    }
+    // the block in which the target was reached stays the current block (the twister's look-ahead went to
+    // the other buffer)
+    for (int i = tid; i < 624; i += 128) state[i] = st[cur][i];
+    if (tid == 0) state[624] = (uint32_t)s_pos;
 }
 
 __global__ void p2s_gather_kernel(const float *__restrict__ pts, const int32_t *__restrict__ ids, long long n,
@@ -788,7 +844,7 @@ int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t nq, int n, int32_t
     } else {
         uint32_t mask = rng;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-        hipLaunchKernelGGL(p2s_mt_randint_kernel, dim3(1), dim3(256), 0, s, r->state, rng, mask, target, ids_out_dev);
+        hipLaunchKernelGGL(p2s_mt_randint_kernel, dim3(1), dim3(128), 0, s, r->state, rng, mask, target, ids_out_dev);
         P2S_LAUNCH_CHECK("p2s_mt_randint_kernel");
     }
     if (pts_out_dev) return p2s_gather_points(c, ids_out_dev, target, pts_out_dev, stream);

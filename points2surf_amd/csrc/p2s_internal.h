@@ -19,6 +19,9 @@ struct p2s_model_s {
     struct Span { int stage, a, b; };
     std::vector<Span> spans;
     p2s_counters counters = {};
+    // auxiliary stream: the data path (kNN, sub-sample) of chunk i+1, i+2 overlaps the encoders of chunk i
+    hipStream_t aux = nullptr;
+    bool overlap = true;
 };
 
 enum P2SStage { ST_CHAIN_STN = 0, ST_HEAD, ST_CHAIN_MAIN, ST_DECODER, ST_KNN, ST_SUB, ST_GRID };
