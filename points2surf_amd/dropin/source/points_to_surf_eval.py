@@ -1,0 +1,247 @@
+"""Drop-in ``source.points_to_surf_eval`` (boundary level B1).
+
+``parse_arguments`` accepts exactly the reference's flags (reference source/points_to_surf_eval.py:16-65)
+and ``points_to_surf_eval(eval_opt)`` has the same side effects -- files under ``<outdir>/rec/...`` --
+so that the reference's ``full_eval.py`` (:17-75) runs unchanged.  Underneath, the whole per-query
+path runs on the MI355X engine: the query grid, the kNN patches, the global sub-sample (numpy-legacy
+MT19937 stream reproduced on the device, one stream over all shapes in dataset order = the
+reference's ``--workers 0`` semantics), the encoders and the decoder.
+
+Deliberate differences (documented in INTEGRATION.md):
+  * ``--workers`` / ``--cache_capacity`` / ``--batchSize`` do not influence results (the reference's
+    results depend on the worker count through duplicated RNG streams);
+  * ``--gpu_idx < 0`` raises: the reference's CPU branch does not run as written either
+    (:167,362 call .cuda() unconditionally) and this engine has no CPU fallback;
+  * the debug visualisations ``rec/query_pts_ms_vis/*.ply`` and ``rec/vis/*.ply`` need trimesh and are
+    written only when trimesh is importable;
+  * the non-reconstruction pass (GT query points with random rotation augmentation,
+    source/data_loader.py:381-393) is outside the accelerated path and raises NotImplementedError;
+  * with torchrun (WORLD_SIZE > 1) shapes are sharded over ranks (one process per GPU).
+"""
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from points2surf_amd import engine as _engine
+from points2surf_amd import sharding as _sharding
+from points2surf_amd.model_spec import strip_module_prefix
+
+
+def parse_arguments(args=None):
+    parser = argparse.ArgumentParser()
+
+    parser.add_argument('--indir', type=str, default='datasets/abc_minimal', help='input folder (meshes)')
+    parser.add_argument('--outdir', type=str, default='results',
+                        help='output folder (estimated point cloud properties)')
+    parser.add_argument('--dataset', nargs='+', type=str, default=['testset.txt'], help='shape set file name')
+    parser.add_argument('--reconstruction', type=bool, default=False, help='do reconstruction instead of evaluation')
+    parser.add_argument('--query_grid_resolution', type=int, default=None,
+                        help='resolution of sampled volume used for reconstruction')
+    parser.add_argument('--epsilon', type=int, default=None, help='neighborhood size for reconstruction')
+    parser.add_argument('--certainty_threshold', type=float, default=None, help='')
+    parser.add_argument('--sigma', type=int, default=None, help='')
+    parser.add_argument('--up_sampling_factor', type=int, default=10, help='unused by the reconstruction path')
+    parser.add_argument('--modeldir', type=str, default='models', help='model folder')
+    parser.add_argument('--models', type=str, default='p2s_vanilla',
+                        help='names of trained models, can evaluate multiple models')
+    parser.add_argument('--modelpostfix', type=str, default='_model.pth', help='model file postfix')
+    parser.add_argument('--parampostfix', type=str, default='_params.pth', help='parameter file postfix')
+    parser.add_argument('--gpu_idx', type=int, default=0, help='GPU index (the engine has no CPU path)')
+    parser.add_argument('--sparse_patches', type=int, default=False, help='unused by the reconstruction path')
+    parser.add_argument('--sampling', type=str, default='full', help='sampling strategy: full')
+    parser.add_argument('--patches_per_shape', type=int, default=1000, help='only for random-patch sampling')
+    parser.add_argument('--query_points_per_patch', type=int, default=1, help='number of query points per patch')
+    parser.add_argument('--sub_sample_size', type=int, default=500, help='overridden by the training parameters')
+    parser.add_argument('--seed', type=int, default=40938661, help='manual seed')
+    parser.add_argument('--batchSize', type=int, default=0, help='queries per engine chunk (0 = engine default)')
+    parser.add_argument('--workers', type=int, default=0, help='ignored by the device data path')
+    parser.add_argument('--cache_capacity', type=int, default=100, help='ignored by the device data path')
+
+    opt = parser.parse_args(args=args)
+    if len(opt.dataset) == 1:
+        opt.dataset = opt.dataset[0]
+    return opt
+
+
+def get_output_dimensions(train_opt):
+    """reference :81-103: the engine implements outputs = magnitude + sign (pred_dim 2)"""
+    pred_dim = 0
+    for o in train_opt.outputs:
+        if o in ('imp_surf', 'imp_surf_magnitude', 'imp_surf_sign'):
+            pred_dim += 1
+        elif o in ('p_index', 'patch_pts_ids'):
+            pass
+        else:
+            raise ValueError('Unknown output: %s' % o)
+    return pred_dim
+
+
+def _load_train_opt(param_filename):
+    train_opt = torch.load(param_filename, weights_only=False)
+    if not hasattr(train_opt, 'single_transformer'):
+        train_opt.single_transformer = 0
+    if not hasattr(train_opt, 'shared_transformer'):
+        train_opt.shared_transformer = False
+    return train_opt
+
+
+def _engine_cfg(train_opt, pred_dim):
+    outputs = list(train_opt.outputs)
+    if 'imp_surf' in outputs or 'imp_surf_magnitude' not in outputs or 'imp_surf_sign' not in outputs:
+        raise ValueError('the HIP engine supports outputs imp_surf_magnitude + imp_surf_sign (got %s)' % outputs)
+    if getattr(train_opt, 'patch_radius', 0.0) > 0.0:
+        raise ValueError('fixed patch_radius (radius query) models are not supported by the HIP engine')
+    if int(getattr(train_opt, 'fixed_subsample', 0)):
+        raise ValueError('fixed_subsample ablation is not supported by the HIP engine')
+    return dict(
+        net_size=getattr(train_opt, 'net_size', 1024), points_per_patch=train_opt.points_per_patch,
+        sub_sample_size=train_opt.sub_sample_size, output_dim=pred_dim,
+        use_point_stn=bool(train_opt.use_point_stn), use_feat_stn=bool(train_opt.use_feat_stn),
+        sym_op=train_opt.sym_op, single_transformer=bool(train_opt.single_transformer),
+        shared_transformer=bool(train_opt.shared_transformer),
+        uniform_subsample=bool(getattr(train_opt, 'uniform_subsample', 0)))
+
+
+def _load_points(indir, shape_name):
+    base = os.path.join(indir, '04_pts', shape_name + '.xyz')
+    if os.path.isfile(base + '.npy'):
+        pts = np.load(base + '.npy')
+    elif os.path.isfile(base):
+        pts = np.loadtxt(base).astype(np.float32)
+    else:
+        raise FileNotFoundError(base + '[.npy]')
+    if pts.shape[1] > 3:
+        pts = pts[:, 0:3]
+    if pts.dtype != np.float32:
+        print('Warning: pts_np must be converted to float32: {}'.format(base))
+        pts = pts.astype(np.float32)
+    return np.ascontiguousarray(pts)
+
+
+def _weighted_subsample_host(rng_np, pts_np, q_np, n):
+    """p2s_vanilla parity mode: legacy ``choice(N, n, replace=False, p)`` on the host, exactly the
+    reference's call (source/base/utils.py:200-208,218-219)."""
+    out = np.empty((q_np.shape[0], n), dtype=np.int32)
+    for i in range(q_np.shape[0]):
+        dist = np.linalg.norm(np.broadcast_to(q_np[i], pts_np.shape) - pts_np, axis=1)
+        prob = np.clip(1.0 - 1.5 * (dist / np.max(dist)), 0.05, 1.0)
+        prob = prob / np.sum(prob)
+        out[i] = rng_np.choice(pts_np.shape[0], size=n, replace=False, p=prob)
+    return out
+
+
+def _infer_one_shape(model, cloud, pts_np, rng_dev, rng_np, cfg, res, eps, chunk):
+    if cfg['uniform_subsample']:
+        return _engine.infer_shape(model, cloud, rng_dev, res, eps, chunk=chunk)
+    # distance-weighted sub-sample: ids from the host's legacy RNG, everything else on the device
+    q = cloud.query_grid(res, eps)
+    sdf = torch.empty((q.shape[0],), dtype=torch.float32, device=q.device)
+    step = chunk if chunk > 0 else 2048
+    for s in range(0, q.shape[0], step):
+        qc = q[s:s + step]
+        _, patch, rad = cloud.knn_patch(qc, model.points_per_patch, want_ids=False)
+        ids = _weighted_subsample_host(rng_np, pts_np, qc.cpu().numpy(), model.sub_sample_size)
+        sub = cloud.gather(torch.from_numpy(ids).to(q.device))
+        _, sd = model.forward(patch, sub, qc, rad, want_logits=False, want_sdf=True)
+        sdf[s:s + step] = sd
+    return sdf, q
+
+
+def _save_shape(model_out_dir, shape_name, sdf_np, q_np):
+    """files of save_evaluation + save_reconstruction_data (reference :199-222, :263-282)"""
+    os.makedirs(os.path.join(model_out_dir, 'eval'), exist_ok=True)
+    np.save(os.path.join(model_out_dir, 'eval', shape_name + '.xyz.npy'), sdf_np)
+    np.savetxt(os.path.join(model_out_dir, 'eval', shape_name + '.xyz.txt'), sdf_np)
+    os.makedirs(os.path.join(model_out_dir, 'query_pts_ms'), exist_ok=True)
+    np.save(os.path.join(model_out_dir, 'query_pts_ms', shape_name + '.xyz.npy'), q_np)
+    os.makedirs(os.path.join(model_out_dir, 'dist_ms'), exist_ok=True)
+    np.save(os.path.join(model_out_dir, 'dist_ms', shape_name + '.xyz.npy'), sdf_np)
+    try:   # debug visualisations exist only where the reference's own dependencies are installed
+        import trimesh  # noqa: F401
+        from source import sdf as ref_sdf
+        for sub in ('vis', 'query_pts_ms_vis'):
+            os.makedirs(os.path.join(model_out_dir, sub), exist_ok=True)
+            ref_sdf.visualize_query_points(q_np, sdf_np, os.path.join(model_out_dir, sub, shape_name + '.ply'))
+    except Exception:
+        pass
+
+
+def points_to_surf_eval(eval_opt):
+    models = eval_opt.models.split()
+    if eval_opt.seed < 0:
+        eval_opt.seed = random.randint(1, 10000)
+    if eval_opt.gpu_idx < 0:
+        raise RuntimeError('points2surf_amd: --gpu_idx < 0 (CPU) is not available; the HIP engine needs an MI355X')
+    if not eval_opt.reconstruction:
+        raise NotImplementedError('the GT-query evaluation pass (random-rotation augmentation, needs trimesh) is '
+                                  'outside the accelerated path; use the reference implementation for it')
+    if eval_opt.sampling != 'full':
+        raise ValueError('Unknown sampling strategy: %s' % eval_opt.sampling)
+    if eval_opt.query_grid_resolution is None or eval_opt.epsilon is None:
+        raise ValueError('reconstruction needs --query_grid_resolution and --epsilon')
+
+    world, rank, local_rank = _sharding.dist_env()
+    device = torch.device('cuda', eval_opt.gpu_idx if world == 1 else local_rank)
+    torch.cuda.set_device(device)
+
+    for model_name in models:
+        print('Random Seed: %d' % eval_opt.seed)
+        random.seed(eval_opt.seed)
+        torch.manual_seed(eval_opt.seed)
+        model_filename = os.path.join(eval_opt.modeldir, model_name + eval_opt.modelpostfix)
+        param_filename = os.path.join(eval_opt.modeldir, model_name + eval_opt.parampostfix)
+        train_opt = _load_train_opt(param_filename)
+        pred_dim = get_output_dimensions(train_opt)
+        cfg = _engine_cfg(train_opt, pred_dim)
+        state = strip_module_prefix(torch.load(model_filename, map_location='cpu', weights_only=False))
+        model = _engine.Model(state, cfg, device=device)
+        chunk = int(eval_opt.batchSize) if int(eval_opt.batchSize) > 0 else 0
+
+        with open(os.path.join(eval_opt.indir, eval_opt.dataset)) as f:
+            shape_names = [x.strip() for x in f.readlines()]
+        shape_names = list(filter(None, shape_names))
+        model_out_dir = os.path.join(eval_opt.outdir, 'rec')
+        os.makedirs(model_out_dir, exist_ok=True)
+        print('getting information for {} shapes'.format(len(shape_names)))
+
+        # one RNG stream over all shapes in dataset order (--workers 0 semantics of the reference)
+        rng_dev = _engine.Rng(eval_opt.seed, device=device)
+        rng_np = np.random.RandomState(eval_opt.seed)
+        mine = set(range(len(shape_names)))
+        if world > 1:
+            sizes = [os.path.getsize(os.path.join(eval_opt.indir, '04_pts', n + '.xyz.npy'))
+                     if os.path.isfile(os.path.join(eval_opt.indir, '04_pts', n + '.xyz.npy')) else 1
+                     for n in shape_names]
+            mine = set(_sharding.assign_lpt(sizes, world)[rank])
+        total_q = 0
+        t0 = time.time()
+        for shape_ind, shape_name in enumerate(shape_names):
+            pts_np = _load_points(eval_opt.indir, shape_name)
+            if shape_ind not in mine:
+                # keep the dataset-wide stream exact on every rank: consume this shape's draws without inference
+                cloud = _engine.Cloud(pts_np, device=device)
+                _sharding.skip_shape_stream(cloud, pts_np, rng_dev, rng_np, cfg, eval_opt.query_grid_resolution,
+                                            eval_opt.epsilon, model.sub_sample_size)
+                continue
+            cloud = _engine.Cloud(pts_np, device=device)
+            sdf, q = _infer_one_shape(model, cloud, pts_np, rng_dev, rng_np, cfg, eval_opt.query_grid_resolution,
+                                      eval_opt.epsilon, chunk)
+            sdf_np = sdf.cpu().numpy()
+            q_np = q.cpu().numpy()
+            total_q += sdf_np.shape[0]
+            _save_shape(model_out_dir, shape_name, sdf_np, q_np)
+            cloud.close()
+        dt = time.time() - t0
+        if world > 1:
+            _sharding.barrier()
+        print('evaluated %d patches of %d shapes in %.2f s (%.0f queries/s on rank %d)'
+              % (total_q, len(mine), dt, total_q / max(dt, 1e-9), rank))
+        model.close()
+
+
+if __name__ == '__main__':
+    points_to_surf_eval(parse_arguments())

@@ -1,0 +1,100 @@
+"""Shape-level sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+The path has no cross-query state, so shapes shard embarrassingly: longest-processing-time-first
+assignment, no data-path collective.  Two things cross ranks:
+  * the dataset-wide sub-sample RNG stream (reference source/data_loader.py:274-277): every rank
+    consumes the draws of the shapes it does not own (``skip_shape_stream``), which keeps results
+    bit-identical to the single-process run;
+  * the final variable-length gather of per-shape results to rank 0 (``gather_variable``; RCCL over
+    xGMI with the nccl backend, gloo in the CPU tests).
+Replaces the reference's only multi-GPU mechanism, ``torch.nn.DataParallel`` (reference
+source/points_to_surf_eval.py:168), which re-broadcasts all 21.5 MB of weights on every forward.
+"""
+import os
+
+import numpy as np
+
+
+def dist_env():
+    """(world_size, rank, local_rank) from the torchrun environment."""
+    return (int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')),
+            int(os.environ.get('LOCAL_RANK', '0')))
+
+
+def assign_lpt(costs, world):
+    """Longest-processing-time-first: returns ``world`` lists of item indices (each ascending).
+    Deterministic (ties broken by index) so every rank computes the same assignment."""
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+    load = [0.0] * world
+    out = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += float(costs[i])
+    return [sorted(x) for x in out]
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def init_process_group(backend=None):
+    """idempotent; 127.0.0.1 rendezvous (the container hostname may not resolve)"""
+    import torch
+    import torch.distributed as dist
+    world, rank, local_rank = dist_env()
+    if world == 1 or dist.is_initialized():
+        return world, rank, local_rank
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    kw = {}
+    if backend == 'nccl':
+        torch.cuda.set_device(local_rank)
+        kw['device_id'] = torch.device('cuda', local_rank)
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return world, rank, local_rank
+
+
+def gather_variable(t, dst=0):
+    """Gather 1-D tensors of different lengths to ``dst``.  Returns the list (by rank) on ``dst``,
+    None elsewhere.  One all_gather of the sizes + one padded gather (the path's only collective)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [t]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    padded = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    padded[:t.shape[0]] = t
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return [b[:s] for b, s in zip(bufs, sizes)]
+
+
+def skip_shape_stream(cloud, pts_np, rng_dev, rng_np, cfg, grid_resolution, epsilon, sub_sample_size, chunk=8192):
+    """Advance the dataset-wide RNG stream(s) past one shape without running inference."""
+    import torch
+    q = cloud.query_grid(grid_resolution, epsilon)
+    Q = int(q.shape[0])
+    if cfg.get('uniform_subsample'):
+        for s in range(0, Q, chunk):
+            rng_dev.subsample_uniform(cloud, min(chunk, Q - s), sub_sample_size, want_pts=False)
+        torch.cuda.synchronize()
+    else:
+        qn = q.cpu().numpy()
+        for i in range(Q):
+            dist_ = np.linalg.norm(np.broadcast_to(qn[i], pts_np.shape) - pts_np, axis=1)
+            prob = np.clip(1.0 - 1.5 * (dist_ / np.max(dist_)), 0.05, 1.0)
+            prob = prob / np.sum(prob)
+            rng_np.choice(pts_np.shape[0], size=sub_sample_size, replace=False, p=prob)
+    return Q

@@ -1,0 +1,91 @@
+"""Boundary (B1/B2): the drop-in modules expose the reference's API surface.  CPU only."""
+import os
+import sys
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(REPO, 'points2surf_amd', 'dropin')
+
+
+@pytest.fixture()
+def dropin_source():
+    saved = {k: v for k, v in sys.modules.items() if k == 'source' or k.startswith('source.')}
+    for k in saved:
+        del sys.modules[k]
+    sys.path.insert(0, DROPIN)
+    try:
+        import source.points_to_surf_eval as ev
+        import source.points_to_surf_model as mo
+        yield ev, mo
+    finally:
+        sys.path.remove(DROPIN)
+        for k in [k for k in sys.modules if k == 'source' or k.startswith('source.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_state_dict_layout_matches_spec(dropin_source):
+    from points2surf_amd import model_spec, synth
+    ev, mo = dropin_source
+    for name in ('p2s_max', 'p2s_vanilla'):
+        c = model_spec.NAMED_MODELS[name]
+        m = mo.PointsToSurfModel(net_size_max=1024, num_points=300, output_dim=2, use_point_stn=c['use_point_stn'],
+                                 use_feat_stn=True, sym_op='max', use_query_point=True, sub_sample_size=1000,
+                                 do_augmentation=False, single_transformer=0,
+                                 shared_transformation=c['shared_transformation'])
+        spec = model_spec.state_shapes(use_point_stn=c['use_point_stn'], shared_transformation=c['shared_transformation'])
+        sd = m.state_dict()
+        assert set(sd.keys()) == set(spec.keys())
+        for k, shape in spec.items():
+            assert tuple(sd[k].shape) == tuple(shape), k
+        # a reference-format checkpoint (DataParallel 'module.' prefix) loads strictly
+        w, _ = synth.make_weights(name)
+        torch.nn.DataParallel(m).load_state_dict(synth.to_torch_state_dict(w))
+        assert len(sd) == {'p2s_max': 174, 'p2s_vanilla': 211}[name]     # key counts of the reference (golden meta)
+
+
+def test_parse_arguments_defaults_and_quirks(dropin_source):
+    ev, _ = dropin_source
+    o = ev.parse_arguments([])
+    assert o.dataset == 'testset.txt' and o.seed == 40938661 and o.models == 'p2s_vanilla'
+    assert o.reconstruction is False and o.query_grid_resolution is None and o.batchSize == 0
+    o = ev.parse_arguments(['--dataset', 'a/testset.txt', 'b/testset.txt', '--query_grid_resolution', '256',
+                            '--epsilon', '3', '--certainty_threshold', '13', '--sigma', '5', '--workers', '7',
+                            '--batchSize', '501', '--cache_capacity', '5', '--modelpostfix', '_model_249.pth',
+                            '--models', 'p2s_max', '--indir', 'datasets', '--outdir', 'results', '--modeldir', 'models'])
+    assert o.dataset == ['a/testset.txt', 'b/testset.txt'] and o.query_grid_resolution == 256 and o.sigma == 5
+
+
+@pytest.mark.skipif(not os.path.isfile('/root/reference/source/points_to_surf_eval.py'), reason='reference not present')
+def test_parse_arguments_identical_to_reference(dropin_source):
+    ev, _ = dropin_source
+    from oracle import ref_shims
+    args = ['--query_grid_resolution', '128', '--epsilon', '3', '--models', 'p2s_max', '--dataset', 'x.txt']
+    mine_default, mine = vars(ev.parse_arguments([])), vars(ev.parse_arguments(args))
+    for k in [k for k in sys.modules if k == 'source' or k.startswith('source.')]:
+        del sys.modules[k]
+    sys.path.remove(DROPIN)
+    try:
+        with ref_shims.reference():
+            from source import points_to_surf_eval as ref_ev
+            assert vars(ref_ev.parse_arguments([])) == mine_default
+            assert vars(ref_ev.parse_arguments(args)) == mine
+    finally:
+        sys.path.insert(0, DROPIN)
+
+
+def test_errors_mirror_reference(dropin_source):
+    ev, mo = dropin_source
+    with pytest.raises(ValueError):
+        mo.PointsToSurfModel(sym_op='median')
+    o = ev.parse_arguments(['--gpu_idx', '-1'])
+    o.reconstruction = True
+    with pytest.raises(RuntimeError):
+        ev.points_to_surf_eval(o)
+    m = mo.PointsToSurfModel(net_size_max=1024, num_points=300, output_dim=2, use_point_stn=False,
+                             sub_sample_size=1000).eval()
+    with pytest.raises(RuntimeError):      # CPU tensors: loud failure, no fallback
+        m({'patch_pts_ps': torch.zeros(1, 300, 3), 'pts_sub_sample_ms': torch.zeros(1, 1000, 3),
+           'imp_surf_query_point_ms': torch.zeros(1, 3)})

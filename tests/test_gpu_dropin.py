@@ -1,0 +1,133 @@
+"""Drop-in boundary on the GPU: the calls full_eval.py makes (reference full_eval.py:24-49) against the
+reference's golden outputs."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(REPO, 'points2surf_amd', 'dropin')
+SHAPE = '00994122_57d9d4755722f9d2d7436f0a_trimesh_000'
+
+
+@pytest.fixture()
+def dropin_source():
+    for k in [k for k in sys.modules if k == 'source' or k.startswith('source.')]:
+        del sys.modules[k]
+    sys.path.insert(0, DROPIN)
+    try:
+        import source.points_to_surf_eval as ev
+        import source.points_to_surf_model as mo
+        yield ev, mo
+    finally:
+        sys.path.remove(DROPIN)
+        for k in [k for k in sys.modules if k == 'source' or k.startswith('source.')]:
+            del sys.modules[k]
+
+
+def _write_model_files(modeldir, name):
+    import torch
+    from points2surf_amd import synth
+    w, cfg = synth.make_weights(name)
+    os.makedirs(modeldir, exist_ok=True)
+    torch.save(synth.to_torch_state_dict(w), os.path.join(modeldir, name + '_model.pth'))
+    ns = argparse.Namespace(
+        outputs=['imp_surf_magnitude', 'imp_surf_sign', 'patch_pts_ids', 'p_index'], points_per_patch=300,
+        patch_center='mean', sub_sample_size=1000, patch_radius=0.0, uniform_subsample=int(cfg['uniform_subsample']),
+        fixed_subsample=0, net_size=1024, use_point_stn=int(cfg['use_point_stn']), use_feat_stn=1, sym_op='max',
+        single_transformer=0, shared_transformer=int(cfg['shared_transformer']), batchSize=501)
+    torch.save(ns, os.path.join(modeldir, name + '_params.pth'))
+
+
+def _make_dataset(root, fixture_cloud, n_shapes=1):
+    os.makedirs(os.path.join(root, '04_pts'), exist_ok=True)
+    names = [SHAPE] + ['copy_%d' % i for i in range(1, n_shapes)]
+    for n in names:
+        np.save(os.path.join(root, '04_pts', n + '.xyz.npy'), fixture_cloud)
+    with open(os.path.join(root, 'testset.txt'), 'w') as f:
+        f.write('\n'.join(names) + '\n')
+    return names
+
+
+@pytest.mark.parametrize('name', ['p2s_max', 'p2s_vanilla'])
+def test_points_to_surf_eval_writes_reference_outputs(name, dropin_source, tmp_path, fixture_cloud, golden_dir):
+    ev, _ = dropin_source
+    root = str(tmp_path / 'abc_minimal')
+    _make_dataset(root, fixture_cloud)
+    modeldir = str(tmp_path / 'models')
+    _write_model_files(modeldir, name)
+    outdir = str(tmp_path / 'results')
+    opt = ev.parse_arguments(['--indir', root, '--outdir', outdir, '--dataset', 'testset.txt', '--modeldir', modeldir,
+                              '--models', name, '--query_grid_resolution', '32', '--epsilon', '3',
+                              '--certainty_threshold', '13', '--sigma', '5', '--workers', '7', '--batchSize', '501',
+                              '--cache_capacity', '5'])
+    opt.reconstruction = True                                    # what full_eval.py:45 does
+    ev.points_to_surf_eval(opt)
+    g = np.load(os.path.join(golden_dir, 'ref_%s_grid32.npz' % name))
+    rec = os.path.join(outdir, 'rec')
+    sdf = np.load(os.path.join(rec, 'dist_ms', SHAPE + '.xyz.npy'))
+    q = np.load(os.path.join(rec, 'query_pts_ms', SHAPE + '.xyz.npy'))
+    assert np.array_equal(q, np.load(os.path.join(golden_dir, 'query_grid_32_3.npy')))
+    assert np.array_equal(np.load(os.path.join(rec, 'eval', SHAPE + '.xyz.npy')), sdf)
+    assert np.allclose(np.loadtxt(os.path.join(rec, 'eval', SHAPE + '.xyz.txt')), sdf)
+    d = np.abs(sdf - g['sdf_full'])
+    flips = int((np.sign(sdf) != np.sign(g['sdf_full'])).sum())
+    print('%s via points_to_surf_eval: max|dSDF| %.3g, sign flips %d/%d' % (name, d.max(), flips, sdf.size))
+    assert d.max() < 1e-5 and flips == 0
+
+
+def test_rng_stream_continues_across_shapes(dropin_source, tmp_path, fixture_cloud):
+    """two shapes in one dataset: the second shape's result depends on the stream position left by the first
+    (reference: one RandomState for the whole dataset, data_loader.py:274-277)"""
+    from oracle import p2s_oracle as O
+    from points2surf_amd import synth
+    ev, _ = dropin_source
+    root = str(tmp_path / 'ds')
+    names = _make_dataset(root, fixture_cloud, n_shapes=2)
+    modeldir = str(tmp_path / 'models')
+    _write_model_files(modeldir, 'p2s_max')
+    outdir = str(tmp_path / 'results')
+    opt = ev.parse_arguments(['--indir', root, '--outdir', outdir, '--dataset', 'testset.txt', '--modeldir', modeldir,
+                              '--models', 'p2s_max', '--query_grid_resolution', '32', '--epsilon', '3'])
+    opt.reconstruction = True
+    ev.points_to_surf_eval(opt)
+    a = np.load(os.path.join(outdir, 'rec', 'dist_ms', names[0] + '.xyz.npy'))
+    b = np.load(os.path.join(outdir, 'rec', 'dist_ms', names[1] + '.xyz.npy'))
+    assert a.shape == b.shape and not np.array_equal(a, b)
+    # oracle for the first 16 queries of the SECOND shape with the stream advanced past the first
+    w, cfg = synth.make_weights('p2s_max')
+    rng = O.LegacyMT19937(40938661)
+    rng.randint(fixture_cloud.shape[0], a.shape[0] * 1000)
+    _, ref = O.infer_shape(w, cfg, fixture_cloud, 32, 3, rng, query_range=(0, 16))
+    assert np.abs(b[:16] - ref).max() < 1e-5
+
+
+def test_module_forward_b2(dropin_source, fixture_cloud, golden_dir):
+    import torch
+    from points2surf_amd import synth, engine
+    _, mo = dropin_source
+    g = np.load(os.path.join(golden_dir, 'ref_p2s_max_grid32.npz'))
+    m = mo.PointsToSurfModel(net_size_max=1024, num_points=300, output_dim=2, use_point_stn=0, use_feat_stn=1,
+                             sym_op='max', use_query_point=True, sub_sample_size=1000, do_augmentation=False,
+                             single_transformer=0, shared_transformation=0)
+    m.cuda(device=torch.device('cuda', 0))
+    m = torch.nn.DataParallel(m, device_ids=[0])
+    w, _ = synth.make_weights('p2s_max')
+    m.load_state_dict(synth.to_torch_state_dict(w))
+    m.eval()
+    cloud = engine.Cloud(fixture_cloud)
+    q = cloud.query_grid(32, 3)[:64]
+    _, patch, _ = cloud.knn_patch(q, 300)
+    sub = cloud.gather(torch.from_numpy(g['sub_ids']).cuda())
+    sub0 = sub.clone()
+    with torch.no_grad():
+        pred = m({'patch_pts_ps': patch, 'pts_sub_sample_ms': sub.clone(), 'imp_surf_query_point_ms': q})
+        pred2 = m.module({'patch_pts_ps': patch, 'pts_sub_sample_ms': sub, 'imp_surf_query_point_ms': q})
+    assert pred.shape == (64, 2) and pred.is_cuda
+    assert np.abs(pred.cpu().numpy() - g['logits']).max() < 1e-4
+    assert torch.equal(pred, pred2)
+    assert torch.allclose(sub, sub0 - q.unsqueeze(1))            # reference side effect (:303)
