@@ -143,6 +143,16 @@ def main():
         avg_launch_ms = chain_ms / launches
         flop_per_launch = FLOP_CHAIN_PER_QUERY * n_queries / launches
         achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
+        # committed under profiles/; they cannot be collected from inside this process
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(REPO, 'profiles', 'r01', 'pmc_summary.json')) as f:
+                ck = json.load(f)['chain_kernel']
+            traffic = ck['hbm_traffic_bytes_per_launch'] * (n_queries / launches * 2) / (2 * ck['queries_per_launch'])
+            traffic_src = 'profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, scaled to this launch size)'
+        except Exception:
+            pass
         out = {
             'metric': 'SDF queries/sec/GPU (p2s_max, 256^3 grid)', 'value': value, 'unit': 'queries/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -155,7 +165,7 @@ def main():
                        'shapes_per_hour': world * args.steps / dt * 3600.0,
                        'queries_per_s_per_gpu': value / world},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'p2s_chain_kernel', 'launches': int(launches), 'avg_launch_ms': avg_launch_ms,
                          'algorithmic_flop_per_launch': flop_per_launch,
                          'hbm_algorithmic_GBps': value / world * BYTES_PER_QUERY / 1e9},
