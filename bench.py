@@ -149,7 +149,7 @@ def main():
         try:
             with open(os.path.join(REPO, 'profiles', 'r01', 'pmc_summary.json')) as f:
                 ck = json.load(f)['chain_kernel']
-            traffic = ck['hbm_traffic_bytes_per_launch'] * (n_queries / launches * 2) / (2 * ck['queries_per_launch'])
+            traffic = ck['hbm_traffic_bytes_per_launch'] * (2.0 * n_queries / launches) / ck['queries_per_launch']
             traffic_src = 'profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, scaled to this launch size)'
         except Exception:
             pass
