@@ -34,7 +34,7 @@ def build(force=False, verbose=True, extra_flags=()):
         return LIB
     cmd = [hipcc_path(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
            '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
-           '-o', LIB] + list(extra_flags) + sources()
+           '-o', LIB] + list(extra_flags) + os.environ.get('P2S_EXTRA_HIPCC_FLAGS', '').split() + sources()
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -2,6 +2,7 @@
 #include "p2s_common.h"
 #include "p2s_internal.h"
 #include <cstring>
+#include <cstdlib>
 #include <algorithm>
 
 static thread_local char g_err[512] = "";
@@ -51,6 +52,7 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
     m->offs = *offs;
     m->device = device;
     m->n_floats = n_floats;
+    if (getenv("P2S_MAX_CHUNK")) m->max_chunk = std::max(64, atoi(getenv("P2S_MAX_CHUNK")));   // development knob
     hipError_t e = hipMalloc(&m->blob, n_floats * sizeof(float));
     if (e != hipSuccess) {
         delete m;

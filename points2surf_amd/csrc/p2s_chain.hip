@@ -24,6 +24,7 @@
 //  * bias (and ReLU for STN trunks) commute with the max and are applied once per item.
 // Padding rows of the last tile replicate the item's last point (max is idempotent).
 #include "p2s_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -37,6 +38,13 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 
 __device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ f32x4 lds4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ f32x4 bufld4(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    f32x4 r;
+    r[0] = __uint_as_float(v[0]); r[1] = __uint_as_float(v[1]); r[2] = __uint_as_float(v[2]); r[3] = __uint_as_float(v[3]);
+    return r;
+}
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 __device__ __forceinline__ void store_tile_bias_relu(const f32x16 &acc, float *dst, int stride, int row0,
@@ -51,25 +59,6 @@ __device__ __forceinline__ void store_tile_bias_relu(const f32x16 &acc, float *d
     }
 }
 
-// one K=64 layer: RT row tiles (rows row0 + 32 r) x one 32-column tile
-template <int RT>
-__device__ __forceinline__ void layer_k64(const float *src, int ss, int row0, const float *__restrict__ wp,
-                                          int lane, f32x16 (&acc)[RT]) {
-    const int arow = row0 + (lane & 31);
-    const int koff = 4 * (lane >> 5);
-#pragma unroll
-    for (int kg = 0; kg < 8; ++kg) {
-        const f32x4 b = ldg4(wp + (kg * 64 + lane) * 4);
-        f32x4 a[RT];
-#pragma unroll
-        for (int r = 0; r < RT; ++r) a[r] = lds4(src + (arow + 32 * r) * ss + 8 * kg + koff);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < RT; ++r) acc[r] = mfma32(a[r][t], b[t], acc[r]);
-    }
-}
-
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -77,11 +66,71 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
-__device__ __forceinline__ float tile_colmax(const f32x16 &a, const f32x16 &b) {
-    float m = fmaxf(a[0], b[0]);
+// B operand of one K=64 layer, one 32-column tile: 8 k-groups = 8 buffer loads (32 VGPRs).  Weights do not
+// depend on the activations, so they are fetched BEFORE the barrier that guards the layer's input.
+struct B8 {
+    f32x4 v[8];
+};
+__device__ __forceinline__ void load_b8(B8 &b, __amdgpu_buffer_rsrc_t rsrc, int lane16, int soff) {
 #pragma unroll
-    for (int i = 1; i < 16; ++i) m = fmaxf(m, fmaxf(a[i], b[i]));
+    for (int kg = 0; kg < 8; ++kg) b.v[kg] = bufld4(rsrc, lane16, soff + kg * 1024);
+}
+
+// one K=64 layer: RT row tiles (rows row0 + 32 r) x one 32-column tile; A from LDS one k-group ahead, each
+// ds_read in its own MFMA shadow; the first k-group accumulates into the literal 0 (no v_mov init)
+template <int RT>
+__device__ __forceinline__ void layer_k64(const float *src, int ss, int row0, const B8 &b, int lane,
+                                          f32x16 (&acc)[RT]) {
+    const float *ap = src + (row0 + (lane & 31)) * ss + 4 * (lane >> 5);
+    f32x4 a[RT], na[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) a[r] = lds4(ap + 32 * r * ss);
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        if (kg < 7) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) na[r] = lds4(ap + 32 * r * ss + 8 * (kg + 1));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                acc[r] = (kg == 0 && t == 0) ? mfma32(a[r][0], b.v[0][0], zero16()) : mfma32(a[r][t], b.v[kg][t], acc[r]);
+        if (kg < 7) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) a[r] = na[r];
+        }
+    }
+}
+
+
+// max over the 32 accumulator values of one output column (two row tiles): 1 v_max + 15 v_max3.
+// Inline asm because fmaxf() on MFMA results makes hipcc prepend an sNaN-quieting v_max(x, x) to every
+// operand (IEEE mode), which doubled the epilogue; (LLVM also folds med3(a, b, +inf) back to that form).
+// hipcc does not pad hazards for asm operands, so the first statement carries the XDL-write -> VALU-read
+// wait states itself (16-pass MFMA: 19 states; s_nop 15 + s_nop 4 = 21).  asm volatile keeps the order.
+__device__ __forceinline__ float tile_colmax(const f32x16 &a, const f32x16 &b) {
+    float m;
+    asm volatile("s_nop 15\n\ts_nop 4\n\tv_max_f32 %0, %1, %2" : "=v"(m) : "v"(a[0]), "v"(b[0]));
+#pragma unroll
+    for (int i = 1; i < 16; ++i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(a[i]), "v"(b[i]));
     return m;
+}
+
+// max of lane l and lane l^32 in both lanes, without an LDS round trip: v_permlane32_swap exchanges the
+// upper half of its first operand with the lower half of the second
+__device__ __forceinline__ float half_max(float m) {
+    const unsigned u = __float_as_uint(m);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    float x = __uint_as_float(r[0]), y = __uint_as_float(r[1]), o;
+    asm volatile("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(x), "v"(y));
+    return o;
 }
 
 __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
@@ -127,12 +176,20 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
     // item); v_max_f32 does not.  Track non-finite inputs and poison the pooled output instead.
     bool bad = false;
 
-    const int ntiles = (P + MT - 1) / MT;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        // ---- load this lane's point (all 4 waves load the same 64 points; L1/L2 hits) ------------
+    // buffer descriptors of the layer weights (wave-uniform): SGPR base + scalar offset + 16 * lane
+    const int lane16 = lane * 16;
+    const __amdgpu_buffer_rsrc_t rs0b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(br.w0b), 0, 4096 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w1), 0, 4096 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(br.w2), 0, 8192 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w3), 0, 128 * 1024 * 4, 0x00020000);
+    // this wave's 8 conv3 column tiles start at byte offset wave * 8 * 16 KB of the packed weights
+    const int w3soff = wave * (8 * 16 * 1024);
+
+    // coordinates of this lane's point of a tile (all 4 waves load the same 64 points; L1/L2 hits);
+    // the next tile's point is fetched under conv3 of the current one
+    auto load_point = [&](int tile, float &x0, float &x1, float &x2) {
         int p = tile * MT + lane;
         if (p >= P) p = P - 1;
-        float x0, x1, x2;
         if (p < P1) {
             const float *src = br.ptsA + ((long long)item * P1 + p) * 3;
             x0 = src[0]; x1 = src[1]; x2 = src[2];
@@ -140,6 +197,19 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
             const float *src = br.ptsB + ((long long)item * (P - P1) + (p - P1)) * 3;
             x0 = src[0] - cx; x1 = src[1] - cy; x2 = src[2] - cz;
         }
+    };
+
+    const int ablate = args.ablate;
+    const int ntiles = (P + MT - 1) / MT;
+    float nx0, nx1, nx2;
+    load_point(0, nx0, nx1, nx2);
+    for (int tile = 0; tile < ntiles; ++tile) {
+      f32x4 bA0, bA1, aA0, aA1, bB0, bB1, aB0, aB1;   // conv3 operand register sets
+      if (ablate != 1) {
+        float x0 = nx0, x1 = nx1, x2 = nx2;
+        B8 wb;
+        if (!short_chain) load_b8(wb, rs0b, lane16, (wave & 1) * 8192);      // conv0b weights, in flight across the barrier
+        else load_b8(wb, rs2, lane16, wave * 8192);
         if (has_rot) {
             const float y0 = R[0] * x0 + R[1] * x1 + R[2] * x2;
             const float y1 = R[3] * x0 + R[4] * x1 + R[5] * x2;
@@ -171,41 +241,47 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
             // ---- conv0b: bufA[64x64] -> bufB[:, 0:64] ; wave = (row tile, col tile) ---------------
             {
                 const int rt = wave >> 1, nt = wave & 1;
-                f32x16 acc[1] = {zero16()};
-                layer_k64<1>(bufA, SA, 32 * rt, br.w0b + nt * 8 * 256, lane, acc);
+                f32x16 acc[1];
+                layer_k64<1>(bufA, SA, 32 * rt, wb, lane, acc);
+                load_b8(wb, rs1, lane16, nt * 8192);                           // conv1 weights
                 store_tile_bias_relu(acc[0], bufB, SB, 32 * rt, 32 * nt, br.b0b, lane);
             }
             __syncthreads();
             // ---- conv1 (STN: shared weights; main: per-item W1' = W1 . trans2): bufB -> bufA ---------
             {
                 const int rt = wave >> 1, nt = wave & 1;
-                f32x16 acc[1] = {zero16()};
-                layer_k64<1>(bufB, SB, 32 * rt, w1 + nt * 8 * 256, lane, acc);
+                f32x16 acc[1];
+                layer_k64<1>(bufB, SB, 32 * rt, wb, lane, acc);
+                load_b8(wb, rs2, lane16, wave * 8192);                         // conv2 weights
                 store_tile_bias_relu(acc[0], bufA, SA, 32 * rt, 32 * nt, br.b1, lane);
             }
             __syncthreads();
         }
         // ---- conv2: bufA[64x64] -> bufB[64x128]; wave w = column tile w, both row tiles --------------
         {
-            f32x16 acc[2] = {zero16(), zero16()};
-            layer_k64<2>(bufA, SA, 0, br.w2 + wave * 8 * 256, lane, acc);
+            f32x16 acc[2];
+            layer_k64<2>(bufA, SA, 0, wb, lane, acc);
+            // first conv3 weight fragments, in flight across the barrier
+            bA0 = bufld4(w3rsrc, lane16, w3soff);
+            bA1 = bufld4(w3rsrc, lane16, w3soff + 16 * 1024);
             store_tile_bias_relu(acc[0], bufB, SB, 0, 32 * wave, br.b2, lane);
             store_tile_bias_relu(acc[1], bufB, SB, 32, 32 * wave, br.b2, lane);
         }
         __syncthreads();
+      } else {
+        bA0 = bufld4(w3rsrc, lane16, w3soff);
+        bA1 = bufld4(w3rsrc, lane16, w3soff + 16 * 1024);
+      }
+      if (ablate == 2) continue;
         // ---- conv3 (K = 128, N = 1024) + running max over points -----------------------------------
         // wave w owns channels [256w, 256w+256) = 8 column tiles, processed as 4 pairs with a
         // 2 (row tiles) x 2 (column tiles) register block: 64 accumulator registers.
+        // One continuous software pipeline over the 4 x 16 k-groups: two operand register sets (A/B)
+        // ping-pong, the operands of k-group g+1 are fetched while the 16 MFMAs of k-group g issue --
+        // across pair boundaries too -- and every memory instruction sits in its own MFMA shadow.
         {
             const float *a0p = bufB + (lane & 31) * SB + 4 * (lane >> 5);
             const float *a1p = a0p + 32 * SB;
-#pragma unroll 1
-            for (int pr = 0; pr < 4; ++pr) {
-                const float *wb0 = w3 + (long long)((8 * wave + 2 * pr) * 16) * 256 + lane * 4;
-                const float *wb1 = wb0 + 16 * 256;
-                f32x16 c00 = zero16(), c01 = zero16(), c10 = zero16(), c11 = zero16();
-                // explicit ping-pong pipeline: the operands of the next k-group are in flight while the
-                // 16 MFMAs (1024 cycles) of the current one issue (2x unrolled, two register sets).
 #define P2S_MFMA16(A0, A1, B0, B1)                                   \
     _Pragma("unroll") for (int t = 0; t < 4; ++t) {                  \
         c00 = mfma32(A0[t], B0[t], c00);                             \
@@ -213,41 +289,72 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
         c10 = mfma32(A1[t], B0[t], c10);                             \
         c11 = mfma32(A1[t], B1[t], c11);                             \
     }
-                f32x4 bA0 = ldg4(wb0), bA1 = ldg4(wb1);
-                f32x4 aA0 = lds4(a0p), aA1 = lds4(a1p);
+// first k-group of a pair: accumulate into literal zero (inline constant C operand, no v_mov init)
+#define P2S_MFMA16_FIRST(A0, A1, B0, B1)                             \
+    c00 = mfma32(A0[0], B0[0], zero16());                            \
+    c01 = mfma32(A0[0], B1[0], zero16());                            \
+    c10 = mfma32(A1[0], B0[0], zero16());                            \
+    c11 = mfma32(A1[0], B1[0], zero16());                            \
+    _Pragma("unroll") for (int t = 1; t < 4; ++t) {                  \
+        c00 = mfma32(A0[t], B0[t], c00);                             \
+        c01 = mfma32(A0[t], B1[t], c01);                             \
+        c10 = mfma32(A1[t], B0[t], c10);                             \
+        c11 = mfma32(A1[t], B1[t], c11);                             \
+    }
+// fetch the operands of k-group KG of pair PR into a register set.  B comes through a buffer descriptor
+// (SGPR base + scalar offset + one 32-bit lane offset): no 64-bit VALU address arithmetic in the loop.
+#define P2S_FETCH(BS0, BS1, AS0, AS1, PR, KG)                                                          \
+    BS0 = bufld4(w3rsrc, lane16, w3soff + (((2 * (PR)) * 16 + (KG)) * 1024));                           \
+    BS1 = bufld4(w3rsrc, lane16, w3soff + (((2 * (PR) + 1) * 16 + (KG)) * 1024));                       \
+    AS0 = lds4(a0p + 8 * (KG));                                                                         \
+    AS1 = lds4(a1p + 8 * (KG));
+// issue order of one 16-MFMA block: ONE memory instruction per MFMA shadow.  A VMEM/DS instruction costs
+// tens of issue cycles; clustered at the block boundary (or sunk to first use, the scheduler's default)
+// their issue time exceeds the 64-cycle shadow of one MFMA and the matrix pipe bubbles (measured: 13 %).
+#define P2S_SPREAD()                                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            f32x16 c00, c01, c10, c11;
+            aA0 = lds4(a0p);
+            aA1 = lds4(a1p);
+            if (tile + 1 < ntiles) load_point(tile + 1, nx0, nx1, nx2);   // lands during conv3
 #pragma unroll 1
-                for (int kg = 0; kg < 16; kg += 2) {
-                    f32x4 bB0 = ldg4(wb0 + (kg + 1) * 256);
-                    f32x4 bB1 = ldg4(wb1 + (kg + 1) * 256);
-                    f32x4 aB0 = lds4(a0p + 8 * (kg + 1));
-                    f32x4 aB1 = lds4(a1p + 8 * (kg + 1));
-                    P2S_MFMA16(aA0, aA1, bA0, bA1)
-                    const int kn = (kg + 2 < 16) ? kg + 2 : kg;   // last: harmless re-load
-                    bA0 = ldg4(wb0 + kn * 256);
-                    bA1 = ldg4(wb1 + kn * 256);
-                    aA0 = lds4(a0p + 8 * kn);
-                    aA1 = lds4(a1p + 8 * kn);
+            for (int pr = 0; pr < 4; ++pr) {
+                // k-group 0 (set A, C = 0) while set B <- k-group 1
+                P2S_FETCH(bB0, bB1, aB0, aB1, pr, 1)
+                P2S_MFMA16_FIRST(aA0, aA1, bA0, bA1)
+                P2S_SPREAD()
+#pragma unroll 1
+                for (int kg = 1; kg < 15; kg += 2) {
+                    P2S_FETCH(bA0, bA1, aA0, aA1, pr, kg + 1)
                     P2S_MFMA16(aB0, aB1, bB0, bB1)
-                    // pin the issue order: next operands first, then the MFMA block that hides them
-                    // (the default scheduler sinks every load to just before its first use)
-                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // 2 VMEM reads
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
-                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // 16 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                    P2S_SPREAD()
+                    P2S_FETCH(bB0, bB1, aB0, aB1, pr, kg + 2)
+                    P2S_MFMA16(aA0, aA1, bA0, bA1)
+                    P2S_SPREAD()
                 }
-#undef P2S_MFMA16
+                // k-group 15 (set B) while set A <- k-group 0 of the next pair (the last pair re-fetches its own)
+                const int prn = (pr < 3) ? pr + 1 : 3;
+                P2S_FETCH(bA0, bA1, aA0, aA1, prn, 0)
+                P2S_MFMA16(aB0, aB1, bB0, bB1)
+                P2S_SPREAD()
                 float m0 = tile_colmax(c00, c10);
                 float m1 = tile_colmax(c01, c11);
-                m0 = fmaxf(m0, __shfl_xor(m0, 32));
-                m1 = fmaxf(m1, __shfl_xor(m1, 32));
+                m0 = half_max(m0);
+                m1 = half_max(m1);
                 // static register indexing (runtime-indexed arrays would go to scratch)
                 if (pr == 0) { rmax[0] = fmaxf(rmax[0], m0); rmax[1] = fmaxf(rmax[1], m1); }
                 else if (pr == 1) { rmax[2] = fmaxf(rmax[2], m0); rmax[3] = fmaxf(rmax[3], m1); }
                 else if (pr == 2) { rmax[4] = fmaxf(rmax[4], m0); rmax[5] = fmaxf(rmax[5], m1); }
                 else { rmax[6] = fmaxf(rmax[6], m0); rmax[7] = fmaxf(rmax[7], m1); }
             }
+#undef P2S_MFMA16
+#undef P2S_MFMA16_FIRST
+#undef P2S_FETCH
+#undef P2S_SPREAD
         }
         // next tile's first layer writes bufA, whose last readers (conv2) are behind the barrier above
     }
@@ -300,10 +407,14 @@ __global__ __launch_bounds__(256) void p2s_fold_kernel(FoldArgs args) {
 
 }  // namespace
 
-int p2s_launch_chain(const ChainArgs &args, hipStream_t stream) {
-    const int n = args.br[0].n_items + args.br[1].n_items;
+int p2s_launch_chain(const ChainArgs &args_in, hipStream_t stream) {
+    const int n = args_in.br[0].n_items + args_in.br[1].n_items;
     if (n <= 0) return P2S_OK;
-    hipLaunchKernelGGL(p2s_chain_kernel, dim3(n), dim3(256), 0, stream, args);
+    ChainArgs args = args_in;
+    static const int ablate = getenv("P2S_CHAIN_ABLATE") ? atoi(getenv("P2S_CHAIN_ABLATE")) : 0;
+    static const int padlds = getenv("P2S_CHAIN_PADLDS") ? atoi(getenv("P2S_CHAIN_PADLDS")) : 0;   // occupancy knob
+    args.ablate = ablate;
+    hipLaunchKernelGGL(p2s_chain_kernel, dim3(n), dim3(256), padlds, stream, args);
     P2S_LAUNCH_CHECK("p2s_chain_kernel");
     return P2S_OK;
 }

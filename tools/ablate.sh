@@ -1,0 +1,14 @@
+#!/bin/bash
+# timing-only ablations of the chain kernel (development aid)
+run() {
+  python tools/quick_bench.py --B 4096 --iters 3 2>/dev/null | tail -1 | python -c '
+import sys, json
+d = json.loads(sys.stdin.read())
+print(round(d["ms"], 2), "ms; chain_stn", round(d["stages_ms"]["ms_chain_stn"], 2), "chain_main", round(d["stages_ms"]["ms_chain_main"], 2))'
+}
+for ab in ${ABL:-0 1 2}; do
+  for pad in ${PADS:-0}; do
+    echo -n "ablate=$ab padlds=$pad: "
+    P2S_CHAIN_ABLATE=$ab P2S_CHAIN_PADLDS=$pad run
+  done
+done
