@@ -13,6 +13,7 @@
 #include "p2s_common.h"
 #include "p2s_internal.h"
 #include <vector>
+#include <cstdlib>
 
 // a5 must reproduce numpy's fp32 results bit for bit: no FMA contraction anywhere in this file, and
 // sqrtf / operator/ (correctly rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt);
@@ -844,7 +845,16 @@ int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t nq, int n, int32_t
     } else {
         uint32_t mask = rng;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-        hipLaunchKernelGGL(p2s_mt_randint_kernel, dim3(1), dim3(128), 0, s, r->state, rng, mask, target, ids_out_dev);
+        // The recurrence is serial (one workgroup) and pure latency: co-resident MFMA-saturated encoder
+        // workgroups slow it ~3x.  Requesting most of a CU's LDS keeps any 50 KB encoder workgroup off its CU
+        // (the workgroup is placed when CUs drain at an encoder-kernel boundary); cost: 1 of 256 CUs.
+        static const int hog = getenv("P2S_RNG_LDS_HOG") ? atoi(getenv("P2S_RNG_LDS_HOG")) : 120 * 1024;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)p2s_mt_randint_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(p2s_mt_randint_kernel, dim3(1), dim3(128), hog, s, r->state, rng, mask, target, ids_out_dev);
         P2S_LAUNCH_CHECK("p2s_mt_randint_kernel");
     }
     if (pts_out_dev) return p2s_gather_points(c, ids_out_dev, target, pts_out_dev, stream);

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -59,12 +60,39 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
     if (chunk <= 0) chunk = m->max_chunk;
     chunk = std::min(chunk, m->max_chunk);
     if (getenv("P2S_NO_OVERLAP")) m->overlap = false;   // development knob: single-stream pipeline
+    hipStream_t s_user = s;
     if (m->overlap && !m->aux) {
-        // high queue priority: the data-path kernels are tiny next to the encoder kernel and must not
-        // wait behind its ~8k workgroups for a free CU slot
-        int lo = 0, hi = 0;
-        P2S_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, hi));
+        // The MT19937 recurrence is serial (one workgroup).  Sharing CUs with the MFMA-saturated encoder
+        // workgroups slows it ~3x and makes it the critical path, so it gets two CUs of its own
+        // (CU-masked stream) and the encoders / kNN run on a stream masked to the other CUs.
+        hipDeviceProp_t prop;
+        P2S_HIP_CHECK(hipGetDeviceProperties(&prop, m->device));
+        const int ncu = prop.multiProcessorCount;
+        const int words = (ncu + 31) / 32;
+        std::vector<uint32_t> mask_aux(words, 0u), mask_comp(words, 0u);
+        for (int cu = 0; cu < ncu; ++cu) {
+            const bool aux_cu = (cu == ncu - 1) || (cu == ncu / 2 - 1);
+            (aux_cu ? mask_aux : mask_comp)[cu / 32] |= 1u << (cu % 32);
+        }
+        if (!getenv("P2S_CUMASK") || ncu < 16 ||   // CU masking measured slower (masked compute stream loses >2 CUs)
+            hipExtStreamCreateWithCUMask(&m->aux, words, mask_aux.data()) != hipSuccess ||
+            hipExtStreamCreateWithCUMask(&m->comp, words, mask_comp.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            if (m->aux) (void)hipStreamDestroy(m->aux);
+            m->aux = m->comp = nullptr;
+            int lo = 0, hi = 0;
+            P2S_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, hi));
+        }
+    }
+    hipEvent_t ev_in = nullptr;
+    if (m->overlap && m->comp) {
+        // the caller's stream only orders the call: fork to the compute stream, join at the end
+        P2S_HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+        P2S_HIP_CHECK(hipEventRecord(ev_in, s_user));
+        P2S_HIP_CHECK(hipStreamWaitEvent(m->comp, ev_in, 0));
+        s = m->comp;
+        stream = (void *)m->comp;
     }
     hipStream_t sa = m->overlap ? m->aux : s;
 
@@ -84,6 +112,7 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
     auto fail = [&](int code) {
         (void)hipStreamSynchronize(s);
         if (sa != s) (void)hipStreamSynchronize(sa);
+        if (ev_in) (void)hipEventDestroy(ev_in);
         free_pipe(b);
         return code;
     };
@@ -115,37 +144,38 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
     }
 
     const int64_t nchunks = (nq + C - 1) / C;
-    auto produce = [&](int64_t ci) -> int {       // data path of chunk ci on the aux stream
+    auto produce = [&](int64_t ci) -> int {       // sub-sample ids of chunk ci on the aux stream
         const int bi = (int)(ci % nbuf);
         const int64_t q0 = q_begin + ci * C;
         const int cur = (int)std::min<int64_t>(C, q_end - q0);
-        const float *qc = b.q + (size_t)q0 * 3;
         if (ci >= nbuf && sa != s) P2S_HIP_CHECK(hipStreamWaitEvent(sa, b.freed[bi], 0));
-        const int ek0 = p2s_prof_mark(m, sa);
-        int rc2 = p2s_knn_patch(c, qc, cur, k, nullptr, b.patch[bi], b.radius[bi], sa);
+        const int e0 = p2s_prof_mark(m, sa);
+        const int rc2 = p2s_subsample_uniform(r, c, cur, n, b.sub_ids[bi], nullptr, sa);
         if (rc2) return rc2;
-        const int ek1 = p2s_prof_mark(m, sa);
-        rc2 = p2s_subsample_uniform(r, c, cur, n, b.sub_ids[bi], b.sub[bi], sa);
-        if (rc2) return rc2;
-        const int es1 = p2s_prof_mark(m, sa);
-        p2s_prof_span(m, ST_KNN, ek0, ek1);
-        p2s_prof_span(m, ST_SUB, ek1, es1);
+        p2s_prof_span(m, ST_SUB, e0, p2s_prof_mark(m, sa));
         if (sa != s) P2S_HIP_CHECK(hipEventRecord(b.ready[bi], sa));
         return P2S_OK;
     };
 
-    // prologue: up to nbuf chunks of data path in flight
+    // prologue: up to nbuf chunks of ids in flight
     for (int64_t ci = 0; ci < std::min<int64_t>(nbuf, nchunks); ++ci)
         if ((rc = produce(ci))) return fail(rc);
     for (int64_t ci = 0; ci < nchunks; ++ci) {
         const int bi = (int)(ci % nbuf);
         const int64_t q0 = q_begin + ci * C;
         const int cur = (int)std::min<int64_t>(C, q_end - q0);
+        const float *qc = b.q + (size_t)q0 * 3;
+        const int ek0 = p2s_prof_mark(m, s);
+        rc = p2s_knn_patch(c, qc, cur, k, nullptr, b.patch[bi], b.radius[bi], s);
+        if (rc) return fail(rc);
+        p2s_prof_span(m, ST_KNN, ek0, p2s_prof_mark(m, s));
         if (sa != s) P2S_HIP_CHECK(hipStreamWaitEvent(s, b.ready[bi], 0));
-        rc = p2s_run_chunk(m, b.patch[bi], b.sub[bi], b.q + (size_t)q0 * 3, b.radius[bi], cur, nullptr,
-                           sdf_out_dev + (q0 - q_begin), nullptr, nullptr, s);
+        rc = p2s_gather_points(c, b.sub_ids[bi], (int64_t)cur * n, b.sub[bi], s);
         if (rc) return fail(rc);
         if (sa != s) P2S_HIP_CHECK(hipEventRecord(b.freed[bi], s));
+        rc = p2s_run_chunk(m, b.patch[bi], b.sub[bi], qc, b.radius[bi], cur, nullptr, sdf_out_dev + (q0 - q_begin),
+                           nullptr, nullptr, s);
+        if (rc) return fail(rc);
         if (ci + nbuf < nchunks)
             if ((rc = produce(ci + nbuf))) return fail(rc);
     }
