@@ -169,6 +169,20 @@ int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int grid_resoluti
                     int64_t q_begin, int64_t q_end, int chunk, float *sdf_out_dev, float *q_out_dev,
                     int64_t *n_done, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * "next" row: the consumer of the SDF samples.  add_samples_to_volume + propagate_sign
+ * (+ the clamp that follows) of reference source/sdf.py:82-178,199-201: scatter the samples into a dense
+ * grid_res^3 volume, set the border faces to -1 (outside), propagate signs into the unknown voxels with a
+ * sigma^3 box filter (edge replication) thresholded at certainty_threshold until the number of unknown
+ * voxels stops falling.  vol_out_dev: [grid_res]^3 float32 in C order -- every value of the reference's
+ * float64 volume (float32 SDF samples, -1, 0, +1) is exactly representable.  One sample per voxel is
+ * expected (what the query grid produces).  *iterations (host, may be NULL) = number of sweeps.
+ * Synchronises `stream`.
+ * ------------------------------------------------------------------------------------------ */
+int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int64_t n, int grid_res, int sigma,
+                   float certainty_threshold, int clamp, int device, float *vol_out_dev, int32_t *iterations,
+                   void *stream);
+
 /* per-stage counters of the last p2s_encode_decode / p2s_infer_shape on this model
  * (HIP-event milliseconds on the launch stream; valid after the stream is synchronised) */
 typedef struct {

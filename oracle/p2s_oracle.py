@@ -458,3 +458,75 @@ def infer_shape(w, cfg, pts, grid_resolution, epsilon, rng, points_per_patch=300
         return dict(q=q, knn_ids=ids, radius=r, patch_ps=patch_ps, sub_ids=sub_ids, logits=logits, sdf=sdf,
                     q_total=q_all.shape[0])
     return q, sdf
+
+
+# --------------------------------------------------------------------------------------
+# "next" row f-1: SDF samples -> dense volume -> iterative sign propagation
+# --------------------------------------------------------------------------------------
+
+def add_samples_to_volume(vol, pos_ms, val):
+    """source/sdf.py:82-111.  The reference clusters samples by voxel with np.unique(axis=0) and keeps,
+    per voxel, the sample closest to the voxel centre -- but it measures the distance of every sample to
+    ITSELF (:94-95, always 0), so the first sample of each group wins; groups are cut from ``val`` in the
+    ORIGINAL order by the sorted-unique counts (:98-101), which is only meaningful when ``pos`` is already
+    sorted with one sample per voxel -- exactly what the query grid (a1) produces.  Restated literally."""
+    res = vol.shape[0]
+    pos_vs = model_space_to_volume_space(pos_ms, res)
+    _, counts = np.unique(pos_vs, return_counts=True, axis=0)
+    cuts = np.cumsum(counts)[:-1]
+    vals = np.split(np.asarray(val), cuts)
+    coords = np.split(pos_vs, cuts)
+    first = np.array([c[0] for c in coords])
+    vol[first[:, 0], first[:, 1], first[:, 2]] = np.array([v[0] for v in vals])
+    return vol
+
+
+def _box_sum_nearest(a, size):
+    """sum over a size^3 box with edge replication == scipy.ndimage.convolve(a, ones, mode='nearest')"""
+    res = a.shape[0]
+    idx = np.arange(res)
+    out = a
+    for axis in range(3):
+        acc = np.zeros_like(out)
+        for o in _box_offsets(int(size)):
+            acc = acc + np.take(out, np.clip(idx + o, 0, res - 1), axis=axis)
+        out = acc
+    return out
+
+
+def propagate_sign(vol, sigma=5, certainty_threshold=13, return_iters=False):
+    """source/sdf.py:114-178 (modifies and returns ``vol``, float64)."""
+    sgn = np.sign(vol)
+    unknown_initially = sgn == 0
+    vol[0, :, :] = -1.0
+    vol[-1, :, :] = -1.0
+    vol[:, 0, :] = -1.0
+    vol[:, -1, :] = -1.0
+    vol[:, :, 0] = -1.0
+    vol[:, :, -1] = -1.0
+    iters = 0
+    while True:
+        unknown_before = sgn == 0
+        if unknown_before.sum() == 0:
+            break
+        new = _box_sum_nearest(sgn, sigma)
+        new[np.abs(new) < certainty_threshold] = 0.0
+        new = np.sign(new)
+        iters += 1
+        if (new == 0).sum() >= unknown_before.sum():
+            break
+        sgn[unknown_initially] = new[unknown_initially]
+    zero = vol == 0
+    vol[zero] = sgn[zero]
+    return (vol, iters) if return_iters else vol
+
+
+def sdf_volume(query_pts_ms, query_dist_ms, grid_res, sigma, certainty_threshold, clamp=True):
+    """the volume source/sdf.py:181-201 hands to marching cubes (float64 [res]^3)."""
+    vol = np.zeros((grid_res, grid_res, grid_res))
+    vol = add_samples_to_volume(vol, query_pts_ms, query_dist_ms)
+    vol = propagate_sign(vol, sigma, certainty_threshold)
+    if clamp:
+        vol[vol < -1.0] = -1.0
+        vol[vol > 1.0] = 1.0
+    return vol

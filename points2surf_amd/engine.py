@@ -237,3 +237,27 @@ def infer_shape(model, cloud, rng, grid_resolution, epsilon, q_begin=0, q_end=-1
                                        int(q_begin), int(qe), int(chunk), _ptr(sdf), _ptr(q), ctypes.byref(done),
                                        _stream_ptr(dev)))
     return sdf[:nq], (q[:nq] if q is not None else None)
+
+
+def sdf_volume(query_pts_ms, query_dist_ms, grid_resolution, sigma, certainty_threshold, clamp=True):
+    """add_samples_to_volume + propagate_sign (+ clamp) of reference source/sdf.py:82-178,199-201
+    on the device.  Returns (volume [res,res,res] float32 device tensor, number of propagation sweeps)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError('points2surf_amd needs a ROCm GPU (gfx950); no CPU fallback exists')
+    lib = _lib.load()
+    if isinstance(query_pts_ms, np.ndarray):
+        query_pts_ms = torch.from_numpy(np.ascontiguousarray(query_pts_ms, dtype=np.float32)).cuda()
+    if isinstance(query_dist_ms, np.ndarray):
+        query_dist_ms = torch.from_numpy(np.ascontiguousarray(query_dist_ms, dtype=np.float32)).cuda()
+    dev = query_pts_ms.device
+    q = _f32c(query_pts_ms, dev)
+    d = _f32c(query_dist_ms.reshape(-1), dev)
+    if q.shape != (d.shape[0], 3):
+        raise ValueError('bad shapes %s %s' % (tuple(q.shape), tuple(d.shape)))
+    res = int(grid_resolution)
+    vol = torch.empty((res, res, res), dtype=torch.float32, device=dev)
+    iters = ctypes.c_int32(0)
+    with torch.cuda.device(dev):
+        _lib.check(lib.p2s_sdf_volume(_ptr(q), _ptr(d), d.shape[0], res, int(sigma), ctypes.c_float(certainty_threshold),
+                                      int(bool(clamp)), dev.index, _ptr(vol), ctypes.byref(iters), _stream_ptr(dev)))
+    return vol, int(iters.value)

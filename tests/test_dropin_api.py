@@ -89,3 +89,40 @@ def test_errors_mirror_reference(dropin_source):
     with pytest.raises(RuntimeError):      # CPU tensors: loud failure, no fallback
         m({'patch_pts_ps': torch.zeros(1, 300, 3), 'pts_sub_sample_ms': torch.zeros(1, 1000, 3),
            'imp_surf_query_point_ms': torch.zeros(1, 3)})
+
+
+@pytest.mark.skipif(not os.path.isfile('/root/reference/source/sdf.py'), reason='reference not present')
+def test_sdf_bridge_reexports_reference_and_overrides_two_functions():
+    """drop-in source.sdf: reference module re-exported, only the volume functions swapped (no GPU call here)"""
+    import numpy as np
+    from oracle import ref_shims
+    saved = {k: v for k, v in sys.modules.items() if k == 'source' or k.startswith('source.')}
+    for k in saved:
+        del sys.modules[k]
+    ref_shims._install_trimesh_stub()
+    if not hasattr(np, 'int'):
+        np.int = int
+    sys.path.insert(0, ref_shims.REFERENCE_ROOT)
+    sys.path.insert(0, DROPIN)
+    try:
+        import source.sdf as sdf
+        assert sdf.__file__.startswith(DROPIN)
+        ref = sys.modules['source._reference_sdf']
+        assert ref.__file__.startswith(ref_shims.REFERENCE_ROOT)
+        # re-exported reference functions (query grid helper is the reference's own object)
+        assert sdf.get_voxel_centers_grid_smaller_pc is ref.get_voxel_centers_grid_smaller_pc
+        assert sdf.implicit_surface_to_mesh_directory is ref.implicit_surface_to_mesh_directory
+        # the two overridden names are patched into the reference module too
+        assert ref.propagate_sign is sdf.propagate_sign and ref.add_samples_to_volume is sdf.add_samples_to_volume
+        v = sdf.add_samples_to_volume(np.zeros((8, 8, 8)), np.zeros((1, 3), np.float32), np.ones(1, np.float32))
+        assert v.shape == (8, 8, 8) and v._p2s_samples[1][0] == 1.0
+        import torch
+        if not torch.cuda.is_available():
+            with pytest.raises(RuntimeError):       # no GPU -> loud failure, not the reference's CPU loop
+                sdf.propagate_sign(v, 5, 13)
+    finally:
+        sys.path.remove(DROPIN)
+        sys.path.remove(ref_shims.REFERENCE_ROOT)
+        for k in [k for k in sys.modules if k == 'source' or k.startswith('source.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)

@@ -128,3 +128,15 @@ def test_torch_port_matches_reference(golden_dir, fixture_cloud, meta, model):
     r, ps = O.patch_radius_and_ps(fixture_cloud, g['knn_ids'][:nq], q[:nq])
     logits = port.forward(ps, fixture_cloud[g['sub_ids'][:nq]], q[:nq]).numpy()
     assert np.abs(logits - g['logits'][:nq]).max() < 1e-5
+
+
+@pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
+@pytest.mark.parametrize('sigma,thr', [(5, 13), (3, 5)])
+def test_sdf_volume_matches_reference(golden_dir, model, sigma, thr):
+    """row f-1: add_samples_to_volume + propagate_sign + clamp vs the unmodified reference"""
+    g = np.load(os.path.join(golden_dir, 'ref_volume_grid32.npz'))
+    q = np.load(os.path.join(golden_dir, 'query_grid_32_3.npy'))
+    sdf = np.load(os.path.join(golden_dir, 'ref_%s_grid32.npz' % model))['sdf_full']
+    vol = O.sdf_volume(q, sdf, 32, sigma, thr)
+    assert vol.dtype == np.float64
+    assert np.array_equal(vol, g['%s_s%d_t%d' % (model, sigma, thr)].astype(np.float64))

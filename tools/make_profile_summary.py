@@ -1,0 +1,51 @@
+"""Turn the rocprofv3 CSVs of tools/gpu_profile.sh (gpurun_out/prof_<tag>/) into the committed summaries
+under profiles/<round>/.   usage: python tools/make_profile_summary.py <tag> <round-dir>"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag, out = sys.argv[1], sys.argv[2]
+src = os.path.join('gpurun_out', 'prof_' + tag)
+os.makedirs(out, exist_ok=True)
+shutil.copy(os.path.join(src, 'trace', 'bench_kernel_stats.csv'), os.path.join(out, 'bench_kernel_stats.csv'))
+if os.path.isfile(os.path.join(src, 'counters_available.txt')):
+    shutil.copy(os.path.join(src, 'counters_available.txt'), os.path.join(out, 'counters_available.txt'))
+raw, rows = {}, []
+for name in sorted(d for d in os.listdir(src) if d.startswith('pmc_') and os.path.isdir(os.path.join(src, d))):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(os.path.join(src, name, 'pmc_counter_collection.csv'))):
+        k = r['Kernel_Name']
+        if 'p2s_' not in k:
+            continue
+        short = k.split('p2s_')[1].split('(')[0]
+        acc[(short, r['Counter_Name'])].append(float(r['Counter_Value']))
+        rows.append([name, short, r['Dispatch_Id'], r['Grid_Size'], r['Workgroup_Size'], r['LDS_Block_Size'],
+                     r['VGPR_Count'], r['Accum_VGPR_Count'], r['SGPR_Count'], r['Counter_Name'], r['Counter_Value'],
+                     int(r['End_Timestamp']) - int(r['Start_Timestamp'])])
+    for (k, c), v in acc.items():
+        raw.setdefault('p2s_' + k, {})[c] = {'dispatches': len(v), 'avg_per_dispatch': sum(v) / len(v)}
+with open(os.path.join(out, 'pmc_p2s_kernels.csv'), 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['pass', 'kernel', 'dispatch', 'grid', 'wg', 'lds_bytes', 'vgpr', 'agpr', 'sgpr', 'counter', 'value', 'duration_ns'])
+    w.writerows(rows)
+ch = raw['p2s_chain_kernel']
+dur = [r[-1] for r in rows if r[1] == 'chain_kernel' and r[9] == 'GRBM_GUI_ACTIVE']
+fetch = ch['FETCH_SIZE']['avg_per_dispatch'] * 1024 * 2      # KB -> B, x2 gfx950 correction (MI355X_MICROARCH.md, HBM)
+write = ch['WRITE_SIZE']['avg_per_dispatch'] * 1024
+cyc = ch['GRBM_GUI_ACTIVE']['avg_per_dispatch'] / 8
+summ = {'workload': 'tools/quick_bench.py --B 4096 --iters 1 (p2s_max encoders+decoder, 4096 synthetic queries): 6 chain launches',
+        'chain_kernel': {
+            'queries_per_launch': 4096,
+            'avg_duration_ms_under_pmc': sum(dur) / len(dur) / 1e6,
+            'cycles_per_launch': cyc, 'clock_GHz': cyc / (sum(dur) / len(dur)),
+            'mfma_busy_frac': ch['SQ_VALU_MFMA_BUSY_CYCLES']['avg_per_dispatch'] / (1024 * cyc),
+            'executed_mfma_flop_per_launch': ch['SQ_INSTS_VALU_MFMA_MOPS_F32']['avg_per_dispatch'] * 512,
+            'fetch_bytes_per_launch_corrected_x2': fetch, 'write_bytes_per_launch': write,
+            'hbm_traffic_bytes_per_launch': fetch + write,
+            'lds_bank_conflict_cycles': ch['SQ_LDS_BANK_CONFLICT']['avg_per_dispatch']},
+        'raw': raw}
+json.dump(summ, open(os.path.join(out, 'pmc_summary.json'), 'w'), indent=1)
+print(json.dumps(summ['chain_kernel'], indent=1))
