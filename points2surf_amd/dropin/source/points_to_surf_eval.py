@@ -16,7 +16,11 @@ Deliberate differences (documented in INTEGRATION.md):
     written only when trimesh is importable;
   * the non-reconstruction pass (GT query points with random rotation augmentation,
     source/data_loader.py:381-393) is outside the accelerated path and raises NotImplementedError;
-  * with torchrun (WORLD_SIZE > 1) shapes are sharded over ranks (one process per GPU).
+  * with torchrun (WORLD_SIZE > 1) shapes are sharded over ranks (one process per GPU).  By default every
+    rank also consumes the sub-sample draws of the shapes it does not own, so results stay identical to the
+    single-process run (dataset-wide stream); ``P2S_RNG_MODE=per_shape`` instead seeds shape i with
+    ``seed + i`` (no cross-shape dependency, scales freely, but differs from the reference from the second
+    shape on -- a declared deviation).
 """
 import argparse
 import os
@@ -219,7 +223,13 @@ def points_to_surf_eval(eval_opt):
             mine = set(_sharding.assign_lpt(sizes, world)[rank])
         total_q = 0
         t0 = time.time()
+        per_shape_rng = os.environ.get('P2S_RNG_MODE', 'dataset') == 'per_shape'
         for shape_ind, shape_name in enumerate(shape_names):
+            if per_shape_rng:
+                if shape_ind not in mine:
+                    continue
+                rng_dev = _engine.Rng((eval_opt.seed + shape_ind) & 0xffffffff, device=device)
+                rng_np = np.random.RandomState((eval_opt.seed + shape_ind) & 0xffffffff)
             pts_np = _load_points(eval_opt.indir, shape_name)
             if shape_ind not in mine:
                 # keep the dataset-wide stream exact on every rank: consume this shape's draws without inference
