@@ -149,6 +149,15 @@ int p2s_rng_destroy(p2s_rng_t r);
 int p2s_rng_get_state(p2s_rng_t r, uint32_t *mt624_host, int32_t *pos_host, void *stream);
 int p2s_rng_set_state(p2s_rng_t r, const uint32_t *mt624_host, int32_t pos, void *stream);
 
+/* Optional: tables for parallel generation of the stream (GF(2) jump-ahead, tools/mt_jump.py ->
+ * points2surf_amd/mt_jump_tables.npz): supports of t^(B*2^m*624) mod phi(t), m = 0..levels-1, concatenated
+ * (uint16 exponents), counts_host[m] entries each.  Requests of >= 400k values are then generated by
+ * 2^levels workgroups at once; the result is bit-identical to the serial generator. */
+int p2s_rng_set_jump_tables(p2s_rng_t r, const uint16_t *supports_host, const int32_t *counts_host, int levels,
+                            int blocks_per_stream);
+/* sticky error of the parallel generator (0 = none); synchronises `stream` */
+int p2s_rng_check(p2s_rng_t r, void *stream);
+
 /* uniform mode (p2s_max, uniform_subsample=1): ids = rng.randint(0, N, n) per query, consumed in
  * query order from one continuous stream.  ids_out_dev [Q][n] int32 (may be NULL),
  * pts_out_dev [Q][n][3] gathered points in model space (may be NULL). */

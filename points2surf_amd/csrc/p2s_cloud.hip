@@ -24,40 +24,6 @@
 #include <cstring>
 #include <algorithm>
 
-// ---------------------------------------------------------------------------------------------
-// handles
-// ---------------------------------------------------------------------------------------------
-struct CloudDev {
-    const float *pts;        // [n][3] original order (owned copy)
-    const float4 *spts;      // [n] sorted by cell: xyz + original id (bit cast)
-    const int *cell_start;   // [G^3 + 1]
-    const int *sat;          // [(G+1)^3] inclusive 3-D prefix sums of the per-cell counts
-    float lo[3];
-    float inv_cell;
-    int G;
-    int n;
-};
-
-struct p2s_cloud_s {
-    int device = 0;
-    CloudDev d = {};
-    float *pts = nullptr;
-    float4 *spts = nullptr;
-    int *cell_start = nullptr;
-    int *sat = nullptr;
-    // query-grid scratch (grown on demand)
-    uint32_t *occ = nullptr;
-    size_t occ_words = 0;
-    int *blk_cnt = nullptr;
-    size_t blk_cap = 0;
-    long long *totals = nullptr;   // [2] device: total count, error flag
-};
-
-struct p2s_rng_s {
-    int device = 0;
-    uint32_t *state = nullptr;   // [624] mt + [1] pos
-};
-
 namespace {
 
 __host__ __device__ inline int cell_coord(float x, float lo, float inv, int G) {
@@ -765,6 +731,27 @@ int p2s_gather_points(p2s_cloud_t c, const int32_t *ids_dev, int64_t n_ids, floa
 }
 
 // ---- RNG -----------------------------------------------------------------------------------------
+}  // extern "C"
+
+int p2s_rng_serial_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s) {
+    // The recurrence is serial (one workgroup) and pure latency: co-resident MFMA-saturated encoder
+    // workgroups slow it ~3x.  Requesting most of a CU's LDS keeps any 50 KB encoder workgroup off its CU
+    // (the workgroup is placed when CUs drain at an encoder-kernel boundary); cost: 1 of 256 CUs.
+    static const int hog = getenv("P2S_RNG_LDS_HOG") ? atoi(getenv("P2S_RNG_LDS_HOG")) : 120 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)p2s_mt_randint_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    // tiny requests (tests, tails) do not need a CU of their own
+    const int lds = target >= 100000 ? hog : 0;
+    hipLaunchKernelGGL(p2s_mt_randint_kernel, dim3(1), dim3(128), lds, s, r->state, rng, mask, target, out);
+    P2S_LAUNCH_CHECK("p2s_mt_randint_kernel");
+    return P2S_OK;
+}
+
+extern "C" {
+
 int p2s_rng_create(uint32_t seed, int device, p2s_rng_t *out) {
     if (!out) return P2S_EINVAL;
     if (p2s_device_count() <= device || device < 0) {
@@ -798,6 +785,11 @@ int p2s_rng_destroy(p2s_rng_t r) {
     if (!r) return P2S_OK;
     (void)hipSetDevice(r->device);
     if (r->state) (void)hipFree(r->state);
+    if (r->jump_sup) (void)hipFree(r->jump_sup);
+    if (r->streams) (void)hipFree(r->streams);
+    if (r->tmp) (void)hipFree(r->tmp);
+    if (r->blk_cum) (void)hipFree(r->blk_cum);
+    if (r->meta) (void)hipFree(r->meta);
     delete r;
     return P2S_OK;
 }
@@ -845,17 +837,12 @@ int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t nq, int n, int32_t
     } else {
         uint32_t mask = rng;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-        // The recurrence is serial (one workgroup) and pure latency: co-resident MFMA-saturated encoder
-        // workgroups slow it ~3x.  Requesting most of a CU's LDS keeps any 50 KB encoder workgroup off its CU
-        // (the workgroup is placed when CUs drain at an encoder-kernel boundary); cost: 1 of 256 CUs.
-        static const int hog = getenv("P2S_RNG_LDS_HOG") ? atoi(getenv("P2S_RNG_LDS_HOG")) : 120 * 1024;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)p2s_mt_randint_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(p2s_mt_randint_kernel, dim3(1), dim3(128), hog, s, r->state, rng, mask, target, ids_out_dev);
-        P2S_LAUNCH_CHECK("p2s_mt_randint_kernel");
+        // large requests: parallel generation over 2^levels jump-ahead streams; small ones: the serial kernel
+        static const long long par_min = getenv("P2S_RNG_PARALLEL_MIN") ? atoll(getenv("P2S_RNG_PARALLEL_MIN")) : 400000;
+        int rc;
+        if (r->levels > 0 && target >= par_min) rc = p2s_rng_parallel_randint(r, rng, mask, target, ids_out_dev, s);
+        else rc = p2s_rng_serial_randint(r, rng, mask, target, ids_out_dev, s);
+        if (rc) return rc;
     }
     if (pts_out_dev) return p2s_gather_points(c, ids_out_dev, target, pts_out_dev, stream);
     return P2S_OK;

@@ -35,3 +35,51 @@ int p2s_model_reserve(p2s_model_s *m, int chunk);
 int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const float *query, const float *radius,
                   int C, float *logits_out, float *sdf_out, float *feat_local_out, float *feat_global_out,
                   hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// cloud / rng handles (p2s_cloud.hip, p2s_rng.hip)
+// ---------------------------------------------------------------------------------------------
+struct CloudDev {
+    const float *pts;        // [n][3] original order (owned copy)
+    const float4 *spts;      // [n] sorted by cell: xyz + original id (bit cast)
+    const int *cell_start;   // [G^3 + 1]
+    const int *sat;          // [(G+1)^3] inclusive 3-D prefix sums of the per-cell counts
+    float lo[3];
+    float inv_cell;
+    int G;
+    int n;
+};
+
+struct p2s_cloud_s {
+    int device = 0;
+    CloudDev d = {};
+    float *pts = nullptr;
+    float4 *spts = nullptr;
+    int *cell_start = nullptr;
+    int *sat = nullptr;
+    // query-grid scratch (grown on demand)
+    uint32_t *occ = nullptr;
+    size_t occ_words = 0;
+    int *blk_cnt = nullptr;
+    size_t blk_cap = 0;
+    long long *totals = nullptr;   // [2] device: total count, error flag
+};
+
+struct p2s_rng_s {
+    int device = 0;
+    uint32_t *state = nullptr;     // [624] mt + [1] pos
+    // parallel generation (GF(2) jump-ahead), optional: tables uploaded by p2s_rng_set_jump_tables
+    int levels = 0;                // streams = 2^levels
+    int blocks_per_stream = 0;
+    uint16_t *jump_sup = nullptr;  // concatenated supports of the jump polynomials
+    int jump_off[16] = {};         // offset / count per level
+    int jump_cnt[16] = {};
+    uint32_t *streams = nullptr;   // [S][624] block states
+    uint32_t *tmp = nullptr;       // [S][B*624] accepted values per stream
+    int *blk_cum = nullptr;        // [S][B] cumulative accepted count per block
+    long long *meta = nullptr;     // [S] offsets + locate record + sticky error flag
+};
+
+// serial generator (p2s_cloud.hip) and parallel generator (p2s_rng.hip)
+int p2s_rng_serial_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s);
+int p2s_rng_parallel_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s);

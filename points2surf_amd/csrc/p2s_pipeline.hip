@@ -186,6 +186,8 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
     P2S_HIP_CHECK(hipStreamSynchronize(s));
     if (sa != s) P2S_HIP_CHECK(hipStreamSynchronize(sa));
     p2s_prof_collect(m);
+    rc = p2s_rng_check(r, s);
+    if (rc) return fail(rc);
     if (n_done) *n_done = nq;
     return fail(P2S_OK);
 }

@@ -4,12 +4,16 @@ PyTorch-ROCm tensors are used only as containers (device memory + streams); all 
 happens in libp2s_hip.so.  Nothing here computes on the CPU and nothing falls back.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
 
 from . import _lib
 from .weights import build_blob
+
+
+_JUMP_TABLES = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'mt_jump_tables.npz')
 
 
 def _stream_ptr(device):
@@ -171,7 +175,7 @@ class Rng:
     """Device twin of the dataset-wide ``np.random.RandomState(seed)`` used for the global
     sub-sample (reference source/data_loader.py:274-277)."""
 
-    def __init__(self, seed, device=None):
+    def __init__(self, seed, device=None, parallel=None):
         if not torch.cuda.is_available():
             raise RuntimeError('points2surf_amd needs a ROCm GPU (gfx950); no CPU fallback exists')
         self.lib = _lib.load()
@@ -182,6 +186,17 @@ class Rng:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.p2s_rng_create(ctypes.c_uint32(int(seed) & 0xffffffff), self.device.index,
                                                ctypes.byref(self.handle)))
+            if parallel is None:
+                parallel = not os.environ.get('P2S_RNG_SERIAL')
+            if parallel and os.path.isfile(_JUMP_TABLES):
+                t = np.load(_JUMP_TABLES)
+                levels = int(t['levels'])
+                sup = [np.ascontiguousarray(t['jump_%d' % m], dtype=np.uint16) for m in range(levels)]
+                counts = np.array([a.size for a in sup], dtype=np.int32)
+                flat = np.ascontiguousarray(np.concatenate(sup))
+                _lib.check(self.lib.p2s_rng_set_jump_tables(
+                    self.handle, flat.ctypes.data_as(ctypes.c_void_p), counts.ctypes.data_as(ctypes.c_void_p), levels,
+                    int(t['blocks_per_stream'])))
 
     def close(self):
         if getattr(self, 'handle', None):
@@ -208,6 +223,11 @@ class Rng:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.p2s_rng_set_state(self.handle, mt.ctypes.data_as(ctypes.c_void_p), int(pos),
                                                   _stream_ptr(self.device)))
+
+    def check(self):
+        """raise if the parallel generator flagged an (astronomically unlikely) overflow of its super-segment"""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_rng_check(self.handle, _stream_ptr(self.device)))
 
     def subsample_uniform(self, cloud, n_queries, n, want_pts=True):
         """a6 (uniform): ids [Q,n] int32 (+ gathered points [Q,n,3])"""
