@@ -37,6 +37,29 @@ __global__ void vol_scatter_kernel(const float *__restrict__ q, const float *__r
 
 __device__ __forceinline__ int sgn_of(float x) { return (x > 0.0f) - (x < 0.0f); }
 
+// counters: 64 shards per quantity ([0..64) zeros of s / next, [64..128) zeros of new), summed on the host.
+// One atomic per workgroup on shard blockIdx % 64: every wave hitting ONE address serialised at ~12 ns per
+// atomic and made the counting kernels 20-300x slower than their memory traffic.
+constexpr int NSHARD = 64;
+__device__ __forceinline__ void block_count2(int a, int b, unsigned long long *__restrict__ counts) {
+    __shared__ int red[2][4];
+    for (int d = 32; d > 0; d >>= 1) {
+        a += __shfl_xor(a, d);
+        b += __shfl_xor(b, d);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = a; red[1][wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        int sa = 0, sb = 0;
+        for (int w = 0; w < nw; ++w) { sa += red[0][w]; sb += red[1][w]; }
+        const int shard = blockIdx.x & (NSHARD - 1);
+        if (sa) atomicAdd(&counts[shard], (unsigned long long)sa);
+        if (sb) atomicAdd(&counts[NSHARD + shard], (unsigned long long)sb);
+    }
+}
+
 // s = sign(vol), unk0 = (s == 0); counts[0] += #unknown
 __global__ void vol_sign_init_kernel(const float *__restrict__ vol, long long nvox, signed char *__restrict__ s,
                                      unsigned char *__restrict__ unk0, unsigned long long *__restrict__ counts) {
@@ -48,8 +71,7 @@ __global__ void vol_sign_init_kernel(const float *__restrict__ vol, long long nv
         unk0[i] = sg == 0;
         z = sg == 0;
     }
-    const unsigned long long m = __ballot(z);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[0], (unsigned long long)__popcll(m));
+    block_count2(z, 0, counts);
 }
 
 // separable box sums with edge replication.  AXIS 2 = z (fastest), 1 = y, 0 = x
@@ -92,8 +114,7 @@ __global__ void vol_boxsum_x_sign_kernel(const short *__restrict__ in, signed ch
         newsgn[i] = (signed char)sg;
         zero = sg == 0;
     }
-    const unsigned long long m = __ballot(zero);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[1], (unsigned long long)__popcll(m));
+    block_count2(0, zero, counts);
 }
 
 // accepted sweep: s[unknown_initially] = new[unknown_initially]; counts[0] += #zeros of the updated s
@@ -110,8 +131,7 @@ __global__ void vol_apply_kernel(signed char *__restrict__ s, const signed char 
         }
         zero = v == 0;
     }
-    const unsigned long long m = __ballot(zero);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[0], (unsigned long long)__popcll(m));
+    block_count2(zero, 0, counts);
 }
 
 // borders := -1 ; remaining zeros := propagated sign ; optional clamp to [-1, 1]
@@ -223,15 +243,7 @@ __global__ __launch_bounds__(256) void vol16_x_kernel(const u32x4 *__restrict__ 
         }
         s_next[i] = o;
     }
-    // wave reduction, one atomic pair per wave
-    for (int d = 32; d > 0; d >>= 1) {
-        z_new += __shfl_xor(z_new, d);
-        z_next += __shfl_xor(z_next, d);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (z_new) atomicAdd(&counts[1], (unsigned long long)z_new);
-        if (z_next) atomicAdd(&counts[0], (unsigned long long)z_next);
-    }
+    block_count2(z_next, z_new, counts);
 }
 
 }  // namespace
@@ -252,8 +264,8 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
     const long long nvox = (long long)grid_res * grid_res * grid_res;
     // scratch: sign (1) + unknown_initially (1) + new sign (1) + z sums (1) + zy sums (2) bytes per voxel
     char *scratch = nullptr;
-    unsigned long long *counts = nullptr;   // [0] zeros of s, [1] zeros of new, [2] error flag (as int)
-    if (hipMalloc(&scratch, (size_t)nvox * 7) != hipSuccess || hipMalloc(&counts, 32) != hipSuccess) {
+    unsigned long long *counts = nullptr;   // [0..64) zeros of s, [64..128) zeros of new, [128] error flag (as int)
+    if (hipMalloc(&scratch, (size_t)nvox * 7) != hipSuccess || hipMalloc(&counts, (2 * NSHARD + 2) * 8) != hipSuccess) {
         if (scratch) (void)hipFree(scratch);
         p2s_set_error("p2s_sdf_volume: hipMalloc(%lld bytes) failed", nvox * 6);
         (void)hipGetLastError();
@@ -277,21 +289,29 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
     for (int j = 0; j < sigma; ++j) off.o[j] = sigma / 2 - j;   // scipy.ndimage.convolve, origin 0
 
     if (hipMemsetAsync(vol_out_dev, 0, (size_t)nvox * 4, s) != hipSuccess ||
-        hipMemsetAsync(counts, 0, 32, s) != hipSuccess) {
+        hipMemsetAsync(counts, 0, (2 * NSHARD + 2) * 8, s) != hipSuccess) {
         p2s_set_error("p2s_sdf_volume: memset failed");
         return cleanup(P2S_EHIP);
     }
     if (n > 0) {
         hipLaunchKernelGGL(vol_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, query_dev, sdf_dev,
-                           (long long)n, grid_res, vol_out_dev, (int *)(counts + 2));
+                           (long long)n, grid_res, vol_out_dev, (int *)(counts + 2 * NSHARD));
     }
     hipLaunchKernelGGL(vol_sign_init_kernel, dim3(grid), dim3(256), 0, s, vol_out_dev, nvox, sg, unk0, counts);
-    unsigned long long h[4] = {0, 0, 0, 0};
-    if (hipMemcpyAsync(h, counts, 32, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    unsigned long long hc[2 * NSHARD + 2];
+    unsigned long long h[2] = {0, 0};
+    auto read_counts = [&]() -> bool {
+        if (hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+            return false;
+        h[0] = h[1] = 0;
+        for (int i = 0; i < NSHARD; ++i) { h[0] += hc[i]; h[1] += hc[NSHARD + i]; }
+        return true;
+    };
+    if (!read_counts()) {
         p2s_set_error("p2s_sdf_volume: %s", hipGetErrorString(hipGetLastError()));
         return cleanup(P2S_EHIP);
     }
-    if ((int)h[2]) {
+    if ((int)hc[2 * NSHARD]) {
         p2s_set_error("p2s_sdf_volume: query point outside the [-1,1) volume");
         return cleanup(P2S_EINVAL);
     }
@@ -304,12 +324,12 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
         const unsigned gv = (unsigned)((nvec + 255) / 256);
         signed char *cur = sg, *nxt = sg2;
         while (unknown_before != 0) {
-            (void)hipMemsetAsync(counts, 0, 16, s);
+            (void)hipMemsetAsync(counts, 0, 2 * NSHARD * 8, s);
             hipLaunchKernelGGL(vol16_z_kernel, dim3(gv), dim3(256), 0, s, (const u32x4 *)cur, (u32x4 *)t1, grid_res, nvec, off);
             hipLaunchKernelGGL(vol16_y_kernel, dim3(gv), dim3(256), 0, s, (const u32x4 *)t1, (u32x4 *)t2, grid_res, nvec, off);
             hipLaunchKernelGGL(vol16_x_kernel, dim3(gv), dim3(256), 0, s, (const u32x4 *)t2, (const u32x4 *)cur,
                                (const u32x4 *)unk0, (u32x4 *)nxt, grid_res, nvec, off, certainty_threshold, counts);
-            if (hipMemcpyAsync(h, counts, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            if (!read_counts()) {
                 p2s_set_error("p2s_sdf_volume: %s", hipGetErrorString(hipGetLastError()));
                 return cleanup(P2S_EHIP);
             }
@@ -321,12 +341,12 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
         s_final = cur;
     } else {
     while (unknown_before != 0) {
-        (void)hipMemsetAsync(counts, 0, 16, s);
+        (void)hipMemsetAsync(counts, 0, 2 * NSHARD * 8, s);
         hipLaunchKernelGGL((vol_boxsum_kernel<signed char, signed char, 2>), dim3(grid), dim3(256), 0, s, sg, t1, grid_res, off);
         hipLaunchKernelGGL((vol_boxsum_kernel<signed char, short, 1>), dim3(grid), dim3(256), 0, s, t1, t2, grid_res, off);
         hipLaunchKernelGGL(vol_boxsum_x_sign_kernel, dim3(grid), dim3(256), 0, s, t2, newsg, grid_res, off,
                            certainty_threshold, counts);
-        if (hipMemcpyAsync(h, counts, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        if (!read_counts()) {
             p2s_set_error("p2s_sdf_volume: %s", hipGetErrorString(hipGetLastError()));
             return cleanup(P2S_EHIP);
         }
@@ -334,7 +354,7 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
         const unsigned long long unknown_after = h[1];
         if (unknown_after >= unknown_before) break;   // no progress: some voxels are caught in a tie
         hipLaunchKernelGGL(vol_apply_kernel, dim3(grid), dim3(256), 0, s, sg, newsg, unk0, nvox, counts);
-        if (hipMemcpyAsync(h, counts, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        if (!read_counts()) {
             p2s_set_error("p2s_sdf_volume: %s", hipGetErrorString(hipGetLastError()));
             return cleanup(P2S_EHIP);
         }
