@@ -131,3 +131,41 @@ def test_module_forward_b2(dropin_source, fixture_cloud, golden_dir):
     assert np.abs(pred.cpu().numpy() - g['logits']).max() < 1e-4
     assert torch.equal(pred, pred2)
     assert torch.allclose(sub, sub0 - q.unsqueeze(1))            # reference side effect (:303)
+
+
+def test_sharded_eval_is_identical_to_single_process(dropin_source, tmp_path, fixture_cloud, monkeypatch):
+    """shape sharding keeps the dataset-wide RNG stream exact: two 'ranks' (run one after the other here, each
+    consuming the draws of the shapes it does not own) write the same files as the single-process run"""
+    ev, _ = dropin_source
+    root = str(tmp_path / 'ds')
+    rng = np.random.default_rng(0)
+    names = []
+    os.makedirs(os.path.join(root, '04_pts'), exist_ok=True)
+    for i, n in enumerate((9000, 6000, 12000)):                      # three different clouds (sizes -> LPT order)
+        sel = rng.choice(fixture_cloud.shape[0], n, replace=False)
+        names.append('shape_%d' % i)
+        np.save(os.path.join(root, '04_pts', names[-1] + '.xyz.npy'), fixture_cloud[np.sort(sel)])
+    with open(os.path.join(root, 'testset.txt'), 'w') as f:
+        f.write('\n'.join(names) + '\n')
+    modeldir = str(tmp_path / 'models')
+    _write_model_files(modeldir, 'p2s_max')
+
+    def run(outdir, world, rank):
+        monkeypatch.setenv('WORLD_SIZE', str(world))
+        monkeypatch.setenv('RANK', str(rank))
+        monkeypatch.setenv('LOCAL_RANK', '0')
+        opt = ev.parse_arguments(['--indir', root, '--outdir', outdir, '--dataset', 'testset.txt', '--modeldir', modeldir,
+                                  '--models', 'p2s_max', '--query_grid_resolution', '24', '--epsilon', '3'])
+        opt.reconstruction = True
+        ev.points_to_surf_eval(opt)
+
+    single = str(tmp_path / 'single')
+    run(single, 1, 0)
+    sharded = str(tmp_path / 'sharded')
+    run(sharded, 2, 0)
+    run(sharded, 2, 1)
+    for n in names:
+        a = np.load(os.path.join(single, 'rec', 'dist_ms', n + '.xyz.npy'))
+        b = np.load(os.path.join(sharded, 'rec', 'dist_ms', n + '.xyz.npy'))
+        assert a.shape == b.shape and a.size > 500
+        assert np.array_equal(a, b), n
