@@ -199,7 +199,11 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
         }
     };
 
-    const int ablate = args.ablate;
+#ifdef P2S_DEV_ABLATE
+    const int ablate = args.ablate;   // timing-only variants (wrong results): tools/ablate.sh builds with -DP2S_DEV_ABLATE
+#else
+    constexpr int ablate = 0;
+#endif
     const int ntiles = (P + MT - 1) / MT;
     float nx0, nx1, nx2;
     load_point(0, nx0, nx1, nx2);
@@ -411,9 +415,13 @@ int p2s_launch_chain(const ChainArgs &args_in, hipStream_t stream) {
     const int n = args_in.br[0].n_items + args_in.br[1].n_items;
     if (n <= 0) return P2S_OK;
     ChainArgs args = args_in;
+    int padlds = 0;
+#ifdef P2S_DEV_ABLATE
     static const int ablate = getenv("P2S_CHAIN_ABLATE") ? atoi(getenv("P2S_CHAIN_ABLATE")) : 0;
-    static const int padlds = getenv("P2S_CHAIN_PADLDS") ? atoi(getenv("P2S_CHAIN_PADLDS")) : 0;   // occupancy knob
+    static const int pad_env = getenv("P2S_CHAIN_PADLDS") ? atoi(getenv("P2S_CHAIN_PADLDS")) : 0;   // occupancy knob
     args.ablate = ablate;
+    padlds = pad_env;
+#endif
     hipLaunchKernelGGL(p2s_chain_kernel, dim3(n), dim3(256), padlds, stream, args);
     P2S_LAUNCH_CHECK("p2s_chain_kernel");
     return P2S_OK;

@@ -52,7 +52,7 @@ struct ChainBranch {
 };
 struct ChainArgs {
     ChainBranch br[2];       // br[0] items come first in the grid
-    int ablate;              // development only (P2S_CHAIN_ABLATE): 1 = conv3 only, 2 = all but conv3 (wrong results)
+    int ablate;              // only read when built with -DP2S_DEV_ABLATE (timing variants: 1 = conv3 only, 2 = all but conv3)
 };
 int p2s_launch_chain(const ChainArgs &args, hipStream_t stream);
 

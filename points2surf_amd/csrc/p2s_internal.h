@@ -20,8 +20,7 @@ struct p2s_model_s {
     std::vector<Span> spans;
     p2s_counters counters = {};
     // auxiliary stream: the data path (kNN, sub-sample) of chunk i+1, i+2 overlaps the encoders of chunk i
-    hipStream_t aux = nullptr;     // serial MT19937 sub-sample stream: CU-masked to its own 2 CUs
-    hipStream_t comp = nullptr;    // everything else of p2s_infer_shape: the remaining CUs
+    hipStream_t aux = nullptr;     // high-priority stream of the sub-sample generator
     bool overlap = true;
 };
 

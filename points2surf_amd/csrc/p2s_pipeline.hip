@@ -10,7 +10,6 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
-#include <vector>
 
 namespace {
 
@@ -60,39 +59,13 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
     if (chunk <= 0) chunk = m->max_chunk;
     chunk = std::min(chunk, m->max_chunk);
     if (getenv("P2S_NO_OVERLAP")) m->overlap = false;   // development knob: single-stream pipeline
-    hipStream_t s_user = s;
     if (m->overlap && !m->aux) {
-        // The MT19937 recurrence is serial (one workgroup).  Sharing CUs with the MFMA-saturated encoder
-        // workgroups slows it ~3x and makes it the critical path, so it gets two CUs of its own
-        // (CU-masked stream) and the encoders / kNN run on a stream masked to the other CUs.
-        hipDeviceProp_t prop;
-        P2S_HIP_CHECK(hipGetDeviceProperties(&prop, m->device));
-        const int ncu = prop.multiProcessorCount;
-        const int words = (ncu + 31) / 32;
-        std::vector<uint32_t> mask_aux(words, 0u), mask_comp(words, 0u);
-        for (int cu = 0; cu < ncu; ++cu) {
-            const bool aux_cu = (cu == ncu - 1) || (cu == ncu / 2 - 1);
-            (aux_cu ? mask_aux : mask_comp)[cu / 32] |= 1u << (cu % 32);
-        }
-        if (!getenv("P2S_CUMASK") || ncu < 16 ||   // CU masking measured slower (masked compute stream loses >2 CUs)
-            hipExtStreamCreateWithCUMask(&m->aux, words, mask_aux.data()) != hipSuccess ||
-            hipExtStreamCreateWithCUMask(&m->comp, words, mask_comp.data()) != hipSuccess) {
-            (void)hipGetLastError();
-            if (m->aux) (void)hipStreamDestroy(m->aux);
-            m->aux = m->comp = nullptr;
-            int lo = 0, hi = 0;
-            P2S_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, hi));
-        }
-    }
-    hipEvent_t ev_in = nullptr;
-    if (m->overlap && m->comp) {
-        // the caller's stream only orders the call: fork to the compute stream, join at the end
-        P2S_HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
-        P2S_HIP_CHECK(hipEventRecord(ev_in, s_user));
-        P2S_HIP_CHECK(hipStreamWaitEvent(m->comp, ev_in, 0));
-        s = m->comp;
-        stream = (void *)m->comp;
+        // high queue priority: the data-path kernels are tiny next to the encoder kernel and must not queue
+        // behind its ~8k workgroups for a free CU slot.  (Giving the stream its own CUs with a CU mask was
+        // measured slower: the masked compute stream lost far more than the masked-off CUs.)
+        int lo = 0, hi = 0;
+        P2S_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, hi));
     }
     hipStream_t sa = m->overlap ? m->aux : s;
 
@@ -112,7 +85,6 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
     auto fail = [&](int code) {
         (void)hipStreamSynchronize(s);
         if (sa != s) (void)hipStreamSynchronize(sa);
-        if (ev_in) (void)hipEventDestroy(ev_in);
         free_pipe(b);
         return code;
     };

@@ -1,0 +1,78 @@
+"""Stress / randomized checks of the data-path kernels against the oracle (GPU)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_knn_large_clustered_cloud_with_duplicates():
+    """N = 150k (the reference's maximum, make_pc_dataset.py:39): uniform part + tight clusters + exact duplicates.
+    Distance ties make the id choice implementation-defined (also in cKDTree), so distances are compared."""
+    import torch
+    from oracle import p2s_oracle as O
+    from points2surf_amd import engine
+    rng = np.random.default_rng(42)
+    parts = [rng.uniform(-0.5, 0.5, (100000, 3)),
+             0.002 * rng.standard_normal((30000, 3)) + rng.uniform(-0.4, 0.4, (30, 1, 3)).repeat(1000, 1).reshape(-1, 3),
+             np.repeat(rng.uniform(-0.3, 0.3, (40, 3)), 500, axis=0)]          # 40 locations x 500 identical points
+    pts = np.concatenate(parts).astype(np.float32)
+    assert pts.shape[0] == 150000
+    cloud = engine.Cloud(pts)
+    q = np.concatenate([pts[rng.integers(0, pts.shape[0], 150)] + rng.normal(0, 0.003, (150, 3)).astype(np.float32),
+                        parts[2][::500][:20].astype(np.float32),                # queries exactly on duplicate stacks
+                        rng.uniform(-0.9, 0.9, (30, 3)).astype(np.float32)]).astype(np.float32)
+    ids, _, rad = cloud.knn_patch(torch.from_numpy(q).cuda(), 300)
+    ids = ids.cpu().numpy()
+    ref = O.knn_ids(pts, q, 300)
+    p64, q64 = pts.astype(np.float64), q.astype(np.float64)
+    d_dev = ((p64[ids] - q64[:, None, :]) ** 2).sum(-1)
+    d_ref = ((p64[ref] - q64[:, None, :]) ** 2).sum(-1)
+    assert np.array_equal(np.sort(d_dev, axis=1), np.sort(d_ref, axis=1))       # the same 300 distances
+    assert (np.diff(d_dev, axis=1) >= 0).all()                                  # ascending, like cKDTree
+    for row in ids:
+        assert len(set(row.tolist())) == 300                                    # no point twice
+    no_tie = np.array([len(np.unique(d)) == 300 for d in d_ref])
+    assert np.array_equal(ids[no_tie], ref[no_tie])                             # without ties: identical ids
+    r_ref, _ = O.patch_radius_and_ps(pts, ids, q)
+    assert np.array_equal(rad.cpu().numpy(), r_ref)
+
+
+def test_query_grid_random_clouds_match_oracle():
+    import torch
+    from oracle import p2s_oracle as O
+    from points2surf_amd import engine
+    rng = np.random.default_rng(7)
+    for trial in range(12):
+        n = int(rng.integers(1, 4000))
+        res = int(rng.choice([8, 17, 32, 50, 64, 96]))
+        eps = int(rng.integers(1, 8))
+        scale = rng.choice([0.1, 0.5, 0.99])
+        pts = (rng.uniform(-1, 1, (n, 3)) * scale).astype(np.float32)
+        if trial % 3 == 0:
+            pts[: max(1, n // 10)] = np.float32(0.999)               # points in the last voxel slab (dropped by [:-1])
+            pts[-1] = np.float32(-1.0)                               # exactly on the lower border
+        q_ref, _ = O.query_grid(pts, res, eps)
+        q = engine.Cloud(pts).query_grid(res, eps).cpu().numpy()
+        assert q.shape == q_ref.shape, (trial, n, res, eps)
+        assert np.array_equal(q, q_ref), (trial, n, res, eps)
+
+
+def test_forward_extreme_but_finite_inputs(fixture_cloud):
+    """large coordinates / tiny radius do not break parity with the oracle"""
+    import torch
+    from oracle import p2s_oracle as O
+    from points2surf_amd import engine, synth
+    w, cfg = synth.make_weights('p2s_max')
+    m = engine.Model(w, cfg)
+    rng = np.random.default_rng(3)
+    B = 5
+    patch = rng.uniform(-1, 1, (B, 300, 3)).astype(np.float32)
+    patch[0] *= 1e-6                                                  # degenerate tiny patch
+    patch[1, :, 0] = 1.0                                              # all points on a plane
+    sub = rng.uniform(-50, 50, (B, 1000, 3)).astype(np.float32)      # far outside the unit cube
+    q = rng.uniform(-1, 1, (B, 3)).astype(np.float32)
+    ref = O.model_forward(w, cfg, patch, sub, q)
+    t = lambda a: torch.from_numpy(a).cuda()
+    logits, _ = m.forward(t(patch), t(sub), t(q))
+    err = np.abs(logits.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+    assert err < 1e-5, err

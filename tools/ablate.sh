@@ -1,5 +1,6 @@
 #!/bin/bash
-# timing-only ablations of the chain kernel (development aid)
+# timing-only ablations of the chain kernel (development aid).  Needs a library built with the ablation switch:
+#   P2S_EXTRA_HIPCC_FLAGS=-DP2S_DEV_ABLATE python -m points2surf_amd.build --force
 run() {
   python tools/quick_bench.py --B 4096 --iters 3 2>/dev/null | tail -1 | python -c '
 import sys, json
