@@ -190,13 +190,19 @@ class Rng:
                 parallel = not os.environ.get('P2S_RNG_SERIAL')
             if parallel and os.path.isfile(_JUMP_TABLES):
                 t = np.load(_JUMP_TABLES)
-                levels = int(t['levels'])
-                sup = [np.ascontiguousarray(t['jump_%d' % m], dtype=np.uint16) for m in range(levels)]
+                # table entry m = jump of base*2^m blocks.  Streams of `bps` blocks need the entries from
+                # log2(bps/base) upwards; fewer, longer streams mean fewer dependent jump rounds (each round is a
+                # separate launch that has to find CU space next to the encoder kernel): 16 x 1024 by default.
+                base = int(t['blocks_per_stream'])
+                bps = int(os.environ.get('P2S_RNG_BLOCKS_PER_STREAM', 1024))
+                first = max(0, int(round(np.log2(bps / base))))
+                levels = int(t['levels']) - first
+                bps = base << first
+                sup = [np.ascontiguousarray(t['jump_%d' % (first + m)], dtype=np.uint16) for m in range(levels)]
                 counts = np.array([a.size for a in sup], dtype=np.int32)
                 flat = np.ascontiguousarray(np.concatenate(sup))
                 _lib.check(self.lib.p2s_rng_set_jump_tables(
-                    self.handle, flat.ctypes.data_as(ctypes.c_void_p), counts.ctypes.data_as(ctypes.c_void_p), levels,
-                    int(t['blocks_per_stream'])))
+                    self.handle, flat.ctypes.data_as(ctypes.c_void_p), counts.ctypes.data_as(ctypes.c_void_p), levels, bps))
 
     def close(self):
         if getattr(self, 'handle', None):
