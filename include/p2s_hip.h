@@ -54,7 +54,9 @@ typedef struct {
     int32_t output_dim;          /* 2: [|d| logit, sign logit]                                 */
     int32_t use_point_stn;       /* QSTN present (p2s_vanilla)                                 */
     int32_t shared_transformer;  /* one QSTN over cat(patch, sub-sample) (p2s_vanilla)         */
-    int32_t reserved[10];
+    int32_t weighted_subsample;  /* 0: ids = randint (train --uniform_subsample 1, p2s_max);
+                                    1: distance-weighted choice without replacement (p2s_vanilla) */
+    int32_t reserved[9];
 } p2s_model_cfg;
 
 /* Offsets (in floats) into the weight blob.  The blob holds BatchNorm-folded fp32 weights,
@@ -163,7 +165,15 @@ int p2s_rng_check(p2s_rng_t r, void *stream);
  * pts_out_dev [Q][n][3] gathered points in model space (may be NULL). */
 int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t n_queries, int n,
                           int32_t *ids_out_dev, float *pts_out_dev, void *stream);
-/* given-ids mode (p2s_vanilla parity mode: ids from the host's legacy choice(p, replace=False)) */
+/* distance-weighted mode (p2s_vanilla, uniform_subsample=0; reference source/base/utils.py:200-219):
+ * per query p = clip(1 - 1.5 d/max(d), 0.05, 1) / sum (float32, numpy's summation order) and
+ * ids = rng.choice(N, n, replace=False, p=p), consumed in query order from the same continuous stream --
+ * bit-identical to numpy's legacy RandomState.  Needs the jump tables (p2s_rng_set_jump_tables).
+ * q_dev [Q][3] query points (model space), ids_out_dev [Q][n] int32, pts_out_dev as above (may be NULL).
+ * Errors found on the device (degenerate distances) are reported by p2s_rng_check. */
+int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q_dev, int64_t n_queries, int n,
+                           int32_t *ids_out_dev, float *pts_out_dev, void *stream);
+/* given-ids mode (ids produced elsewhere, e.g. fixed_subsample experiments) */
 int p2s_gather_points(p2s_cloud_t c, const int32_t *ids_dev, int64_t n_ids, float *pts_out_dev,
                       void *stream);
 

@@ -620,6 +620,7 @@ int p2s_cloud_destroy(p2s_cloud_t c) {
     if (c->occ) (void)hipFree(c->occ);
     if (c->blk_cnt) (void)hipFree(c->blk_cnt);
     if (c->totals) (void)hipFree(c->totals);
+    if (c->wc_plan) (void)hipFree(c->wc_plan);
     delete c;
     return P2S_OK;
 }
@@ -790,6 +791,7 @@ int p2s_rng_destroy(p2s_rng_t r) {
     if (r->tmp) (void)hipFree(r->tmp);
     if (r->blk_cum) (void)hipFree(r->blk_cum);
     if (r->meta) (void)hipFree(r->meta);
+    p2s_wc_free_rng(r);
     delete r;
     return P2S_OK;
 }

@@ -62,6 +62,9 @@ struct p2s_cloud_s {
     int *blk_cnt = nullptr;
     size_t blk_cap = 0;
     long long *totals = nullptr;   // [2] device: total count, error flag
+    // summation plan of np.sum(float32[n]) for the weighted sub-sample (p2s_wchoice.hip), built on first use
+    int *wc_plan = nullptr;        // device: leaves [L][3], ops [O][3], level offsets [levels+1]
+    int wc_leaves = 0, wc_ops_at = 0, wc_lvl_at = 0, wc_levels = 0, wc_root = 0;
 };
 
 struct p2s_rng_s {
@@ -76,9 +79,21 @@ struct p2s_rng_s {
     uint32_t *streams = nullptr;   // [S][624] block states
     uint32_t *tmp = nullptr;       // [S][B*624] accepted values per stream
     int *blk_cum = nullptr;        // [S][B] cumulative accepted count per block
-    long long *meta = nullptr;     // [S] offsets + locate record + sticky error flag
+    long long *meta = nullptr;     // [S] offsets + locate record + sticky error flag + raw-request record
+    // weighted sub-sample workspace (p2s_wchoice.hip), grown on demand
+    float *wc_dist = nullptr;      // [C][n]   distances to the query
+    double *wc_S = nullptr;        // [C][n]   exact prefix sums of the probabilities
+    int *wc_T = nullptr;           // [C][K]   guide table of the cdf
+    double *wc_stot = nullptr;     // [C]
+    size_t wc_cap_q = 0, wc_cap_n = 0, wc_cap_k = 0;
 };
 
 // serial generator (p2s_cloud.hip) and parallel generator (p2s_rng.hip)
 int p2s_rng_serial_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s);
 int p2s_rng_parallel_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s);
+// raw 32-bit words after the generator's position, flat in r->tmp, committed later by a device-side count
+long long p2s_rng_raw_capacity(const p2s_rng_s *r);
+long long *p2s_rng_raw_meta(p2s_rng_s *r);       // device: [0] words consumed by the raw request, [1] sticky error
+int p2s_rng_raw_begin(p2s_rng_s *r, hipStream_t s);
+int p2s_rng_raw_commit(p2s_rng_s *r, hipStream_t s);
+void p2s_wc_free_rng(p2s_rng_s *r);               // p2s_wchoice.hip workspace

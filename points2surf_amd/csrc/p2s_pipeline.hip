@@ -47,12 +47,7 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
         p2s_set_error("p2s_infer_shape: null argument");
         return P2S_EINVAL;
     }
-    if (m->cfg.use_point_stn) {
-        // p2s_vanilla draws the sub-sample with legacy choice(p, replace=False): ids come from the host
-        p2s_set_error("p2s_infer_shape: model needs the distance-weighted sub-sample (host ids); "
-                      "use p2s_knn_patch + p2s_gather_points + p2s_encode_decode");
-        return P2S_EINVAL;
-    }
+    const bool weighted = m->cfg.weighted_subsample != 0;   // p2s_vanilla: choice(p, replace=False) per query
     P2S_HIP_CHECK(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     const int k = m->cfg.points_per_patch, n = m->cfg.sub_sample_size;
@@ -122,7 +117,8 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
         const int cur = (int)std::min<int64_t>(C, q_end - q0);
         if (ci >= nbuf && sa != s) P2S_HIP_CHECK(hipStreamWaitEvent(sa, b.freed[bi], 0));
         const int e0 = p2s_prof_mark(m, sa);
-        const int rc2 = p2s_subsample_uniform(r, c, cur, n, b.sub_ids[bi], nullptr, sa);
+        const int rc2 = weighted ? p2s_subsample_weighted(r, c, b.q + (size_t)q0 * 3, cur, n, b.sub_ids[bi], nullptr, sa)
+                                 : p2s_subsample_uniform(r, c, cur, n, b.sub_ids[bi], nullptr, sa);
         if (rc2) return rc2;
         p2s_prof_span(m, ST_SUB, e0, p2s_prof_mark(m, sa));
         if (sa != s) P2S_HIP_CHECK(hipEventRecord(b.ready[bi], sa));

@@ -127,33 +127,10 @@ def _load_points(indir, shape_name):
     return np.ascontiguousarray(pts)
 
 
-def _weighted_subsample_host(rng_np, pts_np, q_np, n):
-    """p2s_vanilla parity mode: legacy ``choice(N, n, replace=False, p)`` on the host, exactly the
-    reference's call (source/base/utils.py:200-208,218-219)."""
-    out = np.empty((q_np.shape[0], n), dtype=np.int32)
-    for i in range(q_np.shape[0]):
-        dist = np.linalg.norm(np.broadcast_to(q_np[i], pts_np.shape) - pts_np, axis=1)
-        prob = np.clip(1.0 - 1.5 * (dist / np.max(dist)), 0.05, 1.0)
-        prob = prob / np.sum(prob)
-        out[i] = rng_np.choice(pts_np.shape[0], size=n, replace=False, p=prob)
-    return out
-
-
-def _infer_one_shape(model, cloud, pts_np, rng_dev, rng_np, cfg, res, eps, chunk):
-    if cfg['uniform_subsample']:
-        return _engine.infer_shape(model, cloud, rng_dev, res, eps, chunk=chunk)
-    # distance-weighted sub-sample: ids from the host's legacy RNG, everything else on the device
-    q = cloud.query_grid(res, eps)
-    sdf = torch.empty((q.shape[0],), dtype=torch.float32, device=q.device)
-    step = chunk if chunk > 0 else 2048
-    for s in range(0, q.shape[0], step):
-        qc = q[s:s + step]
-        _, patch, rad = cloud.knn_patch(qc, model.points_per_patch, want_ids=False)
-        ids = _weighted_subsample_host(rng_np, pts_np, qc.cpu().numpy(), model.sub_sample_size)
-        sub = cloud.gather(torch.from_numpy(ids).to(q.device))
-        _, sd = model.forward(patch, sub, qc, rad, want_logits=False, want_sdf=True)
-        sdf[s:s + step] = sd
-    return sdf, q
+def _infer_one_shape(model, cloud, rng_dev, res, eps, chunk):
+    """the reference's batch loop for one shape (:358-404).  Both sub-sample modes run on the device:
+    randint (p2s_max) and the distance-weighted choice without replacement (p2s_vanilla)."""
+    return _engine.infer_shape(model, cloud, rng_dev, res, eps, chunk=chunk)
 
 
 def _save_shape(model_out_dir, shape_name, sdf_np, q_np):
@@ -215,7 +192,6 @@ def points_to_surf_eval(eval_opt):
 
         # one RNG stream over all shapes in dataset order (--workers 0 semantics of the reference)
         rng_dev = _engine.Rng(eval_opt.seed, device=device)
-        rng_np = np.random.RandomState(eval_opt.seed)
         mine = set(range(len(shape_names)))
         if world > 1:
             sizes = [os.path.getsize(os.path.join(eval_opt.indir, '04_pts', n + '.xyz.npy'))
@@ -234,17 +210,15 @@ def points_to_surf_eval(eval_opt):
                 if shape_ind not in mine:
                     continue
                 rng_dev = _engine.Rng((eval_opt.seed + shape_ind) & 0xffffffff, device=device)
-                rng_np = np.random.RandomState((eval_opt.seed + shape_ind) & 0xffffffff)
             pts_np = _load_points(eval_opt.indir, shape_name)
             if shape_ind not in mine:
                 # keep the dataset-wide stream exact on every rank: consume this shape's draws without inference
                 cloud = _engine.Cloud(pts_np, device=device)
-                _sharding.skip_shape_stream(cloud, pts_np, rng_dev, rng_np, cfg, eval_opt.query_grid_resolution,
+                _sharding.skip_shape_stream(cloud, rng_dev, cfg, eval_opt.query_grid_resolution,
                                             eval_opt.epsilon, model.sub_sample_size)
                 continue
             cloud = _engine.Cloud(pts_np, device=device)
-            sdf, q = _infer_one_shape(model, cloud, pts_np, rng_dev, rng_np, cfg, eval_opt.query_grid_resolution,
-                                      eval_opt.epsilon, chunk)
+            sdf, q = _infer_one_shape(model, cloud, rng_dev, eval_opt.query_grid_resolution, eval_opt.epsilon, chunk)
             sdf_np = sdf.cpu().numpy()
             q_np = q.cpu().numpy()
             total_q += sdf_np.shape[0]

@@ -244,6 +244,18 @@ class Rng:
                                                       _stream_ptr(self.device)))
         return ids, pts
 
+    def subsample_weighted(self, cloud, query_ms, n, want_pts=True):
+        """a6 (distance-weighted, p2s_vanilla): ids [Q,n] int32 = ``rng.choice(N, n, replace=False, p=dist_prob)``
+        per query, in query order from the same stream (+ gathered points [Q,n,3])"""
+        q = _f32c(query_ms, self.device).reshape(-1, 3)
+        nq = int(q.shape[0])
+        ids = torch.empty((nq, n), dtype=torch.int32, device=self.device)
+        pts = torch.empty((nq, n, 3), dtype=torch.float32, device=self.device) if want_pts else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_subsample_weighted(self.handle, cloud.handle, _ptr(q), nq, int(n), _ptr(ids), _ptr(pts),
+                                                       _stream_ptr(self.device)))
+        return ids, pts
+
 
 def infer_shape(model, cloud, rng, grid_resolution, epsilon, q_begin=0, q_end=-1, chunk=0, want_queries=True):
     """Fused per-shape pipeline (p2s_infer_shape).  Returns (sdf [n] device tensor, q [n,3] or None)."""

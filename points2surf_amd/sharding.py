@@ -81,20 +81,16 @@ def gather_variable(t, dst=0):
     return [b[:s] for b, s in zip(bufs, sizes)]
 
 
-def skip_shape_stream(cloud, pts_np, rng_dev, rng_np, cfg, grid_resolution, epsilon, sub_sample_size, chunk=8192):
-    """Advance the dataset-wide RNG stream(s) past one shape without running inference."""
+def skip_shape_stream(cloud, rng_dev, cfg, grid_resolution, epsilon, sub_sample_size, chunk=4096):
+    """Advance the dataset-wide RNG stream past one shape without running the encoders."""
     import torch
     q = cloud.query_grid(grid_resolution, epsilon)
     Q = int(q.shape[0])
-    if cfg.get('uniform_subsample'):
-        for s in range(0, Q, chunk):
+    for s in range(0, Q, chunk):
+        if cfg.get('uniform_subsample'):
             rng_dev.subsample_uniform(cloud, min(chunk, Q - s), sub_sample_size, want_pts=False)
-        torch.cuda.synchronize()
-    else:
-        qn = q.cpu().numpy()
-        for i in range(Q):
-            dist_ = np.linalg.norm(np.broadcast_to(qn[i], pts_np.shape) - pts_np, axis=1)
-            prob = np.clip(1.0 - 1.5 * (dist_ / np.max(dist_)), 0.05, 1.0)
-            prob = prob / np.sum(prob)
-            rng_np.choice(pts_np.shape[0], size=sub_sample_size, replace=False, p=prob)
+        else:
+            rng_dev.subsample_weighted(cloud, q[s:s + chunk], sub_sample_size, want_pts=False)
+    torch.cuda.synchronize()
+    rng_dev.check()
     return Q

