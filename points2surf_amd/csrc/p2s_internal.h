@@ -81,9 +81,9 @@ struct p2s_rng_s {
     int *blk_cum = nullptr;        // [S][B] cumulative accepted count per block
     long long *meta = nullptr;     // [S] offsets + locate record + sticky error flag + raw-request record
     // weighted sub-sample workspace (p2s_wchoice.hip), grown on demand
-    float *wc_dist = nullptr;      // [C][n]   distances to the query
+    float *wc_dist = nullptr;      // [C][n]   distances to the query, then the float32 probabilities
     double *wc_S = nullptr;        // [C][n]   exact prefix sums of the probabilities
-    int *wc_T = nullptr;           // [C][K]   guide table of the cdf
+    void *wc_T = nullptr;          // [C][K]   guide records of the cdf (32 B each)
     double *wc_stot = nullptr;     // [C]
     size_t wc_cap_q = 0, wc_cap_n = 0, wc_cap_k = 0;
 };

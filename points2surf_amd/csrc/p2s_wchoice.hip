@@ -13,11 +13,12 @@
 //    of 2^-52 below 2, i.e. EXACT.  np.cumsum (sequential) therefore equals a parallel scan in any order, and
 //    "zero the found entries and cumsum again" (iterations >= 2) equals S_i minus the found mass below i.
 //  * cdf_i = fl(S_i / S_N) and searchsorted(cdf, x, 'right') are evaluated with the same IEEE operations; a guide
-//    table T[b] = #{cdf_i <= b/K} makes the search O(1).
+//    table over K ~ N buckets, R[b] = (i = #{cdf_i <= b/K}, S_{i-1}, S_i, S_{i+1}), answers most look-ups with one
+//    32-byte load.
 //
 // Two kernels per chunk of queries:
 //   wc_tables_kernel  one workgroup per query, fully parallel: distances, max, plan-ordered sum, exact prefix sums
-//                     S[q][N] (float64), guide table T[q][K].  HBM-resident (288 GB: ~0.7 MB per query).
+//                     S[q][N] (float64), guide records R[q][K].  HBM-resident (288 GB: ~2.7 MB per query).
 //   wc_choice_kernel  ONE workgroup walks the queries in order -- the number of random words a query consumes
 //                     depends on its collisions, so the stream position is a true serial dependence -- but per
 //                     query it only does ~1000 table look-ups, an LDS bitmap for duplicates and a rank sort.
@@ -39,6 +40,11 @@ constexpr int WC_MAX_NODES = 8192;   // plan nodes held in LDS -> clouds up to ~
 constexpr int PW_BLOCK = 128;        // numpy PW_BLOCKSIZE
 constexpr int NP_BUFSIZE = 8192;     // numpy ufunc buffer size (np.getbufsize())
 
+struct __attribute__((aligned(32))) WcRec {
+    int i, pad;
+    double sm1, s0, sp1;     // S_{i-1} (0 for i = 0), S_i, S_{i+1} (S_{n-1} for i = n-1)
+};
+
 struct WcPlanDev {
     const int *leaf;       // [L][3] start, len, node
     const int *ops;        // [O][3] dst, a, b   (sorted by level)
@@ -57,7 +63,7 @@ __device__ __forceinline__ float wc_clip_prob(float d, float dmax) {
 
 __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict__ pts, int n, const float *__restrict__ q,
                                                         WcPlanDev plan, int K, float *__restrict__ dist_all,
-                                                        double *__restrict__ S_all, int *__restrict__ T_all,
+                                                        double *__restrict__ S_all, WcRec *__restrict__ R_all,
                                                         double *__restrict__ stot_all, long long *__restrict__ err) {
     __shared__ float nodes[WC_MAX_NODES];
     __shared__ float red_f[4];
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
     const int qi = blockIdx.x;
     float *dist = dist_all + (size_t)qi * n;
     double *S = S_all + (size_t)qi * n;
-    int *T = T_all + (size_t)qi * K;
+    WcRec *R = R_all + (size_t)qi * K;
     const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
 
     // pass 1: d_i = ||q - p_i|| (np.linalg.norm(axis=1): ((dx^2 + dy^2) + dz^2), sqrt), max
@@ -118,9 +124,13 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
     }
     const float sum = nodes[plan.root];
 
-    // pass 3: total mass S_N (float64, exact in any order)
+    // pass 3: p_i = pc_i / sum (float32, kept in place of the distance) and the total mass S_N (exact in any order)
     double acc = 0.0;
-    for (int i = tid; i < n; i += 256) acc += (double)(wc_clip_prob(dist[i], dmax) / sum);
+    for (int i = tid; i < n; i += 256) {
+        const float pi = wc_clip_prob(dist[i], dmax) / sum;
+        dist[i] = pi;
+        acc += (double)pi;
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
     if (lane == 0) red_d[wave] = acc;
@@ -128,14 +138,14 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
     const double Stot = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
     __syncthreads();                                  // red_d is reused by the scan below
 
-    // pass 4: prefix sums + guide table, tiles of 1024 elements (4 consecutive per lane)
+    // pass 4: prefix sums + guide records, tiles of 1024 elements (4 consecutive per lane)
     const double dK = (double)K;
     double carry = 0.0;
     for (int t0 = 0; t0 < n; t0 += 1024) {
         const int i0 = t0 + 4 * tid;
-        double p[4];
+        double p[5];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p[j] = (i0 + j < n) ? (double)(wc_clip_prob(dist[i0 + j], dmax) / sum) : 0.0;
+        for (int j = 0; j < 5; ++j) p[j] = (i0 + j < n) ? (double)dist[i0 + j] : 0.0;
         const double l1 = p[0], l2 = l1 + p[1], l3 = l2 + p[2], l4 = l3 + p[3];
         double v = l4;
 #pragma unroll
@@ -152,15 +162,21 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
             total += red_d[w];
         }
         const double excl = base + (v - l4);          // S_{i0-1}
-        const double s[4] = {excl + l1, excl + l2, excl + l3, excl + l4};
+        const double s[6] = {excl, excl + l1, excl + l2, excl + l3, excl + l4, (excl + l4) + p[4]};
         int cprev = (int)ceil((excl / Stot) * dK);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (i0 + j < n) {
-                S[i0 + j] = s[j];
-                const int c = (int)ceil((s[j] / Stot) * dK);
+                S[i0 + j] = s[j + 1];
+                const int c = (int)ceil((s[j + 1] / Stot) * dK);
                 const int ce = c < K ? c : K;
-                for (int b = cprev; b < ce; ++b) T[b] = i0 + j;
+                WcRec rec;
+                rec.i = i0 + j;
+                rec.pad = 0;
+                rec.sm1 = s[j];
+                rec.s0 = s[j + 1];
+                rec.sp1 = s[j + 2];                   // past the end: p = 0 -> S_{n-1}
+                for (int b = cprev; b < ce; ++b) R[b] = rec;
                 cprev = c;
             }
         }
@@ -175,13 +191,14 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------------------------------------------
 struct WcArgs {
     const double *S;          // [nq][n]
-    const int *T;             // [nq][K]
+    const WcRec *R;           // [nq][K]
     const double *stot;       // [nq]
     const uint32_t *words;    // raw tempered words from the generator's position
     long long cap_words;
     int n, K, nq, nsel;
     int32_t *ids_out;         // [nq][nsel]
     long long *meta;          // [0] words consumed (out), [1] sticky error
+    long long *prof;          // development: per-phase cycle counters (null = off)
 };
 
 struct WcLoc {
@@ -189,13 +206,19 @@ struct WcLoc {
     double s, sprev;          // S_bin, S_{bin-1}
 };
 
-// smallest i with fl((S_i - C(i)) / Stot_cur) > x, where the m_found ids sid[] (ascending) carry no mass any more:
-// V[k] = S' at sid[k], C[k] = found mass up to and including sid[k]
-__device__ __forceinline__ WcLoc wc_locate(const double *__restrict__ Sq, const int *__restrict__ Tq, int n, int K,
-                                           double Stot, double Stot_cur, double x, int m_found, const int *sid,
-                                           const double *sV, const double *sC) {
-    int lo = 0, hi = n;
-    double Ck = 0.0;
+// searchsorted(cdf', x, 'right') = smallest i with fl((S_i - C(i)) / Stot_cur) > x, where the m_found ids sid[]
+// (ascending) carry no mass any more: V[k] = S' at sid[k], C[k] = found mass up to and including sid[k].
+// Step 1 (LDS only): the gap between two found ids that holds the answer, and the guide bucket to fetch.
+struct WcGap {
+    int lo, hi, bucket;
+    double Ck;
+};
+__device__ __forceinline__ WcGap wc_gap(int n, int K, double Stot, double Stot_cur, double x, int m_found, const int *sid,
+                                        const double *sV, const double *sC) {
+    WcGap g;
+    g.lo = 0;
+    g.hi = n;
+    g.Ck = 0.0;
     if (m_found) {
         int a = 0, b = m_found;                       // largest k in [0, m] with k == 0 or V[k-1]/Stot_cur <= x
         while (a < b) {
@@ -204,24 +227,28 @@ __device__ __forceinline__ WcLoc wc_locate(const double *__restrict__ Sq, const 
             else b = mid - 1;
         }
         if (a) {
-            lo = sid[a - 1] + 1;
-            Ck = sC[a - 1];
+            g.lo = sid[a - 1] + 1;
+            g.Ck = sC[a - 1];
         }
-        if (a < m_found) hi = sid[a];
+        if (a < m_found) g.hi = sid[a];
     }
-    const double t = x * Stot_cur + Ck;
+    const double t = x * Stot_cur + g.Ck;
     int b = (int)((t / Stot) * (double)K);
-    b = b < 0 ? 0 : (b > K - 1 ? K - 1 : b);
-    int i = Tq[b];
-    i = i < lo ? lo : (i > hi - 1 ? hi - 1 : i);
-    // one round of loads covers the common cases
-    double s_m1 = (i > 0) ? Sq[i - 1] : 0.0;
-    double s_0 = Sq[i];
-    const double s_p1 = Sq[i + 1 < n ? i + 1 : n - 1];
-    const double s_p2 = Sq[i + 2 < n ? i + 2 : n - 1];
+    g.bucket = b < 0 ? 0 : (b > K - 1 ? K - 1 : b);
+    return g;
+}
+// Step 2: finish from the guide record (one 32-byte load already done by the caller)
+__device__ __forceinline__ WcLoc wc_finish(const double *__restrict__ Sq, int n, int i, double s_m1, double s_0,
+                                           double s_p1, int g_lo, int g_hi, double Ck, double Stot_cur, double x) {
+    if (i < g_lo || i > g_hi - 1) {                   // guide points outside the gap (iterations >= 2 only)
+        i = i < g_lo ? g_lo : g_hi - 1;
+        s_m1 = (i > 0) ? Sq[i - 1] : 0.0;
+        s_0 = Sq[i];
+        s_p1 = Sq[i + 1 < n ? i + 1 : n - 1];
+    }
 #define WC_PRED(sv) ((((sv)-Ck) / Stot_cur) > x)
     if (WC_PRED(s_0)) {
-        while (i > lo && WC_PRED(s_m1)) {
+        while (i > g_lo && WC_PRED(s_m1)) {
             --i;
             s_0 = s_m1;
             s_m1 = (i > 0) ? Sq[i - 1] : 0.0;
@@ -229,9 +256,8 @@ __device__ __forceinline__ WcLoc wc_locate(const double *__restrict__ Sq, const 
         return {i, s_0, s_m1};
     }
     if (WC_PRED(s_p1)) return {i + 1, s_p1, s_0};
-    if (WC_PRED(s_p2)) return {i + 2, s_p2, s_p1};
-    i += 2;
-    double prev = s_p2;
+    i += 1;
+    double prev = s_p1;
     for (;;) {
         ++i;
         if (i >= n) return {n - 1, prev, prev};       // unreachable for valid tables; keeps the loop finite
@@ -241,6 +267,15 @@ __device__ __forceinline__ WcLoc wc_locate(const double *__restrict__ Sq, const 
     }
 #undef WC_PRED
 }
+
+#define WC_T(k)                                                     \
+    do {                                                            \
+        if (a.prof && tid == 0) {                                   \
+            const long long t_ = wall_clock64();                    \
+            a.prof[k] += t_ - t_last;                               \
+            t_last = t_;                                            \
+        }                                                           \
+    } while (0)
 
 __global__ __launch_bounds__(256) void wc_choice_kernel(WcArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
@@ -267,9 +302,10 @@ __global__ __launch_bounds__(256) void wc_choice_kernel(WcArgs a) {
     __syncthreads();
 
     long long o = 0;                                  // words consumed so far (uniform)
+    long long t_last = a.prof ? wall_clock64() : 0;
     for (int q = 0; q < a.nq; ++q) {
         const double *Sq = a.S + (size_t)q * a.n;
-        const int *Tq = a.T + (size_t)q * a.K;
+        const WcRec *Rq = a.R + (size_t)q * a.K;
         const double Stot = a.stot[q];
         double Stot_cur = Stot;
         int n_uniq = 0, m_found = 0, rounds = 0;
@@ -283,32 +319,84 @@ __global__ __launch_bounds__(256) void wc_choice_kernel(WcArgs a) {
                 }
                 return;
             }
+            // locate the bins of rand(m): A the doubles (two words each), B gap + guide record, C finish.
             int bins[4];
             double sb[4], sp[4];
             unsigned valid = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int d = tid * per + j;
                 bins[j] = 0;
                 sb[j] = sp[j] = 0.0;
-                if (j < per && d < m) {
-                    const uint32_t w0 = a.words[o + 2LL * d] >> 5, w1 = a.words[o + 2LL * d + 1] >> 6;
-                    const double x = ((double)w0 * 67108864.0 + (double)w1) / 9007199254740992.0;
-                    const WcLoc L = wc_locate(Sq, Tq, a.n, a.K, Stot, Stot_cur, x, m_found, sid, sV, sC);
-                    bins[j] = L.bin;
-                    sb[j] = L.s;
-                    sp[j] = L.sprev;
-                    valid |= 1u << j;
-                    const uint32_t bit = 1u << (L.bin & 31);
-                    const uint32_t old = atomicOr(&bitmap[L.bin >> 5], bit);
+            }
+            if (m_found == 0) {
+                // first round (nothing found yet, every lane has up to 4 draws): straight-line code, lanes past the
+                // last draw repeat it, so that all loads of a phase are in flight together
+                uint2 wpair[4];
+                int dcl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = tid * per + j;
+                    const bool ok = (j < per) & (d < m);
+                    valid |= (unsigned)ok << j;
+                    dcl[j] = ok ? d : m - 1;
+                    wpair[j] = *(const uint2 *)(a.words + o + 2LL * dcl[j]);      // o is even: 8-byte aligned
+                }
+                double xs[4];
+                int r_i[4];
+                double r_sm1[4], r_s0[4], r_sp1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xs[j] = ((double)(wpair[j].x >> 5) * 67108864.0 + (double)(wpair[j].y >> 6)) / 9007199254740992.0;
+                    int bk = (int)(xs[j] * (double)a.K);              // x * Stot / Stot: the bucket of x itself
+                    bk = bk > a.K - 1 ? a.K - 1 : bk;
+                    const double *rp = (const double *)(Rq + bk);
+                    r_i[j] = *(const int *)rp;
+                    r_sm1[j] = rp[1];
+                    r_s0[j] = rp[2];
+                    r_sp1[j] = rp[3];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if ((valid >> j) & 1u) {
+                        const WcLoc L = wc_finish(Sq, a.n, r_i[j], r_sm1[j], r_s0[j], r_sp1[j], 0, a.n, 0.0, Stot, xs[j]);
+                        bins[j] = L.bin;
+                        sb[j] = L.s;
+                        sp[j] = L.sprev;
+                    }
+                }
+            } else {
+                // redraw rounds: few draws (usually one per lane, < 64 lanes)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = tid * per + j;
+                    if (j < per && d < m) {
+                        valid |= 1u << j;
+                        const uint2 wp = *(const uint2 *)(a.words + o + 2LL * d);
+                        const double x = ((double)(wp.x >> 5) * 67108864.0 + (double)(wp.y >> 6)) / 9007199254740992.0;
+                        const WcGap g = wc_gap(a.n, a.K, Stot, Stot_cur, x, m_found, sid, sV, sC);
+                        const double *rp = (const double *)(Rq + g.bucket);
+                        const WcLoc L = wc_finish(Sq, a.n, *(const int *)rp, rp[1], rp[2], rp[3], g.lo, g.hi, g.Ck, Stot_cur, x);
+                        bins[j] = L.bin;
+                        sb[j] = L.s;
+                        sp[j] = L.sprev;
+                    }
+                }
+            }
+            WC_T(m_found ? 1 : 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if ((valid >> j) & 1u) {
+                    const uint32_t bit = 1u << (bins[j] & 31);
+                    const uint32_t old = atomicOr(&bitmap[bins[j] >> 5], bit);
                     if (old & bit) {
                         const int c = atomicAdd(&s_ncoll, 1);
-                        coll_bin[c] = L.bin;
+                        coll_bin[c] = bins[j];
                         coll_min[c] = 0x7fffffff;
                     }
                 }
             }
             __syncthreads();
+            WC_T(2);
             const int nc = s_ncoll;
             unsigned keep = valid;
             if (nc) {
@@ -331,6 +419,7 @@ __global__ __launch_bounds__(256) void wc_choice_kernel(WcArgs a) {
                 for (int j = 0; j < 4; ++j)
                     if (slot[j] >= 0 && coll_min[slot[j]] != tid * per + j) keep &= ~(1u << j);
             }
+            WC_T(3);
             // ordered compaction of the kept draws behind the ones found so far
             const int cnt = __popc(keep);
             int excl = 0, wtot = 0;
@@ -362,6 +451,7 @@ __global__ __launch_bounds__(256) void wc_choice_kernel(WcArgs a) {
             o += 2LL * m;
             if (tid == 0) s_ncoll = 0;
             __syncthreads();
+            WC_T(4);
             if (n_uniq < a.nsel) {
                 // found ids in ascending order through the bitmap: rank = set bits below
                 const int wper = (BW + 255) >> 8, w0 = tid * wper;
@@ -424,6 +514,7 @@ __global__ __launch_bounds__(256) void wc_choice_kernel(WcArgs a) {
                 __syncthreads();
                 Stot_cur = Stot - sC[n_uniq - 1];
                 m_found = n_uniq;
+                WC_T(5);
             }
         }
         for (int e = tid; e < a.nsel; e += 256) {
@@ -432,6 +523,7 @@ __global__ __launch_bounds__(256) void wc_choice_kernel(WcArgs a) {
             bitmap[f >> 5] = 0;
         }
         __syncthreads();
+        WC_T(6);
     }
     if (tid == 0) a.meta[0] = o;
 }
@@ -538,7 +630,7 @@ int wc_reserve(p2s_rng_s *r, size_t nq, size_t n, size_t K) {
     r->wc_cap_q = r->wc_cap_n = r->wc_cap_k = 0;
     nq = std::max(nq, r->wc_cap_q);
     if (hipMalloc(&r->wc_dist, nq * n * 4) != hipSuccess || hipMalloc(&r->wc_S, nq * n * 8) != hipSuccess ||
-        hipMalloc(&r->wc_T, nq * K * 4) != hipSuccess || hipMalloc(&r->wc_stot, nq * 8) != hipSuccess) {
+        hipMalloc(&r->wc_T, nq * K * sizeof(WcRec)) != hipSuccess || hipMalloc(&r->wc_stot, nq * 8) != hipSuccess) {
         (void)hipGetLastError();
         p2s_set_error("weighted sub-sample: hipMalloc of the per-query tables failed (%zu queries x %zu points)", nq, n);
         return P2S_ENOMEM;
@@ -625,10 +717,10 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
         rc = p2s_rng_raw_begin(r, s);
         if (rc) return rc;
         hipLaunchKernelGGL(wc_tables_kernel, dim3(cur), dim3(256), 0, s, c->d.pts, n, q_dev + (size_t)done * 3, plan, K,
-                           r->wc_dist, r->wc_S, r->wc_T, r->wc_stot, meta);
+                           r->wc_dist, r->wc_S, (WcRec *)r->wc_T, r->wc_stot, meta);
         WcArgs a;
         a.S = r->wc_S;
-        a.T = r->wc_T;
+        a.R = (const WcRec *)r->wc_T;
         a.stot = r->wc_stot;
         a.words = r->tmp;
         a.cap_words = cap;
@@ -638,7 +730,21 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
         a.nsel = n_sel;
         a.ids_out = ids_out_dev + (size_t)done * n_sel;
         a.meta = meta;
+        a.prof = nullptr;
+        static long long *prof_dev = nullptr;
+        if (getenv("P2S_WC_PROF")) {
+            if (!prof_dev) (void)hipMalloc(&prof_dev, 16 * 8);
+            (void)hipMemsetAsync(prof_dev, 0, 16 * 8, s);
+            a.prof = prof_dev;
+        }
         hipLaunchKernelGGL(wc_choice_kernel, dim3(1), dim3(256), lds, s, a);
+        if (a.prof) {
+            long long h[16];
+            (void)hipMemcpyAsync(h, prof_dev, sizeof(h), hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            fprintf(stderr, "[wc prof] %d queries, 100 MHz ticks: locate1 %lld locate2+ %lld mark %lld resolve %lld compact %lld "
+                            "sortprep %lld output %lld\n", cur, h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+        }
         P2S_LAUNCH_CHECK("weighted sub-sample kernels");
         rc = p2s_rng_raw_commit(r, s);
         if (rc) return rc;
