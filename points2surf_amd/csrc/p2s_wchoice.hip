@@ -40,9 +40,11 @@ constexpr int WC_MAX_NODES = 8192;   // plan nodes held in LDS -> clouds up to ~
 constexpr int PW_BLOCK = 128;        // numpy PW_BLOCKSIZE
 constexpr int NP_BUFSIZE = 8192;     // numpy ufunc buffer size (np.getbufsize())
 
-struct __attribute__((aligned(32))) WcRec {
-    int i, pad;
-    double sm1, s0, sp1;     // S_{i-1} (0 for i = 0), S_i, S_{i+1} (S_{n-1} for i = n-1)
+// guide record of bucket b of the cdf (x in [b/K, (b+1)/K)):  i = #{cdf_j <= b/K} is the first candidate,
+// c0 = cdf_i.  x < c0 -> bin i; otherwise bin i+1 unless `more` (a second boundary may lie inside the bucket).
+struct __attribute__((aligned(16))) WcRec {
+    double c0;
+    int i, more;
 };
 
 struct WcPlanDev {
@@ -64,7 +66,8 @@ __device__ __forceinline__ float wc_clip_prob(float d, float dmax) {
 __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict__ pts, int n, const float *__restrict__ q,
                                                         WcPlanDev plan, int K, float *__restrict__ dist_all,
                                                         double *__restrict__ S_all, WcRec *__restrict__ R_all,
-                                                        double *__restrict__ stot_all, long long *__restrict__ err) {
+                                                        double *__restrict__ stot_all, float *__restrict__ pmax_all,
+                                                        long long *__restrict__ err) {
     __shared__ float nodes[WC_MAX_NODES];
     __shared__ float red_f[4];
     __shared__ double red_d[4];
@@ -126,16 +129,25 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
 
     // pass 3: p_i = pc_i / sum (float32, kept in place of the distance) and the total mass S_N (exact in any order)
     double acc = 0.0;
+    float pm = 0.0f;
     for (int i = tid; i < n; i += 256) {
         const float pi = wc_clip_prob(dist[i], dmax) / sum;
         dist[i] = pi;
         acc += (double)pi;
+        pm = fmaxf(pm, pi);
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) red_d[wave] = acc;
+    for (int off = 32; off >= 1; off >>= 1) {
+        acc += __shfl_xor(acc, off);
+        pm = fmaxf(pm, __shfl_xor(pm, off));
+    }
+    if (lane == 0) {
+        red_d[wave] = acc;
+        red_f[wave] = pm;
+    }
     __syncthreads();
     const double Stot = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
+    if (tid == 0) pmax_all[qi] = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
     __syncthreads();                                  // red_d is reused by the scan below
 
     // pass 4: prefix sums + guide records, tiles of 1024 elements (4 consecutive per lane)
@@ -162,22 +174,30 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
             total += red_d[w];
         }
         const double excl = base + (v - l4);          // S_{i0-1}
-        const double s[6] = {excl, excl + l1, excl + l2, excl + l3, excl + l4, (excl + l4) + p[4]};
-        int cprev = (int)ceil((excl / Stot) * dK);
+        const double sv[6] = {excl, excl + l1, excl + l2, excl + l3, excl + l4, (excl + l4) + p[4]};
+        double cd[6];
+        int cc[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            cd[k] = sv[k] / Stot;                     // cdf value exactly as numpy computes it
+            cc[k] = (int)ceil(cd[k] * dK);            // first bucket whose lower edge is >= cdf
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (i0 + j < n) {
-                S[i0 + j] = s[j + 1];
-                const int c = (int)ceil((s[j + 1] / Stot) * dK);
+            const int idx = i0 + j;
+            if (idx < n) {
+                S[idx] = sv[j + 1];
+                const int c = cc[j + 1];
                 const int ce = c < K ? c : K;
                 WcRec rec;
-                rec.i = i0 + j;
-                rec.pad = 0;
-                rec.sm1 = s[j];
-                rec.s0 = s[j + 1];
-                rec.sp1 = s[j + 2];                   // past the end: p = 0 -> S_{n-1}
-                for (int b = cprev; b < ce; ++b) R[b] = rec;
-                cprev = c;
+                rec.c0 = cd[j + 1];
+                rec.i = idx;
+                rec.more = 0;
+                for (int b = cc[j]; b < ce; ++b) {
+                    // only the bucket that contains cdf_idx can hold further boundaries
+                    rec.more = (b == c - 1 && idx + 1 < n && cc[j + 2] == c) ? 1 : 0;
+                    R[b] = rec;
+                }
             }
         }
         carry += total;
@@ -189,18 +209,6 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------------------------------------------
 // choice: one workgroup, queries in order
 // ---------------------------------------------------------------------------------------------------------------
-struct WcArgs {
-    const double *S;          // [nq][n]
-    const WcRec *R;           // [nq][K]
-    const double *stot;       // [nq]
-    const uint32_t *words;    // raw tempered words from the generator's position
-    long long cap_words;
-    int n, K, nq, nsel;
-    int32_t *ids_out;         // [nq][nsel]
-    long long *meta;          // [0] words consumed (out), [1] sticky error
-    long long *prof;          // development: per-phase cycle counters (null = off)
-};
-
 struct WcLoc {
     int bin;
     double s, sprev;          // S_bin, S_{bin-1}
@@ -237,15 +245,13 @@ __device__ __forceinline__ WcGap wc_gap(int n, int K, double Stot, double Stot_c
     g.bucket = b < 0 ? 0 : (b > K - 1 ? K - 1 : b);
     return g;
 }
-// Step 2: finish from the guide record (one 32-byte load already done by the caller)
-__device__ __forceinline__ WcLoc wc_finish(const double *__restrict__ Sq, int n, int i, double s_m1, double s_0,
-                                           double s_p1, int g_lo, int g_hi, double Ck, double Stot_cur, double x) {
-    if (i < g_lo || i > g_hi - 1) {                   // guide points outside the gap (iterations >= 2 only)
-        i = i < g_lo ? g_lo : g_hi - 1;
-        s_m1 = (i > 0) ? Sq[i - 1] : 0.0;
-        s_0 = Sq[i];
-        s_p1 = Sq[i + 1 < n ? i + 1 : n - 1];
-    }
+// Step 2: exact answer from a starting index near it (S values fetched here; walks are short and rare)
+__device__ __forceinline__ WcLoc wc_finish(const double *__restrict__ Sq, int n, int i, int g_lo, int g_hi, double Ck,
+                                           double Stot_cur, double x) {
+    i = i < g_lo ? g_lo : (i > g_hi - 1 ? g_hi - 1 : i);
+    double s_m1 = (i > 0) ? Sq[i - 1] : 0.0;
+    double s_0 = Sq[i];
+    const double s_p1 = Sq[i + 1 < n ? i + 1 : n - 1];
 #define WC_PRED(sv) ((((sv)-Ck) / Stot_cur) > x)
     if (WC_PRED(s_0)) {
         while (i > g_lo && WC_PRED(s_m1)) {
@@ -267,265 +273,632 @@ __device__ __forceinline__ WcLoc wc_finish(const double *__restrict__ Sq, int n,
     }
 #undef WC_PRED
 }
+// first-round shortcut: bin from the guide record alone (unmodified cdf), -1 if a second boundary must be checked
+__device__ __forceinline__ int wc_quick_bin(double c0, int i, int more, double x) {
+    return x < c0 ? i : (more ? -1 : i + 1);
+}
 
-#define WC_T(k)                                                     \
-    do {                                                            \
-        if (a.prof && tid == 0) {                                   \
-            const long long t_ = wall_clock64();                    \
-            a.prof[k] += t_ - t_last;                               \
-            t_last = t_;                                            \
-        }                                                           \
-    } while (0)
+// ---------------------------------------------------------------------------------------------------------------
+// LDS layout shared by the kernels below
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WC_HASH = 2048;        // open-addressing table: bin -> first draw index of the round
+struct WcLds {
+    double *fS, *sV, *sC;            // S at the found ids (numpy order) / V, C of the found ids sorted by id
+    float *fP;                       // probability of the found ids (float32 values, exact)
+    int *fid, *sid;                  // found ids in numpy's order / ascending
+    uint32_t *hash;                  // (bin << 10 | draw) packed, 0xffffffff = empty
+    uint32_t *bitmap;                // one bit per cloud point: found so far
+    uint16_t *wpre;                  // set bits before each bitmap word
+};
+__host__ __device__ inline size_t wc_lds_bytes(int n) {
+    const size_t BW = (size_t)((n + 31) >> 5);
+    return (size_t)WC_MAX_SEL * (3 * 8 + 4 + 2 * 4) + WC_HASH * 4 + BW * 4 + ((BW * 2 + 15) & ~(size_t)15);
+}
+__device__ __forceinline__ WcLds wc_carve(unsigned char *base, int n) {
+    const int BW = (n + 31) >> 5;
+    WcLds l;
+    l.fS = (double *)base;
+    l.sV = l.fS + WC_MAX_SEL;
+    l.sC = l.sV + WC_MAX_SEL;
+    l.fP = (float *)(l.sC + WC_MAX_SEL);
+    l.fid = (int *)(l.fP + WC_MAX_SEL);
+    l.sid = l.fid + WC_MAX_SEL;
+    l.hash = (uint32_t *)(l.sid + WC_MAX_SEL);
+    l.bitmap = l.hash + WC_HASH;
+    l.wpre = (uint16_t *)(l.bitmap + BW);
+    return l;
+}
 
-__global__ __launch_bounds__(256) void wc_choice_kernel(WcArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
-    __shared__ int wsum[4];
-    __shared__ double wsumd[4];
-    __shared__ int s_ncoll;
-    __builtin_amdgcn_s_setprio(3);
-    const int BW = (a.n + 31) >> 5;
-    double *fS = (double *)wc_lds;                    // found, in numpy's order
-    double *fP = fS + WC_MAX_SEL;
-    double *sV = fP + WC_MAX_SEL;                     // found, sorted by id
-    double *sC = sV + WC_MAX_SEL;
-    int *fid = (int *)(sC + WC_MAX_SEL);
-    int *sid = fid + WC_MAX_SEL;
-    int *coll_bin = sid + WC_MAX_SEL;
-    int *coll_min = coll_bin + WC_MAX_SEL;
-    uint32_t *bitmap = (uint32_t *)(coll_min + WC_MAX_SEL);
-    int *wpre = (int *)(bitmap + BW);
+__device__ __forceinline__ double wc_double(uint32_t w0, uint32_t w1) {      // numpy legacy random_sample
+    return ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) / 9007199254740992.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One query, start to end, by one workgroup: the reference algorithm (all rounds).  The bitmap must be all zero on
+// entry and is all zero again on return.  Returns the number of random words consumed (uniform), or -1 if the words
+// ran out / no progress (error code stored by the caller).  With WRITE the ids go to ids_out[0..nsel).
+// ---------------------------------------------------------------------------------------------------------------
+struct WcQuery {
+    const double *Sq;
+    const WcRec *Rq;
+    double Stot;
+    const uint32_t *words;       // word o of this query's first draw at words[0]
+    long long words_left;        // words available from there
+    int n, K, nsel;
+};
+
+template <bool WRITE>
+__device__ long long wc_full_query(const WcQuery &qa, const WcLds &l, int *wsum, double *wsumd, int32_t *ids_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    if (a.meta[1] != 0) return;                       // tables invalid (degenerate input) or an earlier failure
-    for (int i = tid; i < BW; i += 256) bitmap[i] = 0;
-    if (tid == 0) s_ncoll = 0;
-    __syncthreads();
-
-    long long o = 0;                                  // words consumed so far (uniform)
-    long long t_last = a.prof ? wall_clock64() : 0;
-    for (int q = 0; q < a.nq; ++q) {
-        const double *Sq = a.S + (size_t)q * a.n;
-        const WcRec *Rq = a.R + (size_t)q * a.K;
-        const double Stot = a.stot[q];
-        double Stot_cur = Stot;
-        int n_uniq = 0, m_found = 0, rounds = 0;
-        while (n_uniq < a.nsel) {
-            const int m = a.nsel - n_uniq;
-            const int per = (m + 255) >> 8;
-            if (o + 2LL * m > a.cap_words || ++rounds > 64) {
-                if (tid == 0) {
-                    a.meta[1] = (rounds > 64) ? 3 : 2;
-                    a.meta[0] = o;
-                }
-                return;
-            }
-            // locate the bins of rand(m): A the doubles (two words each), B gap + guide record, C finish.
-            int bins[4];
-            double sb[4], sp[4];
-            unsigned valid = 0;
+    const int BW = (qa.n + 31) >> 5;
+    const double Stot = qa.Stot;
+    double Stot_cur = Stot;
+    int n_uniq = 0, m_found = 0, rounds = 0;
+    long long o = 0;
+    while (n_uniq < qa.nsel) {
+        const int m = qa.nsel - n_uniq;
+        const int per = (m + 255) >> 8;
+        if (o + 2LL * m > qa.words_left || ++rounds > 64) return -1;     // uniform
+        for (int i = tid; i < WC_HASH; i += 256) l.hash[i] = 0xffffffffu;
+        // locate the bins of rand(m): A the doubles (two words each), B gap + guide record, C finish
+        int bins[4];
+        double sb[4], sp[4];
+        unsigned valid = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bins[j] = 0;
+            sb[j] = sp[j] = 0.0;
+        }
+        if (m_found == 0) {
+            // first round (nothing found yet, every lane has up to 4 draws): straight-line code, lanes past the last
+            // draw repeat it, so that all loads of a phase are in flight together
+            uint2 wpair[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                bins[j] = 0;
-                sb[j] = sp[j] = 0.0;
+                const int d = tid * per + j;
+                const bool ok = (j < per) & (d < m);
+                valid |= (unsigned)ok << j;
+                wpair[j] = *(const uint2 *)(qa.words + o + 2LL * (ok ? d : m - 1));      // o is even: 8-byte aligned
             }
-            if (m_found == 0) {
-                // first round (nothing found yet, every lane has up to 4 draws): straight-line code, lanes past the
-                // last draw repeat it, so that all loads of a phase are in flight together
-                uint2 wpair[4];
-                int dcl[4];
+            double xs[4];
+            int st[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int d = tid * per + j;
-                    const bool ok = (j < per) & (d < m);
-                    valid |= (unsigned)ok << j;
-                    dcl[j] = ok ? d : m - 1;
-                    wpair[j] = *(const uint2 *)(a.words + o + 2LL * dcl[j]);      // o is even: 8-byte aligned
-                }
-                double xs[4];
-                int r_i[4];
-                double r_sm1[4], r_s0[4], r_sp1[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    xs[j] = ((double)(wpair[j].x >> 5) * 67108864.0 + (double)(wpair[j].y >> 6)) / 9007199254740992.0;
-                    int bk = (int)(xs[j] * (double)a.K);              // x * Stot / Stot: the bucket of x itself
-                    bk = bk > a.K - 1 ? a.K - 1 : bk;
-                    const double *rp = (const double *)(Rq + bk);
-                    r_i[j] = *(const int *)rp;
-                    r_sm1[j] = rp[1];
-                    r_s0[j] = rp[2];
-                    r_sp1[j] = rp[3];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if ((valid >> j) & 1u) {
-                        const WcLoc L = wc_finish(Sq, a.n, r_i[j], r_sm1[j], r_s0[j], r_sp1[j], 0, a.n, 0.0, Stot, xs[j]);
-                        bins[j] = L.bin;
-                        sb[j] = L.s;
-                        sp[j] = L.sprev;
-                    }
-                }
-            } else {
-                // redraw rounds: few draws (usually one per lane, < 64 lanes)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int d = tid * per + j;
-                    if (j < per && d < m) {
-                        valid |= 1u << j;
-                        const uint2 wp = *(const uint2 *)(a.words + o + 2LL * d);
-                        const double x = ((double)(wp.x >> 5) * 67108864.0 + (double)(wp.y >> 6)) / 9007199254740992.0;
-                        const WcGap g = wc_gap(a.n, a.K, Stot, Stot_cur, x, m_found, sid, sV, sC);
-                        const double *rp = (const double *)(Rq + g.bucket);
-                        const WcLoc L = wc_finish(Sq, a.n, *(const int *)rp, rp[1], rp[2], rp[3], g.lo, g.hi, g.Ck, Stot_cur, x);
-                        bins[j] = L.bin;
-                        sb[j] = L.s;
-                        sp[j] = L.sprev;
-                    }
-                }
+            for (int j = 0; j < 4; ++j) {
+                xs[j] = wc_double(wpair[j].x, wpair[j].y);
+                int bk = (int)(xs[j] * (double)qa.K);                 // the bucket of x itself
+                bk = bk > qa.K - 1 ? qa.K - 1 : bk;
+                const WcRec rec = qa.Rq[bk];
+                const int qb = wc_quick_bin(rec.c0, rec.i, rec.more, xs[j]);
+                st[j] = qb >= 0 ? qb : rec.i + 1;
             }
-            WC_T(m_found ? 1 : 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if ((valid >> j) & 1u) {
-                    const uint32_t bit = 1u << (bins[j] & 31);
-                    const uint32_t old = atomicOr(&bitmap[bins[j] >> 5], bit);
-                    if (old & bit) {
-                        const int c = atomicAdd(&s_ncoll, 1);
-                        coll_bin[c] = bins[j];
-                        coll_min[c] = 0x7fffffff;
-                    }
+                    const WcLoc L = wc_finish(qa.Sq, qa.n, st[j], 0, qa.n, 0.0, Stot, xs[j]);
+                    bins[j] = L.bin;
+                    sb[j] = L.s;
+                    sp[j] = L.sprev;
                 }
             }
-            __syncthreads();
-            WC_T(2);
-            const int nc = s_ncoll;
-            unsigned keep = valid;
-            if (nc) {
-                // a bin drawn more than once keeps its FIRST draw (np.unique(return_index) + sort)
-                int slot[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    slot[j] = -1;
-                    if ((valid >> j) & 1u) {
-                        for (int c = 0; c < nc; ++c)
-                            if (coll_bin[c] == bins[j]) {
-                                slot[j] = c;
-                                break;
-                            }
-                        if (slot[j] >= 0) atomicMin(&coll_min[slot[j]], tid * per + j);
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (slot[j] >= 0 && coll_min[slot[j]] != tid * per + j) keep &= ~(1u << j);
-            }
-            WC_T(3);
-            // ordered compaction of the kept draws behind the ones found so far
-            const int cnt = __popc(keep);
-            int excl = 0, wtot = 0;
-#pragma unroll
-            for (int bit = 0; bit < 3; ++bit) {
-                const unsigned long long mk = __ballot((cnt >> bit) & 1);
-                excl += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u)) << bit;
-                wtot += __popcll(mk) << bit;
-            }
-            if (lane == 0) wsum[wave] = wtot;
-            __syncthreads();
-            int base = n_uniq, total = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                if (w < wave) base += wsum[w];
-                total += wsum[w];
-            }
-            int r = base + excl;
+        } else {
+            // redraw rounds: few draws (usually one per lane, < 64 lanes)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if ((keep >> j) & 1u) {
-                    fid[r] = bins[j];
-                    fS[r] = sb[j];
-                    fP[r] = sb[j] - sp[j];
-                    ++r;
+                const int d = tid * per + j;
+                if (j < per && d < m) {
+                    valid |= 1u << j;
+                    const uint2 wp = *(const uint2 *)(qa.words + o + 2LL * d);
+                    const double x = wc_double(wp.x, wp.y);
+                    const WcGap g = wc_gap(qa.n, qa.K, Stot, Stot_cur, x, m_found, l.sid, l.sV, l.sC);
+                    const WcLoc L = wc_finish(qa.Sq, qa.n, qa.Rq[g.bucket].i, g.lo, g.hi, g.Ck, Stot_cur, x);
+                    bins[j] = L.bin;
+                    sb[j] = L.s;
+                    sp[j] = L.sprev;
                 }
-            }
-            n_uniq += total;
-            o += 2LL * m;
-            if (tid == 0) s_ncoll = 0;
-            __syncthreads();
-            WC_T(4);
-            if (n_uniq < a.nsel) {
-                // found ids in ascending order through the bitmap: rank = set bits below
-                const int wper = (BW + 255) >> 8, w0 = tid * wper;
-                int local = 0;
-                for (int i = 0; i < wper; ++i)
-                    if (w0 + i < BW) local += __popc(bitmap[w0 + i]);
-                int v = local;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int u = __shfl_up(v, off);
-                    if (lane >= off) v += u;
-                }
-                if (lane == 63) wsum[wave] = v;
-                __syncthreads();
-                int run = v - local;
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    if (w < wave) run += wsum[w];
-                for (int i = 0; i < wper; ++i) {
-                    if (w0 + i < BW) {
-                        wpre[w0 + i] = run;
-                        run += __popc(bitmap[w0 + i]);
-                    }
-                }
-                __syncthreads();
-                for (int e = tid; e < n_uniq; e += 256) {
-                    const int f = fid[e];
-                    const int rank = wpre[f >> 5] + __popc(bitmap[f >> 5] & ((1u << (f & 31)) - 1u));
-                    sid[rank] = f;
-                    sV[rank] = fS[e];
-                    sC[rank] = fP[e];
-                }
-                __syncthreads();
-                // C = inclusive scan of the found masses (exact), V = S - C
-                const int e0 = 4 * tid;
-                double c[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) c[j] = (e0 + j < n_uniq) ? sC[e0 + j] : 0.0;
-                const double l1 = c[0], l2 = l1 + c[1], l3 = l2 + c[2], l4 = l3 + c[3];
-                double vv = l4;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const double u = __shfl_up(vv, off);
-                    if (lane >= off) vv += u;
-                }
-                if (lane == 63) wsumd[wave] = vv;
-                __syncthreads();
-                double bs = vv - l4;
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    if (w < wave) bs += wsumd[w];
-                const double cs[4] = {bs + l1, bs + l2, bs + l3, bs + l4};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (e0 + j < n_uniq) {
-                        sC[e0 + j] = cs[j];
-                        sV[e0 + j] -= cs[j];
-                    }
-                }
-                __syncthreads();
-                Stot_cur = Stot - sC[n_uniq - 1];
-                m_found = n_uniq;
-                WC_T(5);
             }
         }
-        for (int e = tid; e < a.nsel; e += 256) {
-            const int f = fid[e];
-            a.ids_out[(size_t)q * a.nsel + e] = f;
-            bitmap[f >> 5] = 0;
+        __syncthreads();                                  // hash cleared
+        // a bin drawn more than once in this round keeps its FIRST draw (np.unique(return_index) + sort):
+        // hash bin -> smallest draw index
+        unsigned slot[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            slot[j] = 0;
+            if ((valid >> j) & 1u) {
+                const uint32_t bin = (uint32_t)bins[j];
+                const uint32_t packed = (bin << 10) | (uint32_t)(tid * per + j);
+                atomicOr(&l.bitmap[bin >> 5], 1u << (bin & 31));
+                uint32_t h = (bin * 2654435761u) >> 21;
+                for (;;) {
+                    uint32_t cur = l.hash[h];
+                    if (cur == 0xffffffffu) {
+                        const uint32_t old = atomicCAS(&l.hash[h], 0xffffffffu, packed);
+                        if (old == 0xffffffffu) break;
+                        cur = old;
+                    }
+                    if ((cur >> 10) == bin) {
+                        atomicMin(&l.hash[h], packed);
+                        break;
+                    }
+                    h = (h + 1) & (WC_HASH - 1);
+                }
+                slot[j] = h;
+            }
         }
         __syncthreads();
-        WC_T(6);
+        unsigned keep = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (((valid >> j) & 1u) && (l.hash[slot[j]] & 1023u) == (uint32_t)(tid * per + j)) keep |= 1u << j;
+        // ordered compaction of the kept draws behind the ones found so far
+        const int cnt = __popc(keep);
+        int excl = 0, wtot = 0;
+#pragma unroll
+        for (int bit = 0; bit < 3; ++bit) {
+            const unsigned long long mk = __ballot((cnt >> bit) & 1);
+            excl += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u)) << bit;
+            wtot += __popcll(mk) << bit;
+        }
+        if (lane == 0) wsum[wave] = wtot;
+        __syncthreads();
+        int base = n_uniq, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) base += wsum[w];
+            total += wsum[w];
+        }
+        int r = base + excl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if ((keep >> j) & 1u) {
+                l.fid[r] = bins[j];
+                l.fS[r] = sb[j];
+                l.fP[r] = (float)(sb[j] - sp[j]);           // exact: the float32 probability itself
+                ++r;
+            }
+        }
+        n_uniq += total;
+        o += 2LL * m;
+        __syncthreads();
+        if (n_uniq < qa.nsel) {
+            // found ids in ascending order through the bitmap: rank = set bits below
+            const int wper = (BW + 255) >> 8, w0 = tid * wper;
+            int local = 0;
+            for (int i = 0; i < wper; ++i)
+                if (w0 + i < BW) local += __popc(l.bitmap[w0 + i]);
+            int v = local;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int u = __shfl_up(v, off);
+                if (lane >= off) v += u;
+            }
+            if (lane == 63) wsum[wave] = v;
+            __syncthreads();
+            int run = v - local;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                if (w < wave) run += wsum[w];
+            for (int i = 0; i < wper; ++i) {
+                if (w0 + i < BW) {
+                    l.wpre[w0 + i] = (uint16_t)run;
+                    run += __popc(l.bitmap[w0 + i]);
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < n_uniq; e += 256) {
+                const int f = l.fid[e];
+                const int rank = l.wpre[f >> 5] + __popc(l.bitmap[f >> 5] & ((1u << (f & 31)) - 1u));
+                l.sid[rank] = f;
+                l.sV[rank] = l.fS[e];
+                l.sC[rank] = (double)l.fP[e];
+            }
+            __syncthreads();
+            // C = inclusive scan of the found masses (exact), V = S - C
+            const int e0 = 4 * tid;
+            double c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = (e0 + j < n_uniq) ? l.sC[e0 + j] : 0.0;
+            const double l1 = c[0], l2 = l1 + c[1], l3 = l2 + c[2], l4 = l3 + c[3];
+            double vv = l4;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double u = __shfl_up(vv, off);
+                if (lane >= off) vv += u;
+            }
+            if (lane == 63) wsumd[wave] = vv;
+            __syncthreads();
+            double bs = vv - l4;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                if (w < wave) bs += wsumd[w];
+            const double cs[4] = {bs + l1, bs + l2, bs + l3, bs + l4};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (e0 + j < n_uniq) {
+                    l.sC[e0 + j] = cs[j];
+                    l.sV[e0 + j] -= cs[j];
+                }
+            }
+            __syncthreads();
+            Stot_cur = Stot - l.sC[n_uniq - 1];
+            m_found = n_uniq;
+        }
     }
-    if (tid == 0) a.meta[0] = o;
+    for (int e = tid; e < qa.nsel; e += 256) {
+        const int f = l.fid[e];
+        if (WRITE) ids_out[e] = f;
+        l.bitmap[f >> 5] = 0;
+    }
+    __syncthreads();
+    return o;
+}
+
+struct WcArgs {
+    const double *S;          // [nq][n]
+    const WcRec *R;           // [nq][K]
+    const double *stot;       // [nq]
+    const float *pmax;        // [nq] largest probability of the query
+    const uint32_t *words;    // raw tempered words from the generator's position
+    long long cap_words;      // words this request may consume
+    long long alloc_words;    // words readable in the buffer (>= cap_words)
+    int n, K, nq, nsel;
+    long long *base;          // [nq] word offset of every query's first draw (offsets kernel -> ids kernel)
+    int32_t *ids_out;         // [nq][nsel]
+    long long *meta;          // [0] words consumed (out), [1] sticky error
+    long long *stats;         // development counters (null = off): [0] fallbacks, [1] window misses
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// offsets: ONE workgroup walks the queries in order and determines only where each query's draws start.
+//
+// A query consumes 2*nsel words for its first round plus 2 words per redraw.  The number of redraws of round 2 is the
+// number of first-round draws that hit an already taken bin (a bitmap of atomicOr's counts them); further rounds are
+// needed only if two round-2 draws fall into the same bin, which is impossible when they are pairwise farther apart
+// than the widest bin of the modified cdf -- checked on the x values alone.  Only if that test fails (~1 % of the
+// queries) the whole algorithm is run here (wc_full_query) to get the exact count.
+// The look-ups of query q+1's first round are software-pipelined: while query q is processed, the bins of a window
+// of nsel + RMAX consecutive doubles starting where query q+1 would start if query q needed no redraw are computed
+// (its true start is R_q doubles later; R_q <= RMAX, else the window is recomputed).  Random words are staged through
+// an LDS ring two queries ahead.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WC_RMAX = 128;                         // redraws per query covered by the pipelined windows (x2: two queries ahead)
+constexpr int WC_SLOTS = 1280;                       // window slots: 5 per lane >= nsel + 2 * RMAX
+constexpr int WC_RING = 16384;                       // words
+constexpr int WC_LIST = 512;                         // look-ups per window that need a second round (2 per lane)
+
+__host__ __device__ inline size_t wc_offsets_lds_bytes(int n) {
+    return wc_lds_bytes(n) + (size_t)WC_RING * 4 + 2 * WC_SLOTS * 4 + WC_LIST * 16;
+}
+
+__global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
+    __shared__ int wsum[4];
+    __shared__ double wsumd[4];
+    __shared__ int s_cnt, s_unsafe, s_nlist;
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    const WcLds l = wc_carve(wc_lds, a.n);
+    uint32_t *ring = (uint32_t *)(wc_lds + wc_lds_bytes(a.n));
+    int *wbin = (int *)(ring + WC_RING);             // [2][SLOTS] bins of the windows of queries q, q+1
+    double *list_x = (double *)(wbin + 2 * WC_SLOTS);
+    int *list_e = (int *)(list_x + WC_LIST);
+    int *list_i = list_e + WC_LIST;
+    const int BW = (a.n + 31) >> 5;
+    const int win = a.nsel + 2 * WC_RMAX;            // window length in doubles
+    if (a.meta[1] != 0) return;                      // tables invalid (degenerate input) or an earlier failure
+    for (int i = tid; i < BW; i += 256) l.bitmap[i] = 0;
+    if (tid == 0) s_cnt = s_unsafe = s_nlist = 0;
+
+    // ring: words [.., r_hi) of the request are resident at ring[w & (RING-1)]
+    long long r_hi = 0;
+    auto ring_fill = [&](long long upto) {           // synchronous (prologue / after falling behind)
+        upto = upto < a.cap_words ? upto : a.cap_words;
+        for (long long w = r_hi + 4 * tid; w < upto; w += 1024) {
+            const uint4 v = *(const uint4 *)(a.words + w);
+            *(uint4 *)(ring + (w & (WC_RING - 1))) = v;
+        }
+        if (upto > r_hi) r_hi = (upto + 3) & ~3LL;
+    };
+    // window of query t anchored at word `anchor`, synchronously: bins of the doubles anchor + 2e -> wbin[t & 1][e]
+    auto window_sync = [&](int t, long long anchor) {
+        const double *Sq = a.S + (size_t)t * a.n;
+        const WcRec *Rq = a.R + (size_t)t * a.K;
+        const double Stot = a.stot[t];
+        for (int e = tid; e < win; e += 256) {
+            const long long w = anchor + 2LL * e;
+            int bin = 0;
+            if (w + 1 < a.cap_words) {
+                const uint2 wp = *(const uint2 *)(a.words + w);
+                const double x = wc_double(wp.x, wp.y);
+                int bk = (int)(x * (double)a.K);
+                bk = bk > a.K - 1 ? a.K - 1 : bk;
+                const WcRec rec = Rq[bk];
+                bin = wc_quick_bin(rec.c0, rec.i, rec.more, x);
+                if (bin < 0) bin = wc_finish(Sq, a.n, rec.i + 1, 0, a.n, 0.0, Stot, x).bin;
+            }
+            wbin[(t & 1) * WC_SLOTS + e] = bin;
+        }
+    };
+    // asynchronous part 1: x values from the ring, guide records requested (one 16-byte load per slot)
+    double xs_p[5], c0_p[5];
+    int i_p[5], more_p[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        xs_p[j] = c0_p[j] = 0.0;
+        i_p[j] = more_p[j] = 0;
+    }
+    auto issue = [&](int t, long long anchor, double (&xs)[5], double (&c0)[5], int (&ii)[5], int (&mm)[5]) {
+        const WcRec *Rn = a.R + (size_t)t * a.K;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            int e = tid * 5 + j;
+            e = e < win ? e : win - 1;
+            const long long w = anchor + 2LL * e;
+            xs[j] = wc_double(ring[w & (WC_RING - 1)], ring[(w + 1) & (WC_RING - 1)]);
+            int bk = (int)(xs[j] * (double)a.K);
+            bk = bk > a.K - 1 ? a.K - 1 : bk;
+            const WcRec rec = Rn[bk];
+            c0[j] = rec.c0;
+            ii[j] = rec.i;
+            mm[j] = rec.more;
+        }
+    };
+    auto covered = [&](long long anchor) {           // all words of a window staged and inside the request
+        return anchor + 2LL * win <= r_hi && anchor + 2LL * win <= a.cap_words;
+    };
+
+    long long base = 0;                              // word offset of the current query's first draw (uniform)
+    long long anc0 = 0, anc1 = 2LL * a.nsel;         // anchors of the windows of queries q and q+1
+    bool issued1 = false;
+    ring_fill(8LL * a.nsel + 6 * WC_RMAX + 4096);
+    __syncthreads();
+    window_sync(0, 0);
+    if (a.nq > 1 && covered(anc1)) {
+        issue(1, anc1, xs_p, c0_p, i_p, more_p);
+        issued1 = true;
+    }
+    // per-query scalars one query ahead of their use
+    double St0 = a.stot[0], St1 = a.nq > 1 ? a.stot[1] : 0.0;
+    float pm0 = a.pmax[0], pm1 = a.nq > 1 ? a.pmax[1] : 0.0f;
+    __syncthreads();
+
+    long long t_last = a.stats ? wall_clock64() : 0;
+#define WC_T(k)                                                     \
+    do {                                                            \
+        if (a.stats && tid == 0) {                                  \
+            const long long t_ = wall_clock64();                    \
+            a.stats[k] += t_ - t_last;                              \
+            t_last = t_;                                            \
+        }                                                           \
+    } while (0)
+    for (int q = 0; q < a.nq; ++q) {
+        if (tid == 0) a.base[q] = base;
+        if (base + 2LL * a.nsel > a.cap_words) {     // uniform
+            if (tid == 0) {
+                a.meta[1] = 2;
+                a.meta[0] = base;
+            }
+            return;
+        }
+        const double St2 = (q + 2 < a.nq) ? a.stot[q + 2] : 0.0;
+        const float pm2 = (q + 2 < a.nq) ? a.pmax[q + 2] : 0.0f;
+        // ---- stage more words: loads now, LDS stores at the end of the iteration
+        const long long fill_to = base + 8LL * a.nsel + 6 * WC_RMAX;
+        const bool do_fill = r_hi < fill_to && r_hi + 4096 <= a.alloc_words;    // uniform: a whole 4096-word chunk
+        const long long f0 = r_hi + 16 * tid;
+        uint4 fill[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fill[k] = do_fill ? *(const uint4 *)(a.words + f0 + 4 * k) : make_uint4(0, 0, 0, 0);
+
+        // ---- A: window of query q+1 (records requested one iteration ago): most slots are decided by the record,
+        //         the rest goes to a list whose S values are requested now and looked at after the work on query q
+        const double *Sn = a.S + (size_t)(q + 1) * a.n;
+        int *wn = wbin + ((q + 1) & 1) * WC_SLOTS;
+        if (issued1) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int e = tid * 5 + j;
+                if (e < win) {
+                    const int qb = wc_quick_bin(c0_p[j], i_p[j], more_p[j], xs_p[j]);
+                    if (qb >= 0) {
+                        wn[e] = qb;
+                    } else {
+                        const int k = atomicAdd(&s_nlist, 1);
+                        if (k < WC_LIST) {
+                            list_e[k] = e;
+                            list_i[k] = i_p[j] + 1;
+                            list_x[k] = xs_p[j];
+                        } else {
+                            wn[e] = wc_finish(Sn, a.n, i_p[j] + 1, 0, a.n, 0.0, St1, xs_p[j]).bin;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int nl = s_nlist < WC_LIST ? s_nlist : WC_LIST;
+        double sl[2][8];
+        int le[2], li[2];
+        double lx[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = tid + 256 * u;
+            le[u] = -1;
+            li[u] = 0;
+            lx[u] = 0.0;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) sl[u][v] = 0.0;
+            if (k < nl) {
+                le[u] = list_e[k];
+                li[u] = list_i[k];
+                lx[u] = list_x[k];
+#pragma unroll
+                for (int v = 0; v < 8; ++v) sl[u][v] = Sn[li[u] + v < a.n ? li[u] + v : a.n - 1];
+            }
+        }
+        WC_T(2);
+        // ---- I: request the records of the window of query q+2 (anchor: no redraws in q and q+1)
+        const long long anc2 = base + 4LL * a.nsel;
+        const bool issued2 = (q + 2 < a.nq) && covered(anc2);
+        double xs_c[5], c0_c[5];
+        int i_c[5], more_c[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            xs_c[j] = c0_c[j] = 0.0;
+            i_c[j] = more_c[j] = 0;
+        }
+        if (issued2) issue(q + 2, anc2, xs_c, c0_c, i_c, more_c);
+        WC_T(3);
+
+        // ---- Q: query q itself: number of distinct bins of its first round
+        const int rho = (int)((base - anc0) >> 1);                       // redraw doubles skipped in the window
+        const int *wb = wbin + (q & 1) * WC_SLOTS;
+        int events = 0;
+        for (int d = tid; d < a.nsel; d += 256) {
+            const int bin = wb[rho + d];
+            const uint32_t bit = 1u << (bin & 31);
+            events += (atomicOr(&l.bitmap[bin >> 5], bit) & bit) ? 1 : 0;
+        }
+        if (events) atomicAdd(&s_cnt, events);
+        __syncthreads();
+        const int m2 = s_cnt;
+        WC_T(4);
+        long long used = 2LL * a.nsel + 2LL * m2;
+        bool fallback = false;
+        if (m2 > 0) {
+            // round 2 draws m2 doubles right behind the first round; they are distinct for sure if pairwise farther
+            // apart than the widest possible bin of the modified cdf
+            const double pm = (double)pm0;
+            const double denom = St0 - (double)a.nsel * pm;
+            if (m2 > 64 || !(denom > 0.25 * St0) || base + used > r_hi) {
+                fallback = true;
+            } else {
+                const double wmax = (pm / denom) * (1.0 + 1e-9);     // widest bin of the modified cdf (+ rounding slack)
+                if (tid < m2) {
+                    const long long w = base + 2LL * a.nsel + 2LL * tid;
+                    const double x = wc_double(ring[w & (WC_RING - 1)], ring[(w + 1) & (WC_RING - 1)]);
+                    bool bad = false;
+                    for (int e = 0; e < m2; ++e) {
+                        const long long w2 = base + 2LL * a.nsel + 2LL * e;
+                        const double y = wc_double(ring[w2 & (WC_RING - 1)], ring[(w2 + 1) & (WC_RING - 1)]);
+                        bad |= (e != tid) && (fabs(x - y) <= wmax);
+                    }
+                    if (bad) s_unsafe = 1;
+                }
+                __syncthreads();
+                fallback = s_unsafe != 0;
+            }
+        }
+        WC_T(5);
+        // clear the bits of this query (every set bit belongs to one of its bins)
+        for (int d = tid; d < a.nsel; d += 256) l.bitmap[wb[rho + d] >> 5] = 0;
+        __syncthreads();
+        if (tid == 0) s_cnt = s_unsafe = 0;
+        if (fallback) {
+            WcQuery qa;
+            qa.Sq = a.S + (size_t)q * a.n;
+            qa.Rq = a.R + (size_t)q * a.K;
+            qa.Stot = St0;
+            qa.words = a.words + base;
+            qa.words_left = a.cap_words - base;
+            qa.n = a.n;
+            qa.K = a.K;
+            qa.nsel = a.nsel;
+            used = wc_full_query<false>(qa, l, wsum, wsumd, nullptr);
+            if (tid == 0 && a.stats) a.stats[0] += 1;
+            if (used < 0) {
+                if (tid == 0) {
+                    a.meta[1] = 3;
+                    a.meta[0] = base;
+                }
+                return;
+            }
+        }
+        WC_T(6);
+        // ---- B: second round of the window of query q+1
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (le[u] >= 0) {
+                int bin = -1;
+#pragma unroll
+                for (int v = 0; v < 8; ++v)
+                    if (bin < 0 && li[u] + v < a.n && (sl[u][v] / St1) > lx[u]) bin = li[u] + v;
+                if (bin < 0) bin = wc_finish(Sn, a.n, li[u] + 8, 0, a.n, 0.0, St1, lx[u]).bin;
+                wn[le[u]] = bin;
+            }
+        }
+        const long long base_next = base + used;
+        if (q + 1 < a.nq) {
+            const long long rho1 = (base_next - anc1) >> 1;
+            if (!issued1 || rho1 > 2 * WC_RMAX) {
+                // window miss (more redraws than the window covers, or its words were not staged in time)
+                __syncthreads();
+                window_sync(q + 1, base_next);
+                anc1 = base_next;
+                if (tid == 0 && a.stats) a.stats[1] += 1;
+            }
+        }
+        WC_T(7);
+        // ---- ring: store the words loaded at the top; refill synchronously if the pipeline fell behind
+        if (do_fill) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *(uint4 *)(ring + ((f0 + 4 * k) & (WC_RING - 1))) = fill[k];
+            r_hi += 4096;
+        }
+        if (tid == 0) s_nlist = 0;
+        __syncthreads();
+        if (r_hi < base_next + 6LL * a.nsel + 4 * WC_RMAX && r_hi < a.cap_words) {
+            ring_fill(base_next + 8LL * a.nsel + 6 * WC_RMAX);
+            __syncthreads();
+        }
+        // rotate the pipeline
+        base = base_next;
+        anc0 = anc1;
+        anc1 = anc2;
+        issued1 = issued2;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            xs_p[j] = xs_c[j];
+            c0_p[j] = c0_c[j];
+            i_p[j] = i_c[j];
+            more_p[j] = more_c[j];
+        }
+        St0 = St1;
+        St1 = St2;
+        pm0 = pm1;
+        pm1 = pm2;
+        WC_T(8);
+    }
+#undef WC_T
+    if (tid == 0) a.meta[0] = base;
+}
+
+// ids: one workgroup per query, every query's word offset known -> the full algorithm in parallel
+__global__ __launch_bounds__(256) void wc_ids_kernel(WcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
+    __shared__ int wsum[4];
+    __shared__ double wsumd[4];
+    const int tid = threadIdx.x;
+    if (a.meta[1] != 0) return;
+    const WcLds l = wc_carve(wc_lds, a.n);
+    const int BW = (a.n + 31) >> 5;
+    for (int i = tid; i < BW; i += 256) l.bitmap[i] = 0;
+    __syncthreads();
+    const int q = blockIdx.x;
+    const long long base = a.base[q];
+    WcQuery qa;
+    qa.Sq = a.S + (size_t)q * a.n;
+    qa.Rq = a.R + (size_t)q * a.K;
+    qa.Stot = a.stot[q];
+    qa.words = a.words + base;
+    qa.words_left = a.cap_words - base;
+    qa.n = a.n;
+    qa.K = a.K;
+    qa.nsel = a.nsel;
+    const long long used = wc_full_query<true>(qa, l, wsum, wsumd, a.ids_out + (size_t)q * a.nsel);
+    // cross-check against the offsets kernel: both must agree on where the next query starts
+    const long long next = (q + 1 < a.nq) ? a.base[q + 1] : a.meta[0];
+    if (tid == 0 && (used < 0 || base + used != next)) a.meta[1] = 4;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -630,7 +1003,7 @@ int wc_reserve(p2s_rng_s *r, size_t nq, size_t n, size_t K) {
     r->wc_cap_q = r->wc_cap_n = r->wc_cap_k = 0;
     nq = std::max(nq, r->wc_cap_q);
     if (hipMalloc(&r->wc_dist, nq * n * 4) != hipSuccess || hipMalloc(&r->wc_S, nq * n * 8) != hipSuccess ||
-        hipMalloc(&r->wc_T, nq * K * sizeof(WcRec)) != hipSuccess || hipMalloc(&r->wc_stot, nq * 8) != hipSuccess) {
+        hipMalloc(&r->wc_T, nq * K * sizeof(WcRec)) != hipSuccess || hipMalloc(&r->wc_stot, nq * 20) != hipSuccess) {
         (void)hipGetLastError();
         p2s_set_error("weighted sub-sample: hipMalloc of the per-query tables failed (%zu queries x %zu points)", nq, n);
         return P2S_ENOMEM;
@@ -696,56 +1069,67 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
     plan.n_leaves = c->wc_leaves;
     plan.n_levels = c->wc_levels;
     plan.root = c->wc_root;
-    const int BW = (n + 31) / 32;
-    size_t lds = (size_t)WC_MAX_SEL * (4 * 8 + 4 * 4) + (size_t)BW * 8;
-    // the choice kernel is one latency-bound workgroup running next to the MFMA-saturated encoders: give it a CU of
+    // per-query scalars share one allocation: [stot f64][base i64][pmax f32]
+    double *stot = r->wc_stot;
+    long long *base = (long long *)(stot + r->wc_cap_q);
+    float *pmax = (float *)(base + r->wc_cap_q);
+    const size_t lds_ids = wc_lds_bytes(n);
+    size_t lds_off = wc_offsets_lds_bytes(n);
+    // the offsets kernel is one latency-bound workgroup running next to the MFMA-saturated encoders: give it a CU of
     // its own by claiming most of that CU's LDS (same placement trick as the serial generator)
-    static const size_t hog = getenv("P2S_RNG_LDS_HOG") ? (size_t)atoi(getenv("P2S_RNG_LDS_HOG")) : 120 * 1024;
-    if (nq >= 64) lds = std::max(lds, hog);
-    if (lds > 150 * 1024) {
+    const size_t hog = getenv("P2S_RNG_LDS_HOG") ? (size_t)atoi(getenv("P2S_RNG_LDS_HOG")) : 120 * 1024;
+    if (lds_off > 160 * 1024 - 256) {
         p2s_set_error("p2s_subsample_weighted: cloud of %d points does not fit the LDS bitmap", n);
         return P2S_ECAPACITY;
     }
+    if (nq >= 64) lds_off = std::max(lds_off, hog);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void *)wc_choice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void *)wc_offsets_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute((const void *)wc_ids_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr = true;
     }
     long long *meta = p2s_rng_raw_meta(r);
+    static long long *stats_dev = nullptr;
+    const bool want_stats = getenv("P2S_WC_STATS") != nullptr;
+    if (want_stats && !stats_dev) (void)hipMalloc(&stats_dev, 16 * 8);
     for (int64_t done = 0; done < nq;) {
         const int cur = (int)std::min<int64_t>(per_req, nq - done);
         rc = p2s_rng_raw_begin(r, s);
         if (rc) return rc;
         hipLaunchKernelGGL(wc_tables_kernel, dim3(cur), dim3(256), 0, s, c->d.pts, n, q_dev + (size_t)done * 3, plan, K,
-                           r->wc_dist, r->wc_S, (WcRec *)r->wc_T, r->wc_stot, meta);
+                           r->wc_dist, r->wc_S, (WcRec *)r->wc_T, stot, pmax, meta);
         WcArgs a;
         a.S = r->wc_S;
         a.R = (const WcRec *)r->wc_T;
-        a.stot = r->wc_stot;
+        a.stot = stot;
+        a.pmax = pmax;
         a.words = r->tmp;
         a.cap_words = cap;
+        a.alloc_words = cap + 624;
         a.n = n;
         a.K = K;
         a.nq = cur;
         a.nsel = n_sel;
+        a.base = base;
         a.ids_out = ids_out_dev + (size_t)done * n_sel;
         a.meta = meta;
-        a.prof = nullptr;
-        static long long *prof_dev = nullptr;
-        if (getenv("P2S_WC_PROF")) {
-            if (!prof_dev) (void)hipMalloc(&prof_dev, 16 * 8);
-            (void)hipMemsetAsync(prof_dev, 0, 16 * 8, s);
-            a.prof = prof_dev;
+        a.stats = nullptr;
+        if (want_stats) {
+            (void)hipMemsetAsync(stats_dev, 0, 16 * 8, s);
+            a.stats = stats_dev;
         }
-        hipLaunchKernelGGL(wc_choice_kernel, dim3(1), dim3(256), lds, s, a);
-        if (a.prof) {
-            long long h[16];
-            (void)hipMemcpyAsync(h, prof_dev, sizeof(h), hipMemcpyDeviceToHost, s);
-            (void)hipStreamSynchronize(s);
-            fprintf(stderr, "[wc prof] %d queries, 100 MHz ticks: locate1 %lld locate2+ %lld mark %lld resolve %lld compact %lld "
-                            "sortprep %lld output %lld\n", cur, h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
-        }
+        hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(256), lds_off, s, a);
+        hipLaunchKernelGGL(wc_ids_kernel, dim3(cur), dim3(256), lds_ids, s, a);
         P2S_LAUNCH_CHECK("weighted sub-sample kernels");
+        if (want_stats) {
+            long long h[16];
+            (void)hipMemcpyAsync(h, stats_dev, sizeof(h), hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            fprintf(stderr, "[wc stats] %d queries: %lld full-algorithm fallbacks, %lld window misses; 10-ns ticks: "
+                            "A %lld issue %lld mark %lld sepcheck %lld clear+fallback %lld B %lld ring %lld\n", cur, h[0], h[1], h[2],
+                    h[3], h[4], h[5], h[6], h[7], h[8]);
+        }
         rc = p2s_rng_raw_commit(r, s);
         if (rc) return rc;
         done += cur;
