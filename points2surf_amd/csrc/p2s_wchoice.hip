@@ -277,6 +277,9 @@ __device__ __forceinline__ WcLoc wc_finish(const double *__restrict__ Sq, int n,
 __device__ __forceinline__ int wc_quick_bin(double c0, int i, int more, double x) {
     return x < c0 ? i : (more ? -1 : i + 1);
 }
+__device__ __forceinline__ int wc_finish_cold(const double *Sq, int n, int i, double Stot, double x) {
+    return wc_finish(Sq, n, i, 0, n, 0.0, Stot, x).bin;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // LDS layout shared by the kernels below
@@ -328,7 +331,7 @@ struct WcQuery {
 };
 
 template <bool WRITE>
-__device__ long long wc_full_query(const WcQuery &qa, const WcLds &l, int *wsum, double *wsumd, int32_t *ids_out) {
+__device__ __forceinline__ long long wc_full_query(const WcQuery &qa, const WcLds &l, int *wsum, double *wsumd, int32_t *ids_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int BW = (qa.n + 31) >> 5;
     const double Stot = qa.Stot;
@@ -564,7 +567,39 @@ struct WcArgs {
 constexpr int WC_RMAX = 128;                         // redraws per query covered by the pipelined windows (x2: two queries ahead)
 constexpr int WC_SLOTS = 1280;                       // window slots: 5 per lane >= nsel + 2 * RMAX
 constexpr int WC_RING = 16384;                       // words
+constexpr int WC_CELLW = 2048;                       // words per cell bitmap (65536 cells)
 constexpr int WC_LIST = 512;                         // look-ups per window that need a second round (2 per lane)
+
+// window of query t anchored at word `anchor`, synchronously: bins of the doubles anchor + 2e, e < win -> wbin_t[e]
+__device__ __forceinline__ void wc_window_sync(const WcArgs &a, int t, long long anchor, int win, int *wbin_t) {
+    const double *Sq = a.S + (size_t)t * a.n;
+    const WcRec *Rq = a.R + (size_t)t * a.K;
+    const double Stot = a.stot[t];
+    for (int e = threadIdx.x; e < win; e += 256) {
+        const long long w = anchor + 2LL * e;
+        int bin = 0;
+        if (w + 1 < a.cap_words) {
+            const uint2 wp = *(const uint2 *)(a.words + w);
+            const double x = wc_double(wp.x, wp.y);
+            int bk = (int)(x * (double)a.K);
+            bk = bk > a.K - 1 ? a.K - 1 : bk;
+            const WcRec rec = Rq[bk];
+            bin = wc_quick_bin(rec.c0, rec.i, rec.more, x);
+            if (bin < 0) bin = wc_finish(Sq, a.n, rec.i + 1, 0, a.n, 0.0, Stot, x).bin;
+        }
+        wbin_t[e] = bin;
+    }
+}
+
+struct WSet {                                        // guide records of one window, 5 slots per lane
+    double xs[5], c0[5];
+    int ii[5], mm[5];
+};
+__device__ __forceinline__ void wc_lds_barrier() {
+    // LDS-only synchronisation: __syncthreads() would add s_waitcnt vmcnt(0) and drain the loads kept in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 
 __host__ __device__ inline size_t wc_offsets_lds_bytes(int n) {
     return wc_lds_bytes(n) + (size_t)WC_RING * 4 + 2 * WC_SLOTS * 4 + WC_LIST * 16;
@@ -575,6 +610,10 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
     __shared__ int wsum[4];
     __shared__ double wsumd[4];
     __shared__ int s_cnt, s_unsafe, s_nlist;
+    __shared__ long long s_stats[16];
+    __shared__ double s_St[128];                     // per-query scalars, staged 64..128 queries ahead with VECTOR loads
+    __shared__ float s_pm[128];                      // (uniform-address loads would be scalar loads: their latency would
+                                                     //  land on the next LDS barrier's lgkmcnt(0))
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
     const WcLds l = wc_carve(wc_lds, a.n);
@@ -587,7 +626,14 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
     const int win = a.nsel + 2 * WC_RMAX;            // window length in doubles
     if (a.meta[1] != 0) return;                      // tables invalid (degenerate input) or an earlier failure
     for (int i = tid; i < BW; i += 256) l.bitmap[i] = 0;
+    for (int i = tid; i < 2 * WC_CELLW; i += 256) ((uint32_t *)wc_lds)[i] = 0;
     if (tid == 0) s_cnt = s_unsafe = s_nlist = 0;
+    if (tid < 16) s_stats[tid] = 0;
+    if (tid < 128) {
+        const int qq = tid < a.nq ? tid : a.nq - 1;
+        s_St[tid] = a.stot[qq];
+        s_pm[tid] = a.pmax[qq];
+    }
 
     // ring: words [.., r_hi) of the request are resident at ring[w & (RING-1)]
     long long r_hi = 0;
@@ -599,48 +645,73 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
         }
         if (upto > r_hi) r_hi = (upto + 3) & ~3LL;
     };
-    // window of query t anchored at word `anchor`, synchronously: bins of the doubles anchor + 2e -> wbin[t & 1][e]
-    auto window_sync = [&](int t, long long anchor) {
-        const double *Sq = a.S + (size_t)t * a.n;
-        const WcRec *Rq = a.R + (size_t)t * a.K;
-        const double Stot = a.stot[t];
-        for (int e = tid; e < win; e += 256) {
-            const long long w = anchor + 2LL * e;
-            int bin = 0;
-            if (w + 1 < a.cap_words) {
-                const uint2 wp = *(const uint2 *)(a.words + w);
-                const double x = wc_double(wp.x, wp.y);
-                int bk = (int)(x * (double)a.K);
-                bk = bk > a.K - 1 ? a.K - 1 : bk;
-                const WcRec rec = Rq[bk];
-                bin = wc_quick_bin(rec.c0, rec.i, rec.more, x);
-                if (bin < 0) bin = wc_finish(Sq, a.n, rec.i + 1, 0, a.n, 0.0, Stot, x).bin;
-            }
-            wbin[(t & 1) * WC_SLOTS + e] = bin;
-        }
-    };
     // asynchronous part 1: x values from the ring, guide records requested (one 16-byte load per slot)
-    double xs_p[5], c0_p[5];
-    int i_p[5], more_p[5];
+    WSet RA, RB;                                     // ping-pong: no register copies of values still in flight
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        xs_p[j] = c0_p[j] = 0.0;
-        i_p[j] = more_p[j] = 0;
+        RA.xs[j] = RA.c0[j] = RB.xs[j] = RB.c0[j] = 0.0;
+        RA.ii[j] = RA.mm[j] = RB.ii[j] = RB.mm[j] = 0;
     }
-    auto issue = [&](int t, long long anchor, double (&xs)[5], double (&c0)[5], int (&ii)[5], int (&mm)[5]) {
+    // Two draws can only share a bin if their x values are closer than the widest bin of the cdf, pmax / S_N.  On a
+    // grid of G <= S_N / pmax cells such draws sit in the same or in adjacent cells, so a slot whose cell neighbourhood
+    // holds no other slot of the window cannot collide with anything: it needs no look-up at all (ii = -1).  About
+    // 20 % of the slots remain; only those fetch their guide record.
+    uint32_t *cellA = (uint32_t *)wc_lds;            // overlays the arrays of the fallback algorithm: zero on entry
+    uint32_t *cellB = cellA + WC_CELLW;
+    auto issue = [&](int t, long long anchor, double St, float pm, double (&xs)[5], double (&c0)[5], int (&ii)[5],
+                     int (&mm)[5]) {
         const WcRec *Rn = a.R + (size_t)t * a.K;
+        double Gd = floor(St / ((double)pm * (1.0 + 1e-9)));
+        Gd = Gd < 1.0 ? 1.0 : Gd;
+        const int G = Gd > (double)(WC_CELLW * 32) ? WC_CELLW * 32 : (int)Gd;
+        int cell[5];
+        uint32_t bit[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {                // straight-line: the LDS round trips of the 5 slots overlap
+            const int e = tid * 5 + j;
+            const long long w = anchor + 2LL * (e < win ? e : win - 1);
+            xs[j] = wc_double(ring[w & (WC_RING - 1)], ring[(w + 1) & (WC_RING - 1)]);
+            int c = (int)(xs[j] * (double)G);
+            c = c > G - 1 ? G - 1 : c;
+            cell[j] = c;
+            bit[j] = e < win ? 1u << (c & 31) : 0u;  // slots past the window: no-op atomics
+        }
+        uint32_t dup[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) dup[j] = atomicOr(&cellA[cell[j] >> 5], bit[j]) & bit[j];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) atomicOr(&cellB[cell[j] >> 5], dup[j]);
+        wc_lds_barrier();
+        uint32_t nb[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            int e = tid * 5 + j;
-            e = e < win ? e : win - 1;
-            const long long w = anchor + 2LL * e;
-            xs[j] = wc_double(ring[w & (WC_RING - 1)], ring[(w + 1) & (WC_RING - 1)]);
-            int bk = (int)(xs[j] * (double)a.K);
-            bk = bk > a.K - 1 ? a.K - 1 : bk;
-            const WcRec rec = Rn[bk];
-            c0[j] = rec.c0;
-            ii[j] = rec.i;
-            mm[j] = rec.more;
+            const int c = cell[j];
+            const int cm = c > 0 ? c - 1 : c, cp = c + 1 < G ? c + 1 : c;
+            const uint32_t wB = cellB[c >> 5], wM = cellA[cm >> 5], wP = cellA[cp >> 5];
+            uint32_t near = (wB >> (c & 31)) & 1u;
+            near |= (c > 0) ? (wM >> (cm & 31)) & 1u : 0u;
+            near |= (c + 1 < G) ? (wP >> (cp & 31)) & 1u : 0u;
+            nb[j] = near & (bit[j] != 0u ? 1u : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            c0[j] = 0.0;
+            ii[j] = -1;
+            mm[j] = 0;
+            if (nb[j]) {
+                int bk = (int)(xs[j] * (double)a.K);
+                bk = bk > a.K - 1 ? a.K - 1 : bk;
+                const WcRec rec = Rn[bk];
+                c0[j] = rec.c0;
+                ii[j] = rec.i;
+                mm[j] = rec.more;
+            }
+        }
+        wc_lds_barrier();
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {                // (slots past the window alias the cell of the last slot)
+            cellA[cell[j] >> 5] = 0;
+            cellB[cell[j] >> 5] = 0;
         }
     };
     auto covered = [&](long long anchor) {           // all words of a window staged and inside the request
@@ -651,37 +722,56 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
     long long anc0 = 0, anc1 = 2LL * a.nsel;         // anchors of the windows of queries q and q+1
     bool issued1 = false;
     ring_fill(8LL * a.nsel + 6 * WC_RMAX + 4096);
-    __syncthreads();
-    window_sync(0, 0);
+    wc_lds_barrier();
+    wc_window_sync(a, 0, 0, win, wbin);
+    // per-query scalars, loaded three queries ahead of their first use
+    double St0 = s_St[0], St1 = s_St[1], St2 = s_St[2];
+    float pm0 = s_pm[0], pm1 = s_pm[1], pm2 = s_pm[2];
+    double stage_St = 0.0;                           // values on their way to s_St / s_pm (loaded a step ago)
+    float stage_pm = 0.0f;
+    int stage_q = -1;
     if (a.nq > 1 && covered(anc1)) {
-        issue(1, anc1, xs_p, c0_p, i_p, more_p);
+        issue(1, anc1, St1, pm1, RA.xs, RA.c0, RA.ii, RA.mm);
         issued1 = true;
     }
-    // per-query scalars one query ahead of their use
-    double St0 = a.stot[0], St1 = a.nq > 1 ? a.stot[1] : 0.0;
-    float pm0 = a.pmax[0], pm1 = a.nq > 1 ? a.pmax[1] : 0.0f;
-    __syncthreads();
+    wc_lds_barrier();
 
     long long t_last = a.stats ? wall_clock64() : 0;
+    const long long wall0 = t_last, clk0 = a.stats ? clock64() : 0;
 #define WC_T(k)                                                     \
     do {                                                            \
         if (a.stats && tid == 0) {                                  \
             const long long t_ = wall_clock64();                    \
-            a.stats[k] += t_ - t_last;                              \
+            s_stats[k] += t_ - t_last;                              \
             t_last = t_;                                            \
         }                                                           \
     } while (0)
-    for (int q = 0; q < a.nq; ++q) {
+    // one query; P = records of the window of query q+1 (requested a step ago), C = set to fill for query q+2
+    auto step = [&](const int q, WSet &P, WSet &C) -> bool {
         if (tid == 0) a.base[q] = base;
         if (base + 2LL * a.nsel > a.cap_words) {     // uniform
             if (tid == 0) {
                 a.meta[1] = 2;
                 a.meta[0] = base;
             }
-            return;
+            return false;
         }
-        const double St2 = (q + 2 < a.nq) ? a.stot[q + 2] : 0.0;
-        const float pm2 = (q + 2 < a.nq) ? a.pmax[q + 2] : 0.0f;
+        const double St3 = s_St[(q + 3) & 127];
+        const float pm3 = s_pm[(q + 3) & 127];
+        if (stage_q >= 0 && tid < 64) {              // scalars requested a step ago -> LDS (read >= 60 steps from now)
+            s_St[(stage_q + tid) & 127] = stage_St;
+            s_pm[(stage_q + tid) & 127] = stage_pm;
+        }
+        stage_q = -1;
+        if ((q & 63) == 0 && q + 128 - 64 < a.nq + 64) {
+            // entries [q+64, q+128) replace [q-64, q) of the 128-entry ring
+            stage_q = q + 64;
+            if (tid < 64) {
+                const int qq = q + 64 + tid < a.nq ? q + 64 + tid : a.nq - 1;
+                stage_St = a.stot[qq];
+                stage_pm = a.pmax[qq];
+            }
+        }
         // ---- stage more words: loads now, LDS stores at the end of the iteration
         const long long fill_to = base + 8LL * a.nsel + 6 * WC_RMAX;
         const bool do_fill = r_hi < fill_to && r_hi + 4096 <= a.alloc_words;    // uniform: a whole 4096-word chunk
@@ -699,23 +789,23 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
             for (int j = 0; j < 5; ++j) {
                 const int e = tid * 5 + j;
                 if (e < win) {
-                    const int qb = wc_quick_bin(c0_p[j], i_p[j], more_p[j], xs_p[j]);
-                    if (qb >= 0) {
-                        wn[e] = qb;
+                    const int qb = P.ii[j] < 0 ? -2 : wc_quick_bin(P.c0[j], P.ii[j], P.mm[j], P.xs[j]);
+                    if (qb != -1) {
+                        wn[e] = qb;                  // bin, or -2: cannot collide with any other draw
                     } else {
                         const int k = atomicAdd(&s_nlist, 1);
                         if (k < WC_LIST) {
                             list_e[k] = e;
-                            list_i[k] = i_p[j] + 1;
-                            list_x[k] = xs_p[j];
+                            list_i[k] = P.ii[j] + 1;
+                            list_x[k] = P.xs[j];
                         } else {
-                            wn[e] = wc_finish(Sn, a.n, i_p[j] + 1, 0, a.n, 0.0, St1, xs_p[j]).bin;
+                            wn[e] = wc_finish_cold(Sn, a.n, P.ii[j] + 1, St1, P.xs[j]);
                         }
                     }
                 }
             }
         }
-        __syncthreads();
+        wc_lds_barrier();
         const int nl = s_nlist < WC_LIST ? s_nlist : WC_LIST;
         double sl[2][8];
         int le[2], li[2];
@@ -740,27 +830,27 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
         // ---- I: request the records of the window of query q+2 (anchor: no redraws in q and q+1)
         const long long anc2 = base + 4LL * a.nsel;
         const bool issued2 = (q + 2 < a.nq) && covered(anc2);
-        double xs_c[5], c0_c[5];
-        int i_c[5], more_c[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            xs_c[j] = c0_c[j] = 0.0;
-            i_c[j] = more_c[j] = 0;
-        }
-        if (issued2) issue(q + 2, anc2, xs_c, c0_c, i_c, more_c);
+        if (issued2) issue(q + 2, anc2, St2, pm2, C.xs, C.c0, C.ii, C.mm);
         WC_T(3);
 
         // ---- Q: query q itself: number of distinct bins of its first round
         const int rho = (int)((base - anc0) >> 1);                       // redraw doubles skipped in the window
         const int *wb = wbin + (q & 1) * WC_SLOTS;
         int events = 0;
-        for (int d = tid; d < a.nsel; d += 256) {
-            const int bin = wb[rho + d];
-            const uint32_t bit = 1u << (bin & 31);
-            events += (atomicOr(&l.bitmap[bin >> 5], bit) & bit) ? 1 : 0;
+        int mbin[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                // nsel <= 1024: 4 draws per lane, straight-line
+            const int d = tid + 256 * k;
+            const int bin = wb[rho + (d < a.nsel ? d : 0)];
+            mbin[k] = d < a.nsel ? bin : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t bit = mbin[k] >= 0 ? 1u << (mbin[k] & 31) : 0u;
+            events += (atomicOr(&l.bitmap[mbin[k] >= 0 ? mbin[k] >> 5 : 0], bit) & bit) ? 1 : 0;
         }
         if (events) atomicAdd(&s_cnt, events);
-        __syncthreads();
+        wc_lds_barrier();
         const int m2 = s_cnt;
         WC_T(4);
         long long used = 2LL * a.nsel + 2LL * m2;
@@ -774,25 +864,27 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
                 fallback = true;
             } else {
                 const double wmax = (pm / denom) * (1.0 + 1e-9);     // widest bin of the modified cdf (+ rounding slack)
-                if (tid < m2) {
-                    const long long w = base + 2LL * a.nsel + 2LL * tid;
+                if (tid < 64) {                      // wave 0: lane e holds draw e, compared against all through readlane
+                    const long long w = base + 2LL * a.nsel + 2LL * (tid < m2 ? tid : 0);
                     const double x = wc_double(ring[w & (WC_RING - 1)], ring[(w + 1) & (WC_RING - 1)]);
+                    const int xl = __double2loint(x), xh = __double2hiint(x);
                     bool bad = false;
                     for (int e = 0; e < m2; ++e) {
-                        const long long w2 = base + 2LL * a.nsel + 2LL * e;
-                        const double y = wc_double(ring[w2 & (WC_RING - 1)], ring[(w2 + 1) & (WC_RING - 1)]);
+                        const double y = __hiloint2double(__builtin_amdgcn_readlane(xh, e), __builtin_amdgcn_readlane(xl, e));
                         bad |= (e != tid) && (fabs(x - y) <= wmax);
                     }
-                    if (bad) s_unsafe = 1;
+                    if (bad && tid < m2) s_unsafe = 1;
                 }
-                __syncthreads();
+                wc_lds_barrier();
                 fallback = s_unsafe != 0;
             }
         }
         WC_T(5);
         // clear the bits of this query (every set bit belongs to one of its bins)
-        for (int d = tid; d < a.nsel; d += 256) l.bitmap[wb[rho + d] >> 5] = 0;
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (mbin[k] >= 0) l.bitmap[mbin[k] >> 5] = 0;
+        wc_lds_barrier();
         if (tid == 0) s_cnt = s_unsafe = 0;
         if (fallback) {
             WcQuery qa;
@@ -805,13 +897,15 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
             qa.K = a.K;
             qa.nsel = a.nsel;
             used = wc_full_query<false>(qa, l, wsum, wsumd, nullptr);
-            if (tid == 0 && a.stats) a.stats[0] += 1;
+            for (int i = tid; i < 2 * WC_CELLW; i += 256) ((uint32_t *)wc_lds)[i] = 0;    // cell maps overlay its arrays
+            wc_lds_barrier();
+            if (tid == 0 && a.stats) s_stats[0] += 1;
             if (used < 0) {
                 if (tid == 0) {
                     a.meta[1] = 3;
                     a.meta[0] = base;
                 }
-                return;
+                return false;
             }
         }
         WC_T(6);
@@ -823,7 +917,7 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
 #pragma unroll
                 for (int v = 0; v < 8; ++v)
                     if (bin < 0 && li[u] + v < a.n && (sl[u][v] / St1) > lx[u]) bin = li[u] + v;
-                if (bin < 0) bin = wc_finish(Sn, a.n, li[u] + 8, 0, a.n, 0.0, St1, lx[u]).bin;
+                if (bin < 0) bin = wc_finish_cold(Sn, a.n, li[u] + 8, St1, lx[u]);
                 wn[le[u]] = bin;
             }
         }
@@ -832,10 +926,10 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
             const long long rho1 = (base_next - anc1) >> 1;
             if (!issued1 || rho1 > 2 * WC_RMAX) {
                 // window miss (more redraws than the window covers, or its words were not staged in time)
-                __syncthreads();
-                window_sync(q + 1, base_next);
+                wc_lds_barrier();
+                wc_window_sync(a, q + 1, base_next, win, wbin + ((q + 1) & 1) * WC_SLOTS);
                 anc1 = base_next;
-                if (tid == 0 && a.stats) a.stats[1] += 1;
+                if (tid == 0 && a.stats) s_stats[1] += 1;
             }
         }
         WC_T(7);
@@ -846,31 +940,37 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
             r_hi += 4096;
         }
         if (tid == 0) s_nlist = 0;
-        __syncthreads();
+        wc_lds_barrier();
         if (r_hi < base_next + 6LL * a.nsel + 4 * WC_RMAX && r_hi < a.cap_words) {
             ring_fill(base_next + 8LL * a.nsel + 6 * WC_RMAX);
-            __syncthreads();
+            wc_lds_barrier();
         }
         // rotate the pipeline
         base = base_next;
         anc0 = anc1;
         anc1 = anc2;
         issued1 = issued2;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            xs_p[j] = xs_c[j];
-            c0_p[j] = c0_c[j];
-            i_p[j] = i_c[j];
-            more_p[j] = more_c[j];
-        }
         St0 = St1;
         St1 = St2;
+        St2 = St3;
         pm0 = pm1;
         pm1 = pm2;
+        pm2 = pm3;
         WC_T(8);
+        return true;
+    };
+    for (int q = 0; q < a.nq; q += 2) {
+        if (!step(q, RA, RB)) return;
+        if (q + 1 < a.nq && !step(q + 1, RB, RA)) return;
     }
 #undef WC_T
     if (tid == 0) a.meta[0] = base;
+    if (a.stats && tid == 0) {
+        s_stats[9] = wall_clock64() - wall0;
+        s_stats[10] = clock64() - clk0;
+    }
+    wc_lds_barrier();
+    if (a.stats && tid < 16) a.stats[tid] = s_stats[tid];
 }
 
 // ids: one workgroup per query, every query's word offset known -> the full algorithm in parallel
@@ -1078,14 +1178,14 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
     // the offsets kernel is one latency-bound workgroup running next to the MFMA-saturated encoders: give it a CU of
     // its own by claiming most of that CU's LDS (same placement trick as the serial generator)
     const size_t hog = getenv("P2S_RNG_LDS_HOG") ? (size_t)atoi(getenv("P2S_RNG_LDS_HOG")) : 120 * 1024;
-    if (lds_off > 160 * 1024 - 256) {
+    if (lds_off > 160 * 1024 - 4096) {
         p2s_set_error("p2s_subsample_weighted: cloud of %d points does not fit the LDS bitmap", n);
         return P2S_ECAPACITY;
     }
     if (nq >= 64) lds_off = std::max(lds_off, hog);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void *)wc_offsets_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute((const void *)wc_offsets_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         (void)hipFuncSetAttribute((const void *)wc_ids_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr = true;
     }
@@ -1127,8 +1227,8 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
             (void)hipMemcpyAsync(h, stats_dev, sizeof(h), hipMemcpyDeviceToHost, s);
             (void)hipStreamSynchronize(s);
             fprintf(stderr, "[wc stats] %d queries: %lld full-algorithm fallbacks, %lld window misses; 10-ns ticks: "
-                            "A %lld issue %lld mark %lld sepcheck %lld clear+fallback %lld B %lld ring %lld\n", cur, h[0], h[1], h[2],
-                    h[3], h[4], h[5], h[6], h[7], h[8]);
+                            "A %lld issue %lld mark %lld sepcheck %lld clear+fallback %lld B %lld ring %lld; kernel %lld ticks = "
+                            "%lld shader clocks\n", cur, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
         }
         rc = p2s_rng_raw_commit(r, s);
         if (rc) return rc;
