@@ -575,7 +575,7 @@ __device__ __forceinline__ void wc_window_sync(const WcArgs &a, int t, long long
     const double *Sq = a.S + (size_t)t * a.n;
     const WcRec *Rq = a.R + (size_t)t * a.K;
     const double Stot = a.stot[t];
-    for (int e = threadIdx.x; e < win; e += 256) {
+    for (int e = threadIdx.x; e < win; e += (int)blockDim.x) {
         const long long w = anchor + 2LL * e;
         int bin = 0;
         if (w + 1 < a.cap_words) {
@@ -591,9 +591,12 @@ __device__ __forceinline__ void wc_window_sync(const WcArgs &a, int t, long long
     }
 }
 
-struct WSet {                                        // guide records of one window, 5 slots per lane
-    double xs[5], c0[5];
-    int ii[5], mm[5];
+constexpr int WC_NT = 640;                           // lanes of the serial kernel: 10 waves hide each other's LDS latency
+constexpr int WC_SL = 2;                             // window slots per lane (WC_NT * WC_SL >= WC_SLOTS)
+constexpr int WC_MD = 2;                             // first-round draws per lane (WC_NT * WC_MD >= WC_MAX_SEL)
+struct WSet {                                        // guide records of one window
+    double xs[WC_SL], c0[WC_SL];
+    int ii[WC_SL], mm[WC_SL];
 };
 __device__ __forceinline__ void wc_lds_barrier() {
     // LDS-only synchronisation: __syncthreads() would add s_waitcnt vmcnt(0) and drain the loads kept in flight
@@ -605,10 +608,10 @@ __host__ __device__ inline size_t wc_offsets_lds_bytes(int n) {
     return wc_lds_bytes(n) + (size_t)WC_RING * 4 + 2 * WC_SLOTS * 4 + WC_LIST * 16;
 }
 
-__global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
+__global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
-    __shared__ int wsum[4];
-    __shared__ double wsumd[4];
+    __shared__ int wsum[16];
+    __shared__ double wsumd[16];
     __shared__ int s_cnt, s_unsafe, s_nlist;
     __shared__ long long s_stats[16];
     __shared__ double s_St[128];                     // per-query scalars, staged 64..128 queries ahead with VECTOR loads
@@ -625,8 +628,8 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
     const int BW = (a.n + 31) >> 5;
     const int win = a.nsel + 2 * WC_RMAX;            // window length in doubles
     if (a.meta[1] != 0) return;                      // tables invalid (degenerate input) or an earlier failure
-    for (int i = tid; i < BW; i += 256) l.bitmap[i] = 0;
-    for (int i = tid; i < 2 * WC_CELLW; i += 256) ((uint32_t *)wc_lds)[i] = 0;
+    for (int i = tid; i < BW; i += WC_NT) l.bitmap[i] = 0;
+    for (int i = tid; i < 2 * WC_CELLW; i += WC_NT) ((uint32_t *)wc_lds)[i] = 0;
     if (tid == 0) s_cnt = s_unsafe = s_nlist = 0;
     if (tid < 16) s_stats[tid] = 0;
     if (tid < 128) {
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
     long long r_hi = 0;
     auto ring_fill = [&](long long upto) {           // synchronous (prologue / after falling behind)
         upto = upto < a.cap_words ? upto : a.cap_words;
-        for (long long w = r_hi + 4 * tid; w < upto; w += 1024) {
+        for (long long w = r_hi + 4 * tid; w < upto; w += 4 * WC_NT) {
             const uint4 v = *(const uint4 *)(a.words + w);
             *(uint4 *)(ring + (w & (WC_RING - 1))) = v;
         }
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
     // asynchronous part 1: x values from the ring, guide records requested (one 16-byte load per slot)
     WSet RA, RB;                                     // ping-pong: no register copies of values still in flight
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < WC_SL; ++j) {
         RA.xs[j] = RA.c0[j] = RB.xs[j] = RB.c0[j] = 0.0;
         RA.ii[j] = RA.mm[j] = RB.ii[j] = RB.mm[j] = 0;
     }
@@ -658,17 +661,17 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
     // 20 % of the slots remain; only those fetch their guide record.
     uint32_t *cellA = (uint32_t *)wc_lds;            // overlays the arrays of the fallback algorithm: zero on entry
     uint32_t *cellB = cellA + WC_CELLW;
-    auto issue = [&](int t, long long anchor, double St, float pm, double (&xs)[5], double (&c0)[5], int (&ii)[5],
-                     int (&mm)[5]) {
+    auto issue = [&](int t, long long anchor, double St, float pm, double (&xs)[WC_SL], double (&c0)[WC_SL], int (&ii)[WC_SL],
+                     int (&mm)[WC_SL]) {
         const WcRec *Rn = a.R + (size_t)t * a.K;
         double Gd = floor(St / ((double)pm * (1.0 + 1e-9)));
         Gd = Gd < 1.0 ? 1.0 : Gd;
         const int G = Gd > (double)(WC_CELLW * 32) ? WC_CELLW * 32 : (int)Gd;
-        int cell[5];
-        uint32_t bit[5];
+        int cell[WC_SL];
+        uint32_t bit[WC_SL];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {                // straight-line: the LDS round trips of the 5 slots overlap
-            const int e = tid * 5 + j;
+        for (int j = 0; j < WC_SL; ++j) {                // straight-line: the LDS round trips of the 5 slots overlap
+            const int e = tid * WC_SL + j;
             const long long w = anchor + 2LL * (e < win ? e : win - 1);
             xs[j] = wc_double(ring[w & (WC_RING - 1)], ring[(w + 1) & (WC_RING - 1)]);
             int c = (int)(xs[j] * (double)G);
@@ -676,15 +679,15 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
             cell[j] = c;
             bit[j] = e < win ? 1u << (c & 31) : 0u;  // slots past the window: no-op atomics
         }
-        uint32_t dup[5];
+        uint32_t dup[WC_SL];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) dup[j] = atomicOr(&cellA[cell[j] >> 5], bit[j]) & bit[j];
+        for (int j = 0; j < WC_SL; ++j) dup[j] = atomicOr(&cellA[cell[j] >> 5], bit[j]) & bit[j];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) atomicOr(&cellB[cell[j] >> 5], dup[j]);
+        for (int j = 0; j < WC_SL; ++j) atomicOr(&cellB[cell[j] >> 5], dup[j]);
         wc_lds_barrier();
-        uint32_t nb[5];
+        uint32_t nb[WC_SL];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < WC_SL; ++j) {
             const int c = cell[j];
             const int cm = c > 0 ? c - 1 : c, cp = c + 1 < G ? c + 1 : c;
             const uint32_t wB = cellB[c >> 5], wM = cellA[cm >> 5], wP = cellA[cp >> 5];
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
             nb[j] = near & (bit[j] != 0u ? 1u : 0u);
         }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < WC_SL; ++j) {
             c0[j] = 0.0;
             ii[j] = -1;
             mm[j] = 0;
@@ -709,7 +712,7 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
         }
         wc_lds_barrier();
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {                // (slots past the window alias the cell of the last slot)
+        for (int j = 0; j < WC_SL; ++j) {                // (slots past the window alias the cell of the last slot)
             cellA[cell[j] >> 5] = 0;
             cellB[cell[j] >> 5] = 0;
         }
@@ -775,10 +778,11 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
         // ---- stage more words: loads now, LDS stores at the end of the iteration
         const long long fill_to = base + 8LL * a.nsel + 6 * WC_RMAX;
         const bool do_fill = r_hi < fill_to && r_hi + 4096 <= a.alloc_words;    // uniform: a whole 4096-word chunk
-        const long long f0 = r_hi + 16 * tid;
-        uint4 fill[4];
+        const long long f0 = r_hi + 8 * tid;        // lanes 0..511: 8 words each
+        uint4 fill[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) fill[k] = do_fill ? *(const uint4 *)(a.words + f0 + 4 * k) : make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < 2; ++k)
+            fill[k] = (do_fill && tid < 512) ? *(const uint4 *)(a.words + f0 + 4 * k) : make_uint4(0, 0, 0, 0);
 
         // ---- A: window of query q+1 (records requested one iteration ago): most slots are decided by the record,
         //         the rest goes to a list whose S values are requested now and looked at after the work on query q
@@ -786,8 +790,8 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
         int *wn = wbin + ((q + 1) & 1) * WC_SLOTS;
         if (issued1) {
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int e = tid * 5 + j;
+            for (int j = 0; j < WC_SL; ++j) {
+                const int e = tid * WC_SL + j;
                 if (e < win) {
                     const int qb = P.ii[j] < 0 ? -2 : wc_quick_bin(P.c0[j], P.ii[j], P.mm[j], P.xs[j]);
                     if (qb != -1) {
@@ -807,12 +811,12 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
         }
         wc_lds_barrier();
         const int nl = s_nlist < WC_LIST ? s_nlist : WC_LIST;
-        double sl[2][8];
-        int le[2], li[2];
-        double lx[2];
+        double sl[1][8];
+        int le[1], li[1];
+        double lx[1];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int k = tid + 256 * u;
+        for (int u = 0; u < 1; ++u) {
+            const int k = tid;                       // WC_LIST <= WC_NT: one entry per lane
             le[u] = -1;
             li[u] = 0;
             lx[u] = 0.0;
@@ -837,15 +841,15 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
         const int rho = (int)((base - anc0) >> 1);                       // redraw doubles skipped in the window
         const int *wb = wbin + (q & 1) * WC_SLOTS;
         int events = 0;
-        int mbin[4];
+        int mbin[WC_MD];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {                // nsel <= 1024: 4 draws per lane, straight-line
-            const int d = tid + 256 * k;
+        for (int k = 0; k < WC_MD; ++k) {            // nsel <= 1024 <= WC_MD * WC_NT, straight-line
+            const int d = tid + WC_NT * k;
             const int bin = wb[rho + (d < a.nsel ? d : 0)];
             mbin[k] = d < a.nsel ? bin : -1;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < WC_MD; ++k) {
             const uint32_t bit = mbin[k] >= 0 ? 1u << (mbin[k] & 31) : 0u;
             events += (atomicOr(&l.bitmap[mbin[k] >= 0 ? mbin[k] >> 5 : 0], bit) & bit) ? 1 : 0;
         }
@@ -882,7 +886,7 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
         WC_T(5);
         // clear the bits of this query (every set bit belongs to one of its bins)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < WC_MD; ++k)
             if (mbin[k] >= 0) l.bitmap[mbin[k] >> 5] = 0;
         wc_lds_barrier();
         if (tid == 0) s_cnt = s_unsafe = 0;
@@ -897,7 +901,7 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
             qa.K = a.K;
             qa.nsel = a.nsel;
             used = wc_full_query<false>(qa, l, wsum, wsumd, nullptr);
-            for (int i = tid; i < 2 * WC_CELLW; i += 256) ((uint32_t *)wc_lds)[i] = 0;    // cell maps overlay its arrays
+            for (int i = tid; i < 2 * WC_CELLW; i += WC_NT) ((uint32_t *)wc_lds)[i] = 0;    // cell maps overlay its arrays
             wc_lds_barrier();
             if (tid == 0 && a.stats) s_stats[0] += 1;
             if (used < 0) {
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
         WC_T(6);
         // ---- B: second round of the window of query q+1
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 1; ++u) {
             if (le[u] >= 0) {
                 int bin = -1;
 #pragma unroll
@@ -935,8 +939,10 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
         WC_T(7);
         // ---- ring: store the words loaded at the top; refill synchronously if the pipeline fell behind
         if (do_fill) {
+            if (tid < 512) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *(uint4 *)(ring + ((f0 + 4 * k) & (WC_RING - 1))) = fill[k];
+                for (int k = 0; k < 2; ++k) *(uint4 *)(ring + ((f0 + 4 * k) & (WC_RING - 1))) = fill[k];
+            }
             r_hi += 4096;
         }
         if (tid == 0) s_nlist = 0;
@@ -976,8 +982,8 @@ __global__ __launch_bounds__(256) void wc_offsets_kernel(WcArgs a) {
 // ids: one workgroup per query, every query's word offset known -> the full algorithm in parallel
 __global__ __launch_bounds__(256) void wc_ids_kernel(WcArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
-    __shared__ int wsum[4];
-    __shared__ double wsumd[4];
+    __shared__ int wsum[16];
+    __shared__ double wsumd[16];
     const int tid = threadIdx.x;
     if (a.meta[1] != 0) return;
     const WcLds l = wc_carve(wc_lds, a.n);
@@ -1219,7 +1225,7 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
             (void)hipMemsetAsync(stats_dev, 0, 16 * 8, s);
             a.stats = stats_dev;
         }
-        hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(256), lds_off, s, a);
+        hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(WC_NT), lds_off, s, a);
         hipLaunchKernelGGL(wc_ids_kernel, dim3(cur), dim3(256), lds_ids, s, a);
         P2S_LAUNCH_CHECK("weighted sub-sample kernels");
         if (want_stats) {
