@@ -799,6 +799,10 @@ int p2s_rng_destroy(p2s_rng_t r) {
 int p2s_rng_get_state(p2s_rng_t r, uint32_t *mt624_host, int32_t *pos_host, void *stream) {
     if (!r || !mt624_host || !pos_host) return P2S_EINVAL;
     P2S_HIP_CHECK(hipSetDevice(r->device));
+    {
+        const int rc = p2s_rng_session_close(r, (hipStream_t)stream);    // the state lags behind an open session
+        if (rc) return rc;
+    }
     uint32_t st[625];
     P2S_HIP_CHECK(hipMemcpyAsync(st, r->state, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));
     P2S_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
@@ -810,6 +814,10 @@ int p2s_rng_get_state(p2s_rng_t r, uint32_t *mt624_host, int32_t *pos_host, void
 int p2s_rng_set_state(p2s_rng_t r, const uint32_t *mt624_host, int32_t pos, void *stream) {
     if (!r || !mt624_host || pos < 0 || pos > 624) return P2S_EINVAL;
     P2S_HIP_CHECK(hipSetDevice(r->device));
+    {
+        const int rc = p2s_rng_session_close(r, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     uint32_t st[625];
     memcpy(st, mt624_host, 624 * 4);
     st[624] = (uint32_t)pos;
@@ -841,9 +849,19 @@ int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t nq, int n, int32_t
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
         // large requests: parallel generation over 2^levels jump-ahead streams; small ones: the serial kernel
         static const long long par_min = getenv("P2S_RNG_PARALLEL_MIN") ? atoll(getenv("P2S_RNG_PARALLEL_MIN")) : 400000;
+        // large requests: values come from a session (2^levels_max jump-ahead streams generated once, many calls
+        // take consecutive ranges); small ones outside a matching session: the serial kernel
+        static const bool use_session = !getenv("P2S_RNG_NO_SESSION");
+        const bool in_session = r->sess_mode == 1 && r->sess_rng == rng && r->sess_mask == mask;
         int rc;
-        if (r->levels > 0 && target >= par_min) rc = p2s_rng_parallel_randint(r, rng, mask, target, ids_out_dev, s);
-        else rc = p2s_rng_serial_randint(r, rng, mask, target, ids_out_dev, s);
+        if (r->levels_max > 0 && use_session && (in_session || target >= par_min)) {
+            rc = p2s_rng_session_randint(r, rng, mask, target, ids_out_dev, s);
+        } else {
+            rc = p2s_rng_session_close(r, s);
+            if (rc) return rc;
+            if (r->levels > 0 && target >= par_min) rc = p2s_rng_parallel_randint(r, rng, mask, target, ids_out_dev, s);
+            else rc = p2s_rng_serial_randint(r, rng, mask, target, ids_out_dev, s);
+        }
         if (rc) return rc;
     }
     if (pts_out_dev) return p2s_gather_points(c, ids_out_dev, target, pts_out_dev, stream);

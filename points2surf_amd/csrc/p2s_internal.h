@@ -71,8 +71,15 @@ struct p2s_rng_s {
     int device = 0;
     uint32_t *state = nullptr;     // [624] mt + [1] pos
     // parallel generation (GF(2) jump-ahead), optional: tables uploaded by p2s_rng_set_jump_tables
-    int levels = 0;                // streams = 2^levels
+    int levels = 0;                // streams of a one-shot request = 2^levels
+    int levels_max = 0;            // jump tables uploaded (sessions use 2^levels_max streams)
+    int levels_alloc = 0;          // tmp / blk_cum sized for 2^levels_alloc streams
     int blocks_per_stream = 0;
+    // session (p2s_rng.hip): 0 closed, 1 randint values, 2 raw words
+    int sess_mode = 0;
+    uint32_t sess_rng = 0, sess_mask = 0;
+    long long sess_cursor = 0;     // mode 1: values handed out; mode 2: conservative word estimate
+    long long sess_limit = 0;
     uint16_t *jump_sup = nullptr;  // concatenated supports of the jump polynomials
     int jump_off[16] = {};         // offset / count per level
     int jump_cnt[16] = {};
@@ -91,9 +98,10 @@ struct p2s_rng_s {
 // serial generator (p2s_cloud.hip) and parallel generator (p2s_rng.hip)
 int p2s_rng_serial_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s);
 int p2s_rng_parallel_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s);
-// raw 32-bit words after the generator's position, flat in r->tmp, committed later by a device-side count
-long long p2s_rng_raw_capacity(const p2s_rng_s *r);
-long long *p2s_rng_raw_meta(p2s_rng_s *r);       // device: [0] words consumed by the raw request, [1] sticky error
-int p2s_rng_raw_begin(p2s_rng_s *r, hipStream_t s);
-int p2s_rng_raw_commit(p2s_rng_s *r, hipStream_t s);
+// sessions: one large generated segment of the stream that many calls draw from (p2s_rng.hip)
+long long p2s_rng_session_words(const p2s_rng_s *r);           // raw words a session holds
+long long *p2s_rng_raw_meta(p2s_rng_s *r);                     // device: [0] word cursor of the raw session, [1] sticky error
+int p2s_rng_session_close(p2s_rng_s *r, hipStream_t s);        // advance the generator to the cursor; no-op if closed
+int p2s_rng_session_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s);
+int p2s_rng_session_raw(p2s_rng_s *r, long long need_words, hipStream_t s);
 void p2s_wc_free_rng(p2s_rng_s *r);               // p2s_wchoice.hip workspace

@@ -639,7 +639,8 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
     }
 
     // ring: words [.., r_hi) of the request are resident at ring[w & (RING-1)]
-    long long r_hi = 0;
+    const long long base0 = a.meta[0];              // word cursor of the session: where this call's first query starts
+    long long r_hi = base0 & ~3LL;
     auto ring_fill = [&](long long upto) {           // synchronous (prologue / after falling behind)
         upto = upto < a.cap_words ? upto : a.cap_words;
         for (long long w = r_hi + 4 * tid; w < upto; w += 4 * WC_NT) {
@@ -721,12 +722,12 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
         return anchor + 2LL * win <= r_hi && anchor + 2LL * win <= a.cap_words;
     };
 
-    long long base = 0;                              // word offset of the current query's first draw (uniform)
-    long long anc0 = 0, anc1 = 2LL * a.nsel;         // anchors of the windows of queries q and q+1
+    long long base = base0;                          // word offset of the current query's first draw (uniform)
+    long long anc0 = base0, anc1 = base0 + 2LL * a.nsel;    // anchors of the windows of queries q and q+1
     bool issued1 = false;
-    ring_fill(8LL * a.nsel + 6 * WC_RMAX + 4096);
+    ring_fill(base0 + 8LL * a.nsel + 6 * WC_RMAX + 4096);
     wc_lds_barrier();
-    wc_window_sync(a, 0, 0, win, wbin);
+    wc_window_sync(a, 0, base0, win, wbin);
     // per-query scalars, loaded three queries ahead of their first use
     double St0 = s_St[0], St1 = s_St[1], St2 = s_St[2];
     float pm0 = s_pm[0], pm1 = s_pm[1], pm2 = s_pm[2];
@@ -1145,7 +1146,7 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
                       n_sel);
         return P2S_EINVAL;
     }
-    if (r->levels == 0) {
+    if (r->levels_max == 0) {
         p2s_set_error("p2s_subsample_weighted: needs the jump-ahead tables (p2s_rng_set_jump_tables)");
         return P2S_EINVAL;
     }
@@ -1156,16 +1157,19 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
     if (rc) return rc;
     int K = 1024;
     while (K < n) K <<= 1;
-    // queries per raw request: numpy draws 2 words per double, n_sel doubles + a few % redraws per query
-    const long long cap = p2s_rng_raw_capacity(r);
-    long long per_req = cap / (long long)(2.0 * n_sel * 1.15);
-    const long long req_env = getenv("P2S_WCHOICE_QUERIES") ? atoll(getenv("P2S_WCHOICE_QUERIES")) : 0;   // tests: force splitting
+    // queries per batch (table memory: ~1.6 MB per query at 50k points); random words come from the raw session
+    long long per_req = 4096;
+    const long long req_env = getenv("P2S_WCHOICE_QUERIES") ? atoll(getenv("P2S_WCHOICE_QUERIES")) : 0;   // tests
     if (req_env > 0) per_req = std::min(per_req, req_env);
-    if (per_req < 1) {
+    per_req = std::min<long long>(per_req, nq);
+    const long long cap = p2s_rng_session_words(r);
+    // numpy draws 2 words per double, n_sel doubles + a few % redraws per query; the serial kernel stages words
+    // a few queries ahead of the one it works on
+    const long long margin = 8LL * n_sel + 6 * 128 + 8192;
+    if ((long long)(2.0 * n_sel * 1.15) + margin > cap) {
         p2s_set_error("p2s_subsample_weighted: jump tables too small for one query");
         return P2S_EINVAL;
     }
-    per_req = std::min<long long>(per_req, nq);
     rc = wc_reserve(r, (size_t)per_req, (size_t)n, (size_t)K);
     if (rc) return rc;
     WcPlanDev plan;
@@ -1201,7 +1205,7 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
     if (want_stats && !stats_dev) (void)hipMalloc(&stats_dev, 16 * 8);
     for (int64_t done = 0; done < nq;) {
         const int cur = (int)std::min<int64_t>(per_req, nq - done);
-        rc = p2s_rng_raw_begin(r, s);
+        rc = p2s_rng_session_raw(r, (long long)(2.0 * n_sel * 1.15 * cur) + margin, s);
         if (rc) return rc;
         hipLaunchKernelGGL(wc_tables_kernel, dim3(cur), dim3(256), 0, s, c->d.pts, n, q_dev + (size_t)done * 3, plan, K,
                            r->wc_dist, r->wc_S, (WcRec *)r->wc_T, stot, pmax, meta);
@@ -1236,8 +1240,6 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
                             "A %lld issue %lld mark %lld sepcheck %lld clear+fallback %lld B %lld ring %lld; kernel %lld ticks = "
                             "%lld shader clocks\n", cur, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
         }
-        rc = p2s_rng_raw_commit(r, s);
-        if (rc) return rc;
         done += cur;
     }
     if (pts_out_dev) return p2s_gather_points(c, ids_out_dev, nq * n_sel, pts_out_dev, stream);

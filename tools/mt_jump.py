@@ -6,7 +6,7 @@ window by one word", F^J = g_J(F) where g_J(t) = t^J mod phi(t) and phi is the m
 g_J, i.e. a GF(2) convolution of ~20.6k generated words -- embarrassingly parallel on the device.
 
 This script computes phi by Berlekamp-Massey on an output bit stream, the polynomials for jumps of
-B * 2^m blocks (B = 64 blocks of 624 words, m = 0..7) and writes their supports to
+B * 2^m blocks (B = 64 blocks of 624 words, m = 0..12) and writes their supports to
 points2surf_amd/mt_jump_tables.npz.  It self-checks every polynomial against straightforward generation.
 
     python tools/mt_jump.py
@@ -23,18 +23,19 @@ sys.path.insert(0, REPO)
 N, M = 624, 397
 DEG = 19937
 BLOCKS_PER_STREAM = 64
-LEVELS = 8
+LEVELS = 13
 
 
 def raw_sequence(seed, nwords):
     """untempered state words x[0..nwords) ; x[0..623] = the block after the first twist of init_genrand(seed)"""
     from oracle.p2s_oracle import LegacyMT19937
     g = LegacyMT19937(seed)
-    out = []
-    while sum(len(o) for o in out) < nwords:
+    nblocks = (nwords + N - 1) // N
+    out = np.empty(nblocks * N, dtype=np.uint32)
+    for b in range(nblocks):
         g._twist()
-        out.append(g.mt.copy())
-    return np.concatenate(out)[:nwords]
+        out[b * N:(b + 1) * N] = g.mt
+    return out[:nwords]
 
 
 def berlekamp_massey(bits):
