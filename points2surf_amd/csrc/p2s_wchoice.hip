@@ -147,7 +147,14 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
     }
     __syncthreads();
     const double Stot = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
-    if (tid == 0) pmax_all[qi] = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    if (tid == 0) {
+        // pmax, and the number of cells of the close-pair grid of the serial kernel: pitch 1/G >= pmax / S_N
+        const float pmx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+        double Gd = floor(Stot / ((double)pmx * (1.0 + 1e-9)));
+        Gd = Gd < 1.0 ? 1.0 : (Gd > 65536.0 ? 65536.0 : Gd);
+        pmax_all[2 * qi] = pmx;
+        pmax_all[2 * qi + 1] = __int_as_float((int)Gd);
+    }
     __syncthreads();                                  // red_d is reused by the scan below
 
     // pass 4: prefix sums + guide records, tiles of 1024 elements (4 consecutive per lane)
@@ -245,6 +252,14 @@ __device__ __forceinline__ WcGap wc_gap(int n, int K, double Stot, double Stot_c
     g.bucket = b < 0 ? 0 : (b > K - 1 ? K - 1 : b);
     return g;
 }
+// fl(S / St) > x without the division in all but razor-thin cases: S/St >= x(1+2^-52) rounds to at least the double
+// above x, S/St < x rounds to at most x; t = fl(x*St) is within 2^-53 of x*St, so 1e-15 of slack decides both.
+__device__ __forceinline__ bool wc_gt(double S, double St, double x) {
+    const double t = x * St;
+    if (S > t * (1.0 + 1e-15)) return true;
+    if (S < t * (1.0 - 1e-15)) return false;
+    return (S / St) > x;
+}
 // Step 2: exact answer from a starting index near it (S values fetched here; walks are short and rare)
 __device__ __forceinline__ WcLoc wc_finish(const double *__restrict__ Sq, int n, int i, int g_lo, int g_hi, double Ck,
                                            double Stot_cur, double x) {
@@ -252,7 +267,7 @@ __device__ __forceinline__ WcLoc wc_finish(const double *__restrict__ Sq, int n,
     double s_m1 = (i > 0) ? Sq[i - 1] : 0.0;
     double s_0 = Sq[i];
     const double s_p1 = Sq[i + 1 < n ? i + 1 : n - 1];
-#define WC_PRED(sv) ((((sv)-Ck) / Stot_cur) > x)
+#define WC_PRED(sv) wc_gt((sv)-Ck, Stot_cur, x)
     if (WC_PRED(s_0)) {
         while (i > g_lo && WC_PRED(s_m1)) {
             --i;
@@ -540,7 +555,7 @@ struct WcArgs {
     const double *S;          // [nq][n]
     const WcRec *R;           // [nq][K]
     const double *stot;       // [nq]
-    const float *pmax;        // [nq] largest probability of the query
+    const float *pmax;        // [nq][2] largest probability of the query; cells of its close-pair grid (int bits)
     const uint32_t *words;    // raw tempered words from the generator's position
     long long cap_words;      // words this request may consume
     long long alloc_words;    // words readable in the buffer (>= cap_words)
@@ -615,7 +630,7 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
     __shared__ int s_cnt, s_unsafe, s_nlist;
     __shared__ long long s_stats[16];
     __shared__ double s_St[128];                     // per-query scalars, staged 64..128 queries ahead with VECTOR loads
-    __shared__ float s_pm[128];                      // (uniform-address loads would be scalar loads: their latency would
+    __shared__ float2 s_pm[128];                     // (uniform-address loads would be scalar loads: their latency would
                                                      //  land on the next LDS barrier's lgkmcnt(0))
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
@@ -635,7 +650,7 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
     if (tid < 128) {
         const int qq = tid < a.nq ? tid : a.nq - 1;
         s_St[tid] = a.stot[qq];
-        s_pm[tid] = a.pmax[qq];
+        s_pm[tid] = ((const float2 *)a.pmax)[qq];
     }
 
     // ring: words [.., r_hi) of the request are resident at ring[w & (RING-1)]
@@ -662,12 +677,10 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
     // 20 % of the slots remain; only those fetch their guide record.
     uint32_t *cellA = (uint32_t *)wc_lds;            // overlays the arrays of the fallback algorithm: zero on entry
     uint32_t *cellB = cellA + WC_CELLW;
-    auto issue = [&](int t, long long anchor, double St, float pm, double (&xs)[WC_SL], double (&c0)[WC_SL], int (&ii)[WC_SL],
+    auto issue = [&](int t, long long anchor, float2 pmg, double (&xs)[WC_SL], double (&c0)[WC_SL], int (&ii)[WC_SL],
                      int (&mm)[WC_SL]) {
         const WcRec *Rn = a.R + (size_t)t * a.K;
-        double Gd = floor(St / ((double)pm * (1.0 + 1e-9)));
-        Gd = Gd < 1.0 ? 1.0 : Gd;
-        const int G = Gd > (double)(WC_CELLW * 32) ? WC_CELLW * 32 : (int)Gd;
+        const int G = __float_as_int(pmg.y);         // cells of the close-pair grid (tables kernel), <= 32 * WC_CELLW
         int cell[WC_SL];
         uint32_t bit[WC_SL];
 #pragma unroll
@@ -730,12 +743,12 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
     wc_window_sync(a, 0, base0, win, wbin);
     // per-query scalars, loaded three queries ahead of their first use
     double St0 = s_St[0], St1 = s_St[1], St2 = s_St[2];
-    float pm0 = s_pm[0], pm1 = s_pm[1], pm2 = s_pm[2];
+    float2 pm0 = s_pm[0], pm1 = s_pm[1], pm2 = s_pm[2];
     double stage_St = 0.0;                           // values on their way to s_St / s_pm (loaded a step ago)
-    float stage_pm = 0.0f;
+    float2 stage_pm = make_float2(0.0f, 0.0f);
     int stage_q = -1;
     if (a.nq > 1 && covered(anc1)) {
-        issue(1, anc1, St1, pm1, RA.xs, RA.c0, RA.ii, RA.mm);
+        issue(1, anc1, pm1, RA.xs, RA.c0, RA.ii, RA.mm);
         issued1 = true;
     }
     wc_lds_barrier();
@@ -761,7 +774,7 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
             return false;
         }
         const double St3 = s_St[(q + 3) & 127];
-        const float pm3 = s_pm[(q + 3) & 127];
+        const float2 pm3 = s_pm[(q + 3) & 127];
         if (stage_q >= 0 && tid < 64) {              // scalars requested a step ago -> LDS (read >= 60 steps from now)
             s_St[(stage_q + tid) & 127] = stage_St;
             s_pm[(stage_q + tid) & 127] = stage_pm;
@@ -773,7 +786,7 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
             if (tid < 64) {
                 const int qq = q + 64 + tid < a.nq ? q + 64 + tid : a.nq - 1;
                 stage_St = a.stot[qq];
-                stage_pm = a.pmax[qq];
+                stage_pm = ((const float2 *)a.pmax)[qq];
             }
         }
         // ---- stage more words: loads now, LDS stores at the end of the iteration
@@ -835,7 +848,7 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
         // ---- I: request the records of the window of query q+2 (anchor: no redraws in q and q+1)
         const long long anc2 = base + 4LL * a.nsel;
         const bool issued2 = (q + 2 < a.nq) && covered(anc2);
-        if (issued2) issue(q + 2, anc2, St2, pm2, C.xs, C.c0, C.ii, C.mm);
+        if (issued2) issue(q + 2, anc2, pm2, C.xs, C.c0, C.ii, C.mm);
         WC_T(3);
 
         // ---- Q: query q itself: number of distinct bins of its first round
@@ -863,7 +876,7 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
         if (m2 > 0) {
             // round 2 draws m2 doubles right behind the first round; they are distinct for sure if pairwise farther
             // apart than the widest possible bin of the modified cdf
-            const double pm = (double)pm0;
+            const double pm = (double)pm0.x;
             const double denom = St0 - (double)a.nsel * pm;
             if (m2 > 64 || !(denom > 0.25 * St0) || base + used > r_hi) {
                 fallback = true;
@@ -921,7 +934,7 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
                 int bin = -1;
 #pragma unroll
                 for (int v = 0; v < 8; ++v)
-                    if (bin < 0 && li[u] + v < a.n && (sl[u][v] / St1) > lx[u]) bin = li[u] + v;
+                    if (bin < 0 && li[u] + v < a.n && wc_gt(sl[u][v], St1, lx[u])) bin = li[u] + v;
                 if (bin < 0) bin = wc_finish_cold(Sn, a.n, li[u] + 8, St1, lx[u]);
                 wn[le[u]] = bin;
             }
@@ -1110,7 +1123,7 @@ int wc_reserve(p2s_rng_s *r, size_t nq, size_t n, size_t K) {
     r->wc_cap_q = r->wc_cap_n = r->wc_cap_k = 0;
     nq = std::max(nq, r->wc_cap_q);
     if (hipMalloc(&r->wc_dist, nq * n * 4) != hipSuccess || hipMalloc(&r->wc_S, nq * n * 8) != hipSuccess ||
-        hipMalloc(&r->wc_T, nq * K * sizeof(WcRec)) != hipSuccess || hipMalloc(&r->wc_stot, nq * 20) != hipSuccess) {
+        hipMalloc(&r->wc_T, nq * K * sizeof(WcRec)) != hipSuccess || hipMalloc(&r->wc_stot, nq * 24) != hipSuccess) {
         (void)hipGetLastError();
         p2s_set_error("weighted sub-sample: hipMalloc of the per-query tables failed (%zu queries x %zu points)", nq, n);
         return P2S_ENOMEM;
@@ -1179,7 +1192,7 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
     plan.n_leaves = c->wc_leaves;
     plan.n_levels = c->wc_levels;
     plan.root = c->wc_root;
-    // per-query scalars share one allocation: [stot f64][base i64][pmax f32]
+    // per-query scalars share one allocation: [stot f64][base i64][pmax f32, cells i32]
     double *stot = r->wc_stot;
     long long *base = (long long *)(stot + r->wc_cap_q);
     float *pmax = (float *)(base + r->wc_cap_q);

@@ -144,3 +144,37 @@ def test_infer_shape_vanilla_matches_reference_full_grid32(fixture_cloud, golden
     a, _ = engine.infer_shape(model, cloud, rng2, 32, 3, q_begin=0, q_end=1234, chunk=500)
     b, _ = engine.infer_shape(model, cloud, rng2, 32, 3, q_begin=1234, q_end=-1, chunk=4096)
     assert np.array_equal(np.concatenate([a.cpu().numpy(), b.cpu().numpy()]), sdf)
+
+
+def test_rng_sessions_mixed_calls_match_numpy(fixture_cloud, torch_cuda):
+    """one generated session serves many calls: consecutive takes without touching the state in between, small
+    requests inside an open session, a switch to another cloud size, weighted draws in between, and the lazily
+    committed state -- all identical to one numpy RandomState"""
+    from points2surf_amd import engine
+    from oracle import p2s_oracle as O
+    n_pts = fixture_cloud.shape[0]
+    cloud = engine.Cloud(fixture_cloud)
+    small_pts = np.random.default_rng(3).uniform(-0.5, 0.5, (20011, 3)).astype(np.float32)
+    small = engine.Cloud(small_pts)
+    r = engine.Rng(31337)
+    ref = np.random.RandomState(31337)
+
+    def uni(c, n, nq, k):
+        got = r.subsample_uniform(c, nq, k, want_pts=False)[0].cpu().numpy().reshape(-1)
+        assert np.array_equal(got, ref.randint(0, n, nq * k)), (n, nq, k)
+
+    uni(cloud, n_pts, 600, 1000)          # opens a session
+    uni(cloud, n_pts, 4096, 1000)         # take
+    uni(cloud, n_pts, 3, 11)              # small request served by the open session
+    uni(cloud, n_pts, 1, 1)
+    uni(small, 20011, 500, 1000)          # other modulus: close (commit) + new session
+    q = (fixture_cloud[[5, 77, 4000]] + np.float32(0.01)).astype(np.float32)
+    got = r.subsample_weighted(cloud, torch_cuda.from_numpy(q).cuda(), 1000, want_pts=False)[0].cpu().numpy()
+    want = np.stack([ref.choice(n_pts, size=1000, replace=False, p=O.dist_prob(fixture_cloud, qq)) for qq in q])
+    assert np.array_equal(got, want)      # raw-word session after a value session
+    uni(cloud, n_pts, 700, 1000)          # and back
+    mt, pos = r.get_state()               # closes the session: state = numpy's
+    st = ref.get_state()
+    assert np.array_equal(mt, st[1]) and pos == st[2]
+    uni(cloud, n_pts, 2, 5)               # serial kernel on the committed state
+    r.check()
