@@ -16,14 +16,15 @@
 //    table over K ~ N buckets, R[b] = (i = #{cdf_i <= b/K}, S_{i-1}, S_i, S_{i+1}), answers most look-ups with one
 //    32-byte load.
 //
-// Two kernels per chunk of queries:
-//   wc_tables_kernel  one workgroup per query, fully parallel: distances, max, plan-ordered sum, exact prefix sums
-//                     S[q][N] (float64), guide records R[q][K].  HBM-resident (288 GB: ~2.7 MB per query).
-//   wc_choice_kernel  ONE workgroup walks the queries in order -- the number of random words a query consumes
-//                     depends on its collisions, so the stream position is a true serial dependence -- but per
-//                     query it only does ~1000 table look-ups, an LDS bitmap for duplicates and a rank sort.
-// The random words come from the jump-ahead generator (p2s_rng.hip, raw request); the generator is advanced by the
-// count the choice kernel reports.
+// Three kernels per chunk of queries:
+//   wc_tables_kernel   one workgroup per query, fully parallel: distances, max, plan-ordered sum, exact prefix sums
+//                      S[q][N] (float64), guide records R[q][K].  HBM-resident (288 GB: ~1.6 MB per query).
+//   wc_offsets_kernel  ONE workgroup walks the queries in order -- the number of random words a query consumes
+//                      depends on its collisions, so the stream position is a true serial dependence -- and computes
+//                      nothing but that: where every query's draws start.
+//   wc_ids_kernel      one workgroup per query again: with the offsets known, the complete algorithm in parallel.
+// The random words come from a raw session of the jump-ahead generator (p2s_rng.hip); the word cursor lives on the
+// device and the generator is advanced to it when the session is closed.
 #include "p2s_common.h"
 #include "p2s_internal.h"
 #include <vector>
