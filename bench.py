@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--points', type=int, default=50000, help='points of the synthetic cloud')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target CPU-baseline duration (0 = skip)')
+    ap.add_argument('--cpu-seconds', type=float, default=25.0, help='target CPU-baseline duration (0 = skip)')
     ap.add_argument('--chunk', type=int, default=0)
     return ap.parse_args()
 

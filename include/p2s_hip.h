@@ -151,10 +151,12 @@ int p2s_rng_destroy(p2s_rng_t r);
 int p2s_rng_get_state(p2s_rng_t r, uint32_t *mt624_host, int32_t *pos_host, void *stream);
 int p2s_rng_set_state(p2s_rng_t r, const uint32_t *mt624_host, int32_t pos, void *stream);
 
-/* Optional: tables for parallel generation of the stream (GF(2) jump-ahead, tools/mt_jump.py ->
+/* Tables for parallel generation of the stream (GF(2) jump-ahead, tools/mt_jump.py ->
  * points2surf_amd/mt_jump_tables.npz): supports of t^(B*2^m*624) mod phi(t), m = 0..levels-1, concatenated
- * (uint16 exponents), counts_host[m] entries each.  Requests of >= 400k values are then generated by
- * 2^levels workgroups at once; the result is bit-identical to the serial generator. */
+ * (uint16 exponents), counts_host[m] entries each.  Large requests are then served from a *session*: 2^levels
+ * streams of B blocks generated at once (1.3 GB for 512 x 1024 blocks), from which consecutive calls take their
+ * values; the 624-word state is advanced when the session ends (any call that needs the state, or a request with
+ * another modulus).  Results are bit-identical to the serial generator.  Required by p2s_subsample_weighted. */
 int p2s_rng_set_jump_tables(p2s_rng_t r, const uint16_t *supports_host, const int32_t *counts_host, int levels,
                             int blocks_per_stream);
 /* sticky error of the parallel generator (0 = none); synchronises `stream` */

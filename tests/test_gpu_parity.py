@@ -243,7 +243,7 @@ def test_infer_shape_chunking_and_ranges_are_consistent(model_max, cloud_dev, me
 
 
 def test_rng_parallel_jump_ahead_matches_numpy(cloud_dev, fixture_cloud, torch_cuda):
-    """large requests take the GF(2) jump-ahead path (2^8 streams): same stream as numpy / the serial kernel,
+    """large requests take the GF(2) jump-ahead path (sessions of 512 streams): same stream as numpy / the serial kernel,
     including the resume position, across ragged sizes and across the two code paths"""
     from points2surf_amd import engine
     n_pts = fixture_cloud.shape[0]
