@@ -45,10 +45,12 @@ def parse():
     ap.add_argument('--points', type=int, default=50000, help='points of the synthetic cloud')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='target CPU-baseline duration (0 = skip)')
     ap.add_argument('--chunk', type=int, default=0)
+    ap.add_argument('--res', type=int, default=GRID_RES,
+                    help='query-grid resolution; the headline metric is quoted at 256 (other values: BASELINE configs 1/4)')
     return ap.parse_args()
 
 
-def cpu_baseline(w, cfg, cloud, queries, target_seconds):
+def cpu_baseline(w, cfg, cloud, queries, target_seconds, grid_res=GRID_RES):
     import torch
     from oracle.torch_port import TorchPort
     port = TorchPort(w, cfg)
@@ -66,7 +68,7 @@ def cpu_baseline(w, cfg, cloud, queries, target_seconds):
     dt = time.time() - t0
     return {'value': n / dt, 'unit': 'queries/s', 'cores': int(threads), 'kind': 'port',
             'sample': 'first %d of the same %d^3-grid queries (kNN cKDTree + RandomState sub-sample + torch-CPU '
-                      'forward, batch 500), %.1f s' % (n, GRID_RES, dt),
+                      'forward, batch 500), %.1f s' % (n, grid_res, dt),
             'host_cpus': os.cpu_count()}
 
 
@@ -104,13 +106,13 @@ def main():
 
     sdf = None
     for _ in range(args.warmup):
-        sdf, _ = engine.infer_shape(model, cloud, rng, GRID_RES, EPSILON, chunk=args.chunk, want_queries=False)
+        sdf, _ = engine.infer_shape(model, cloud, rng, args.res, EPSILON, chunk=args.chunk, want_queries=False)
     barrier()
     t0 = time.time()
     n_queries = 0
     acc = {}
     for _ in range(args.steps):
-        sdf, _ = engine.infer_shape(model, cloud, rng, GRID_RES, EPSILON, chunk=args.chunk, want_queries=False)
+        sdf, _ = engine.infer_shape(model, cloud, rng, args.res, EPSILON, chunk=args.chunk, want_queries=False)
         n_queries += int(sdf.shape[0])
         for k, v in model.counters().items():
             acc[k] = acc.get(k, 0) + v
@@ -154,11 +156,11 @@ def main():
         except Exception:
             pass
         out = {
-            'metric': 'SDF queries/sec/GPU (p2s_max, 256^3 grid)', 'value': value, 'unit': 'queries/s',
+            'metric': 'SDF queries/sec/GPU (p2s_max, %d^3 grid)' % args.res, 'value': value, 'unit': 'queries/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / max(args.steps, 1) * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE.json configs[2]: p2s_max, grid_res=256, eps=3, kNN patch=300 / global '
+            'config': {'workload': 'BASELINE.json configs[2]: p2s_max, grid_res=%d, eps=3, kNN patch=300 / global ' % args.res +
                                    'sub=1000, fp32; synthetic %d-point cloud per rank (Famous set not available '
                                    'offline), seeded random-init weights' % args.points,
                        'queries_per_shape_rank0': int(sdf.shape[0]), 'parallelism': 'shape-sharded x%d' % world,
@@ -172,8 +174,8 @@ def main():
             'stage_ms_rank0': {k: acc[k] for k in sorted(acc) if k.startswith('ms_')},
         }
         if args.cpu_seconds > 0 and world == 1:
-            q = cloud.query_grid(GRID_RES, EPSILON).cpu().numpy()
-            out['cpu_baseline'] = cpu_baseline(w, cfg, pts, q, args.cpu_seconds)
+            q = cloud.query_grid(args.res, EPSILON).cpu().numpy()
+            out['cpu_baseline'] = cpu_baseline(w, cfg, pts, q, args.cpu_seconds, args.res)
         elif world == 1:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
