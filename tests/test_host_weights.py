@@ -92,3 +92,13 @@ def test_unsupported_configs_raise():
         c.update(bad)
         with pytest.raises(ValueError):
             weights.build_blob(w, c)
+
+
+def test_model_cfg_carries_the_sub_sample_mode():
+    """p2s_max draws randint ids (--uniform_subsample 1), p2s_vanilla the distance-weighted choice"""
+    from points2surf_amd import synth, weights
+    for name, weighted in (('p2s_max', 0), ('p2s_vanilla', 1)):
+        w, cfg = synth.make_weights(name)
+        _, _, mc = weights.build_blob(w, cfg)
+        assert mc.weighted_subsample == weighted
+        assert mc.use_point_stn == weighted
