@@ -163,15 +163,15 @@ int p2s_rng_set_jump_tables(p2s_rng_t r, const uint16_t *supports_host, const in
 int p2s_rng_check(p2s_rng_t r, void *stream);
 
 /* uniform mode (p2s_max, uniform_subsample=1): ids = rng.randint(0, N, n) per query, consumed in
- * query order from one continuous stream.  ids_out_dev [Q][n] int32 (may be NULL),
- * pts_out_dev [Q][n][3] gathered points in model space (may be NULL). */
+ * query order from one continuous stream.  ids_out_dev [Q][n] int32; NULL = only advance the stream past
+ * these queries (query-range sharding), pts_out_dev [Q][n][3] gathered points in model space (may be NULL). */
 int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t n_queries, int n,
                           int32_t *ids_out_dev, float *pts_out_dev, void *stream);
 /* distance-weighted mode (p2s_vanilla, uniform_subsample=0; reference source/base/utils.py:200-219):
  * per query p = clip(1 - 1.5 d/max(d), 0.05, 1) / sum (float32, numpy's summation order) and
  * ids = rng.choice(N, n, replace=False, p=p), consumed in query order from the same continuous stream --
  * bit-identical to numpy's legacy RandomState.  Needs the jump tables (p2s_rng_set_jump_tables).
- * q_dev [Q][3] query points (model space), ids_out_dev [Q][n] int32, pts_out_dev as above (may be NULL).
+ * q_dev [Q][3] query points (model space), ids_out_dev [Q][n] int32 (NULL = advance only), pts_out_dev as above.
  * Errors found on the device (degenerate distances) are reported by p2s_rng_check. */
 int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q_dev, int64_t n_queries, int n,
                            int32_t *ids_out_dev, float *pts_out_dev, void *stream);

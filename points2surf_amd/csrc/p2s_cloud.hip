@@ -452,7 +452,7 @@ __global__ __launch_bounds__(128) void p2s_mt_randint_kernel(uint32_t *__restric
                 for (int it = 0; it < 10; ++it) sv[it] = stage[64 * it + lane];      // batched LDS reads
 #pragma unroll
                 for (int it = 0; it < 10; ++it)
-                    if (64 * it + lane < lim) out[produced + 64 * it + lane] = (int32_t)sv[it];
+                    if (out && 64 * it + lane < lim) out[produced + 64 * it + lane] = (int32_t)sv[it];
             }
             if (total >= need) {
                 // the stream resumes after the word holding the need-th accepted value
@@ -828,8 +828,8 @@ int p2s_rng_set_state(p2s_rng_t r, const uint32_t *mt624_host, int32_t pos, void
 
 int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t nq, int n, int32_t *ids_out_dev, float *pts_out_dev,
                           void *stream) {
-    if (!r || !c || nq < 0 || n < 1 || !ids_out_dev) {
-        p2s_set_error("p2s_subsample_uniform: bad argument (ids_out_dev is required)");
+    if (!r || !c || nq < 0 || n < 1 || (!ids_out_dev && pts_out_dev)) {
+        p2s_set_error("p2s_subsample_uniform: bad argument (pts_out_dev needs ids_out_dev)");
         return P2S_EINVAL;
     }
     if (c->d.n < n) {
@@ -843,7 +843,7 @@ int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t nq, int n, int32_t
     const uint32_t rng = (uint32_t)(c->d.n - 1);
     const long long target = (long long)nq * n;
     if (rng == 0) {
-        P2S_HIP_CHECK(hipMemsetAsync(ids_out_dev, 0, (size_t)target * 4, s));   // numpy consumes no randomness
+        if (ids_out_dev) P2S_HIP_CHECK(hipMemsetAsync(ids_out_dev, 0, (size_t)target * 4, s));   // numpy consumes no randomness
     } else {
         uint32_t mask = rng;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;

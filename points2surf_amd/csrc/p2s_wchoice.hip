@@ -1146,8 +1146,8 @@ void p2s_wc_free_rng(p2s_rng_s *r) {
 
 extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q_dev, int64_t nq, int n_sel,
                                       int32_t *ids_out_dev, float *pts_out_dev, void *stream) {
-    if (!r || !c || !q_dev || nq < 0 || n_sel < 1 || !ids_out_dev) {
-        p2s_set_error("p2s_subsample_weighted: bad argument (q_dev and ids_out_dev are required)");
+    if (!r || !c || !q_dev || nq < 0 || n_sel < 1 || (!ids_out_dev && pts_out_dev)) {
+        p2s_set_error("p2s_subsample_weighted: bad argument (q_dev is required, pts_out_dev needs ids_out_dev)");
         return P2S_EINVAL;
     }
     if (n_sel > WC_MAX_SEL) {
@@ -1236,7 +1236,7 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
         a.nq = cur;
         a.nsel = n_sel;
         a.base = base;
-        a.ids_out = ids_out_dev + (size_t)done * n_sel;
+        a.ids_out = ids_out_dev ? ids_out_dev + (size_t)done * n_sel : nullptr;
         a.meta = meta;
         a.stats = nullptr;
         if (want_stats) {
@@ -1244,7 +1244,7 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
             a.stats = stats_dev;
         }
         hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(WC_NT), lds_off, s, a);
-        hipLaunchKernelGGL(wc_ids_kernel, dim3(cur), dim3(256), lds_ids, s, a);
+        if (ids_out_dev) hipLaunchKernelGGL(wc_ids_kernel, dim3(cur), dim3(256), lds_ids, s, a);   // NULL: advance the stream only
         P2S_LAUNCH_CHECK("weighted sub-sample kernels");
         if (want_stats) {
             long long h[16];

@@ -152,6 +152,33 @@ def _save_shape(model_out_dir, shape_name, sdf_np, q_np):
         pass
 
 
+def _write_part(model_out_dir, shape_name, rank, sdf_np, q_np):
+    """query-range sharding: this rank's ordered piece of a shape (atomic: visible only when complete)"""
+    pdir = os.path.join(model_out_dir, '.parts')
+    os.makedirs(pdir, exist_ok=True)
+    tmp = os.path.join(pdir, '%s.%d.tmp.npz' % (shape_name, rank))
+    np.savez(tmp, sdf=sdf_np, q=q_np)
+    os.replace(tmp, os.path.join(pdir, '%s.%d.npz' % (shape_name, rank)))
+
+
+def _assemble_if_complete(model_out_dir, shape_name, world):
+    """the rank that finds all pieces of a shape (and wins the lock) writes the reference's output files"""
+    pdir = os.path.join(model_out_dir, '.parts')
+    parts = [os.path.join(pdir, '%s.%d.npz' % (shape_name, r)) for r in range(world)]
+    if not all(os.path.isfile(p) for p in parts):
+        return False
+    try:
+        os.close(os.open(os.path.join(pdir, shape_name + '.lock'), os.O_CREAT | os.O_EXCL | os.O_WRONLY))
+    except FileExistsError:
+        return False
+    loaded = [np.load(p) for p in parts]
+    _save_shape(model_out_dir, shape_name, np.concatenate([d['sdf'] for d in loaded]),
+                np.concatenate([d['q'] for d in loaded]))
+    for p in parts:
+        os.remove(p)
+    return True
+
+
 def points_to_surf_eval(eval_opt):
     models = eval_opt.models.split()
     if eval_opt.seed < 0:
@@ -205,7 +232,23 @@ def points_to_surf_eval(eval_opt):
         writers = concurrent.futures.ThreadPoolExecutor(max_workers=2)
         pending = []
         per_shape_rng = os.environ.get('P2S_RNG_MODE', 'dataset') == 'per_shape'
+        # P2S_SHARD=queries: every rank takes a contiguous query range of EVERY shape (few, large shapes; 512^3 grids)
+        # instead of whole shapes; the RNG stream is advanced past the other ranks' queries, results stay identical
+        shard_queries = world > 1 and os.environ.get('P2S_SHARD', 'shapes') == 'queries' and not per_shape_rng
         for shape_ind, shape_name in enumerate(shape_names):
+            if shard_queries:
+                cloud = _engine.Cloud(_load_points(eval_opt.indir, shape_name), device=device)
+                q_all = cloud.query_grid(eval_opt.query_grid_resolution, eval_opt.epsilon)
+                q0, q1 = _sharding.query_range(int(q_all.shape[0]), world, rank)
+                _sharding.skip_queries(cloud, rng_dev, cfg, q_all[:q0], model.sub_sample_size)
+                sdf, q = _engine.infer_shape(model, cloud, rng_dev, eval_opt.query_grid_resolution, eval_opt.epsilon,
+                                             q_begin=q0, q_end=q1, chunk=chunk)
+                _sharding.skip_queries(cloud, rng_dev, cfg, q_all[q1:], model.sub_sample_size)
+                total_q += int(sdf.shape[0])
+                _write_part(model_out_dir, shape_name, rank, sdf.cpu().numpy(), q.cpu().numpy())
+                _assemble_if_complete(model_out_dir, shape_name, world)
+                cloud.close()
+                continue
             if per_shape_rng:
                 if shape_ind not in mine:
                     continue

@@ -244,6 +244,18 @@ class Rng:
                                                       _stream_ptr(self.device)))
         return ids, pts
 
+    def skip(self, cloud, n, n_queries=0, query_ms=None):
+        """advance the stream past queries without producing their ids: ``n_queries`` uniform draws of ``n`` ids, or
+        the distance-weighted draws of the queries ``query_ms`` (query-range sharding, reference stream semantics)"""
+        with torch.cuda.device(self.device):
+            if query_ms is None:
+                _lib.check(self.lib.p2s_subsample_uniform(self.handle, cloud.handle, int(n_queries), int(n), None, None,
+                                                          _stream_ptr(self.device)))
+            else:
+                q = _f32c(query_ms, self.device).reshape(-1, 3)
+                _lib.check(self.lib.p2s_subsample_weighted(self.handle, cloud.handle, _ptr(q), int(q.shape[0]), int(n),
+                                                           None, None, _stream_ptr(self.device)))
+
     def subsample_weighted(self, cloud, query_ms, n, want_pts=True):
         """a6 (distance-weighted, p2s_vanilla): ids [Q,n] int32 = ``rng.choice(N, n, replace=False, p=dist_prob)``
         per query, in query order from the same stream (+ gathered points [Q,n,3])"""

@@ -81,6 +81,25 @@ def gather_variable(t, dst=0):
     return [b[:s] for b, s in zip(bufs, sizes)]
 
 
+def query_range(n_queries, world, rank):
+    """contiguous, ordered split of a shape's queries (intra-shape sharding for few, large shapes): [begin, end)"""
+    base, rem = divmod(int(n_queries), int(world))
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def skip_queries(cloud, rng_dev, cfg, queries, sub_sample_size, chunk=4096):
+    """advance the RNG stream past ``queries`` ([m,3] device tensor, in order) without inference"""
+    m = int(queries.shape[0])
+    if m == 0:
+        return
+    if cfg.get('uniform_subsample'):
+        rng_dev.skip(cloud, sub_sample_size, n_queries=m)
+    else:
+        for s in range(0, m, chunk):
+            rng_dev.skip(cloud, sub_sample_size, query_ms=queries[s:s + chunk])
+
+
 def skip_shape_stream(cloud, rng_dev, cfg, grid_resolution, epsilon, sub_sample_size, chunk=4096):
     """Advance the dataset-wide RNG stream past one shape without running the encoders."""
     import torch

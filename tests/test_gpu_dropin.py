@@ -169,3 +169,47 @@ def test_sharded_eval_is_identical_to_single_process(dropin_source, tmp_path, fi
         b = np.load(os.path.join(sharded, 'rec', 'dist_ms', n + '.xyz.npy'))
         assert a.shape == b.shape and a.size > 500
         assert np.array_equal(a, b), n
+
+
+@pytest.mark.parametrize('name', ['p2s_max', 'p2s_vanilla'])
+def test_query_range_sharding_is_identical_to_single_process(name, dropin_source, tmp_path, fixture_cloud, monkeypatch):
+    """P2S_SHARD=queries: every 'rank' (run one after the other here) infers a contiguous query range of every shape
+    and advances the RNG stream past the other ranks' queries (uniform: value count; weighted: the serial offsets
+    pass) -- the assembled files equal the single-process run bit for bit"""
+    ev, _ = dropin_source
+    root = str(tmp_path / 'ds')
+    rng = np.random.default_rng(1)
+    names = []
+    os.makedirs(os.path.join(root, '04_pts'), exist_ok=True)
+    for i, n in enumerate((7000, 5000)):
+        sel = rng.choice(fixture_cloud.shape[0], n, replace=False)
+        names.append('shape_%d' % i)
+        np.save(os.path.join(root, '04_pts', names[-1] + '.xyz.npy'), fixture_cloud[np.sort(sel)])
+    with open(os.path.join(root, 'testset.txt'), 'w') as f:
+        f.write('\n'.join(names) + '\n')
+    modeldir = str(tmp_path / 'models')
+    _write_model_files(modeldir, name)
+
+    def run(outdir, world, rank):
+        monkeypatch.setenv('WORLD_SIZE', str(world))
+        monkeypatch.setenv('RANK', str(rank))
+        monkeypatch.setenv('LOCAL_RANK', '0')
+        opt = ev.parse_arguments(['--indir', root, '--outdir', outdir, '--dataset', 'testset.txt', '--modeldir', modeldir,
+                                  '--models', name, '--query_grid_resolution', '20', '--epsilon', '3', '--batchSize', '300'])
+        opt.reconstruction = True
+        ev.points_to_surf_eval(opt)
+
+    single = str(tmp_path / 'single')
+    run(single, 1, 0)
+    monkeypatch.setenv('P2S_SHARD', 'queries')
+    sharded = str(tmp_path / 'sharded')
+    for r in (0, 1, 2):
+        run(sharded, 3, r)
+    for n in names:
+        a = np.load(os.path.join(single, 'rec', 'dist_ms', n + '.xyz.npy'))
+        b = np.load(os.path.join(sharded, 'rec', 'dist_ms', n + '.xyz.npy'))
+        assert a.shape == b.shape and a.size > 300
+        assert np.array_equal(a, b), n
+        assert np.array_equal(np.load(os.path.join(single, 'rec', 'query_pts_ms', n + '.xyz.npy')),
+                              np.load(os.path.join(sharded, 'rec', 'query_pts_ms', n + '.xyz.npy')))
+    assert not [f for f in os.listdir(os.path.join(sharded, 'rec', '.parts')) if f.endswith('.npz')]

@@ -69,3 +69,14 @@ def test_gloo_world2_gather(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert int(np.load(os.path.join(str(tmp_path), 'ok.npy'))[0]) == 1539
+
+
+def test_query_range_is_an_ordered_balanced_partition():
+    from points2surf_amd import sharding
+    for Q in (0, 1, 7, 8, 307237, 757499):
+        for world in (1, 2, 3, 8):
+            r = [sharding.query_range(Q, world, k) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == Q
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
