@@ -6,7 +6,7 @@ import os
 from .weights import ModelCfg, WeightOffsets
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libp2s_hip.so')
+LIB_PATH = os.environ.get('P2S_LIB_PATH') or os.path.join(HERE, 'libp2s_hip.so')   # override: development builds
 
 P2S_OK = 0
 P2S_ECAPACITY = -4

@@ -584,7 +584,7 @@ constexpr int WC_RMAX = 128;                         // redraws per query covere
 constexpr int WC_SLOTS = 1280;                       // window slots: 5 per lane >= nsel + 2 * RMAX
 constexpr int WC_RING = 16384;                       // words
 constexpr int WC_CELLW = 2048;                       // words per cell bitmap (65536 cells)
-constexpr int WC_LIST = 512;                         // look-ups per window that need a second round (2 per lane)
+constexpr int WC_LIST = 256;                         // look-ups per window that need a second round (one per lane; more are resolved at once)
 
 // window of query t anchored at word `anchor`, synchronously: bins of the doubles anchor + 2e, e < win -> wbin_t[e]
 __device__ __forceinline__ void wc_window_sync(const WcArgs &a, int t, long long anchor, int win, int *wbin_t) {
@@ -607,9 +607,13 @@ __device__ __forceinline__ void wc_window_sync(const WcArgs &a, int t, long long
     }
 }
 
-constexpr int WC_NT = 640;                           // lanes of the serial kernel: 10 waves hide each other's LDS latency
-constexpr int WC_SL = 2;                             // window slots per lane (WC_NT * WC_SL >= WC_SLOTS)
-constexpr int WC_MD = 2;                             // first-round draws per lane (WC_NT * WC_MD >= WC_MAX_SEL)
+#ifndef P2S_WC_NT
+#define P2S_WC_NT 512
+#endif
+constexpr int WC_NT = P2S_WC_NT;                     // lanes of the serial kernel (256..768 measured: 512 is fastest, 7.9 us per query)
+constexpr int WC_SL = (WC_SLOTS + WC_NT - 1) / WC_NT;        // window slots per lane
+constexpr int WC_MD = (WC_MAX_SEL + WC_NT - 1) / WC_NT;      // first-round draws per lane
+static_assert(WC_NT % 64 == 0 && WC_NT >= 256 && WC_NT <= 768, "serial kernel: whole waves, one workgroup");
 struct WSet {                                        // guide records of one window
     double xs[WC_SL], c0[WC_SL];
     int ii[WC_SL], mm[WC_SL];
@@ -792,12 +796,11 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
         }
         // ---- stage more words: loads now, LDS stores at the end of the iteration
         const long long fill_to = base + 8LL * a.nsel + 6 * WC_RMAX;
-        const bool do_fill = r_hi < fill_to && r_hi + 4096 <= a.alloc_words;    // uniform: a whole 4096-word chunk
-        const long long f0 = r_hi + 8 * tid;        // lanes 0..511: 8 words each
+        const bool do_fill = r_hi < fill_to && r_hi + 8 * WC_NT <= a.alloc_words;   // uniform: a whole chunk, 8 words per lane
+        const long long f0 = r_hi + 8 * tid;
         uint4 fill[2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-            fill[k] = (do_fill && tid < 512) ? *(const uint4 *)(a.words + f0 + 4 * k) : make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < 2; ++k) fill[k] = do_fill ? *(const uint4 *)(a.words + f0 + 4 * k) : make_uint4(0, 0, 0, 0);
 
         // ---- A: window of query q+1 (records requested one iteration ago): most slots are decided by the record,
         //         the rest goes to a list whose S values are requested now and looked at after the work on query q
@@ -954,11 +957,9 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
         WC_T(7);
         // ---- ring: store the words loaded at the top; refill synchronously if the pipeline fell behind
         if (do_fill) {
-            if (tid < 512) {
 #pragma unroll
-                for (int k = 0; k < 2; ++k) *(uint4 *)(ring + ((f0 + 4 * k) & (WC_RING - 1))) = fill[k];
-            }
-            r_hi += 4096;
+            for (int k = 0; k < 2; ++k) *(uint4 *)(ring + ((f0 + 4 * k) & (WC_RING - 1))) = fill[k];
+            r_hi += 8 * WC_NT;
         }
         if (tid == 0) s_nlist = 0;
         wc_lds_barrier();
