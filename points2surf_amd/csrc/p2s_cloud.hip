@@ -739,10 +739,8 @@ int p2s_rng_serial_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long 
     // workgroups slow it ~3x.  Requesting most of a CU's LDS keeps any 50 KB encoder workgroup off its CU
     // (the workgroup is placed when CUs drain at an encoder-kernel boundary); cost: 1 of 256 CUs.
     static const int hog = getenv("P2S_RNG_LDS_HOG") ? atoi(getenv("P2S_RNG_LDS_HOG")) : 120 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // per device (a process may drive several); the call is cheap
         (void)hipFuncSetAttribute((const void *)p2s_mt_randint_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
     }
     // tiny requests (tests, tails) do not need a CU of their own
     const int lds = target >= 100000 ? hog : 0;

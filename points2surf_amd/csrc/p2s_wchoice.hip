@@ -1208,11 +1208,9 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
         return P2S_ECAPACITY;
     }
     if (nq >= 64) lds_off = std::max(lds_off, hog);
-    static bool attr = false;
-    if (!attr) {
+    {   // per device (a process may drive several); the call is cheap
         (void)hipFuncSetAttribute((const void *)wc_offsets_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         (void)hipFuncSetAttribute((const void *)wc_ids_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr = true;
     }
     long long *meta = p2s_rng_raw_meta(r);
     static long long *stats_dev = nullptr;
