@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--points', type=int, default=50000, help='points of the synthetic cloud')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='target CPU-baseline duration (0 = skip)')
     ap.add_argument('--chunk', type=int, default=0)
+    ap.add_argument('--bf16', action='store_true',
+                    help='secondary mode (BASELINE configs[3]): bf16 encoder + fp32 decoder; NOT the headline metric')
     ap.add_argument('--res', type=int, default=GRID_RES,
                     help='query-grid resolution; the headline metric is quoted at 256 (other values: BASELINE configs 1/4)')
     return ap.parse_args()
@@ -91,6 +93,8 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     w, cfg = synth.make_weights('p2s_max')
+    if args.bf16:
+        cfg = dict(cfg, encoder_bf16=True)
     model = engine.Model(w, cfg)
     model.set_profiling(True)
     # every rank owns its own shapes (seeded by rank): shape-level sharding
@@ -145,6 +149,7 @@ def main():
         avg_launch_ms = chain_ms / launches
         flop_per_launch = FLOP_CHAIN_PER_QUERY * n_queries / launches
         achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+        peak = 2500.0 if args.bf16 else PEAK_FP32_MFMA_TFLOPS     # dense MFMA peak of the compute dtype
         # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
         # committed under profiles/; they cannot be collected from inside this process
         traffic, traffic_src = None, None
@@ -152,23 +157,26 @@ def main():
             with open(os.path.join(REPO, 'profiles', 'r01', 'pmc_summary.json')) as f:
                 ck = json.load(f)['chain_kernel']
             traffic = ck['hbm_traffic_bytes_per_launch'] * (2.0 * n_queries / launches) / ck['queries_per_launch']
+            if args.bf16:
+                traffic, traffic_src = None, None        # counters were collected for the fp32 kernel only
             traffic_src = 'profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, scaled to this launch size)'
         except Exception:
             pass
         out = {
-            'metric': 'SDF queries/sec/GPU (p2s_max, %d^3 grid)' % args.res, 'value': value, 'unit': 'queries/s',
+            'metric': 'SDF queries/sec/GPU (p2s_max, %d^3 grid%s)' % (args.res, ', bf16 encoder' if args.bf16 else ''),
+            'value': value, 'unit': 'queries/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / max(args.steps, 1) * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'bf16' if args.bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[2]: p2s_max, grid_res=%d, eps=3, kNN patch=300 / global ' % args.res +
                                    'sub=1000, fp32; synthetic %d-point cloud per rank (Famous set not available '
                                    'offline), seeded random-init weights' % args.points,
                        'queries_per_shape_rank0': int(sdf.shape[0]), 'parallelism': 'shape-sharded x%d' % world,
                        'shapes_per_hour': world * args.steps / dt * 3600.0,
                        'queries_per_s_per_gpu': value / world},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': 'p2s_chain_kernel', 'launches': int(launches), 'avg_launch_ms': avg_launch_ms,
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'kernel': 'p2s_chain_bf16_kernel' if args.bf16 else 'p2s_chain_kernel', 'launches': int(launches), 'avg_launch_ms': avg_launch_ms,
                          'algorithmic_flop_per_launch': flop_per_launch,
                          'hbm_algorithmic_GBps': value / world * BYTES_PER_QUERY / 1e9},
             'stage_ms_rank0': {k: acc[k] for k in sorted(acc) if k.startswith('ms_')},

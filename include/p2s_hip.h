@@ -56,7 +56,10 @@ typedef struct {
     int32_t shared_transformer;  /* one QSTN over cat(patch, sub-sample) (p2s_vanilla)         */
     int32_t weighted_subsample;  /* 0: ids = randint (train --uniform_subsample 1, p2s_max);
                                     1: distance-weighted choice without replacement (p2s_vanilla) */
-    int32_t reserved[9];
+    int32_t encoder_bf16;        /* 1: per-point encoder layers on bf16 MFMA (fp32 accumulate; first layer, STN/QSTN heads,
+                                    fold and decoder stay fp32).  Not bit-comparable with the fp32 reference path:
+                                    see DESIGN.md for the measured deviation.  0 (default): exact fp32             */
+    int32_t reserved[8];
 } p2s_model_cfg;
 
 /* Offsets (in floats) into the weight blob.  The blob holds BatchNorm-folded fp32 weights,

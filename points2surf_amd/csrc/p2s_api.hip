@@ -1,6 +1,7 @@
 // C-ABI glue: error reporting, model handle, workspace, the encoder/decoder pipeline.
 #include "p2s_common.h"
 #include "p2s_internal.h"
+#include <vector>
 #include <cstring>
 #include <cstdlib>
 #include <algorithm>
@@ -66,6 +67,44 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
         p2s_set_error("hipMemcpy(weights) failed: %s", hipGetErrorString(e));
         return P2S_EHIP;
     }
+    if (cfg->encoder_bf16) {
+        // bf16 fragments of the per-point MFMA layers, packed on the device from the fp32 fragments
+        struct Item { size_t *dst; uint64_t src; int K, N; };
+        std::vector<Item> items;
+        for (int e = 0; e < 2; ++e) {
+            const p2s_encoder_offsets &eo = offs->enc[e];
+            items.push_back({&m->h_w0b[e], eo.w0b, 64, 64});
+            items.push_back({&m->h_s1[e], eo.s1, 64, 64});
+            items.push_back({&m->h_s2[e], eo.s2, 64, 128});
+            items.push_back({&m->h_s3[e], eo.s3, 128, 1024});
+            items.push_back({&m->h_m2[e], eo.m2, 64, 128});
+            items.push_back({&m->h_m3[e], eo.m3, 128, 1024});
+        }
+        if (cfg->use_point_stn) {
+            items.push_back({&m->h_qc2, offs->qstn.c2, 64, 128});
+            items.push_back({&m->h_qc3, offs->qstn.c3, 128, 1024});
+        }
+        size_t total = 0;
+        for (auto &it : items) {
+            *it.dst = total;
+            total += (size_t)it.K * it.N;
+        }
+        if (hipMalloc(&m->blob_h, total * 2) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(m->blob);
+            delete m;
+            p2s_set_error("hipMalloc(bf16 weights) failed");
+            return P2S_ENOMEM;
+        }
+        for (auto &it : items) {
+            const int rc = p2s_launch_pack_bf16(m->blob + it.src, m->blob_h + *it.dst, it.K, it.N, 0, 0, 1, nullptr);
+            if (rc) {
+                p2s_model_destroy(m);
+                return rc;
+            }
+        }
+        P2S_HIP_CHECK(hipDeviceSynchronize());
+    }
     *out = m;
     return P2S_OK;
 }
@@ -75,6 +114,7 @@ int p2s_model_destroy(p2s_model_t m) {
     (void)hipSetDevice(m->device);
     if (m->ws) (void)hipFree(m->ws);
     if (m->blob) (void)hipFree(m->blob);
+    if (m->blob_h) (void)hipFree(m->blob_h);
     for (auto &ev : m->evpool)
         if (ev) (void)hipEventDestroy(ev);
     if (m->aux) (void)hipStreamDestroy(m->aux);
@@ -101,6 +141,7 @@ int p2s_get_counters(p2s_model_t m, p2s_counters *out) {
 static size_t ws_floats_per_query(const p2s_model_s *m) {
     size_t n = 2 * 1024 + 2 * 512 + 2 * 256 + 2 * 4096 + 2 * 4096 + 2 * 1024 + 1024 + 256 + 128;
     if (m->cfg.use_point_stn) n += 1024 + 512 + 256 + 16;
+    if (m->cfg.encoder_bf16) n += 4096;          // W1' of both encoders as bf16 fragments
     return n;
 }
 
@@ -126,6 +167,7 @@ namespace {
 
 struct Ws {
     float *g_stn, *h1, *h2, *T, *w1p, *feat, *d1, *d2, *d3, *qg, *qh1, *qh2, *rot;
+    unsigned short *w1h;
 };
 
 Ws carve(const p2s_model_s *m, int C) {
@@ -148,6 +190,7 @@ Ws carve(const p2s_model_s *m, int C) {
         w.qh2 = take((size_t)C * 256);
         w.rot = take((size_t)C * 16);
     }
+    w.w1h = m->cfg.encoder_bf16 ? reinterpret_cast<unsigned short *>(take((size_t)C * 4096)) : nullptr;
     return w;
 }
 
@@ -162,6 +205,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
     const int PL = m->cfg.points_per_patch, PG = m->cfg.sub_sample_size;
     Ws w = carve(m, C);
     int rc;
+    const bool bf16 = m->cfg.encoder_bf16 != 0;
     const int ev0 = p2s_prof_mark(m, s);
 
     const float *rot = nullptr;
@@ -176,9 +220,13 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         b.w2 = W + o.qstn.c2; b.b2 = W + o.qstn.cb2;
         b.w3 = W + o.qstn.c3; b.b3 = W + o.qstn.cb3;
         b.out = w.qg; b.P = PL + PG; b.P1 = PL; b.n_items = C; b.relu_out = 1; b.short_chain = 1;
+        if (bf16) {
+            b.w2 = reinterpret_cast<const float *>(m->blob_h + m->h_qc2);
+            b.w3 = reinterpret_cast<const float *>(m->blob_h + m->h_qc3);
+        }
         a.br[1] = b;
         a.br[1].n_items = 0;
-        if ((rc = p2s_launch_chain(a, s))) return rc;
+        if ((rc = bf16 ? p2s_launch_chain_bf16(a, s) : p2s_launch_chain(a, s))) return rc;
         GemmArgs g;
         memset(&g, 0, sizeof(g));
         g.A = w.qg; g.lda = 1024; g.a_z = 0; g.W[0] = g.W[1] = W + o.qstn.f1; g.bias[0] = g.bias[1] = W + o.qstn.fb1;
@@ -206,8 +254,14 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         b.w2 = W + eo.s2; b.b2 = W + eo.sb2; b.w3 = W + eo.s3; b.b3 = W + eo.sb3;
         b.out = w.g_stn + (size_t)e * C * 1024;
         b.n_items = C; b.relu_out = 1; b.short_chain = 0;
+        if (bf16) {
+            b.w0b = reinterpret_cast<const float *>(m->blob_h + m->h_w0b[e]);
+            b.w1 = reinterpret_cast<const float *>(m->blob_h + m->h_s1[e]);
+            b.w2 = reinterpret_cast<const float *>(m->blob_h + m->h_s2[e]);
+            b.w3 = reinterpret_cast<const float *>(m->blob_h + m->h_s3[e]);
+        }
     }
-    if ((rc = p2s_launch_chain(a, s))) return rc;
+    if ((rc = bf16 ? p2s_launch_chain_bf16(a, s) : p2s_launch_chain(a, s))) return rc;
     const int ev1 = p2s_prof_mark(m, s);
 
     // ---- STN head: 1024 -> 512 -> 256 -> 4096 (+I), then W1' = W1 . trans2 -------------------------
@@ -247,8 +301,14 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         b.w2 = W + eo.m2; b.b2 = W + eo.mb2; b.w3 = W + eo.m3; b.b3 = W + eo.mb3;
         b.out = w.feat + (size_t)e * C * 1024;
         b.relu_out = 0;
+        if (bf16) {
+            b.w1 = reinterpret_cast<const float *>(w.w1h + (size_t)e * C * 4096);
+            b.w2 = reinterpret_cast<const float *>(m->blob_h + m->h_m2[e]);
+            b.w3 = reinterpret_cast<const float *>(m->blob_h + m->h_m3[e]);
+        }
     }
-    if ((rc = p2s_launch_chain(a, s))) return rc;
+    if (bf16 && (rc = p2s_launch_pack_bf16(w.w1p, w.w1h, 64, 64, 4096, 4096, 2 * C, s))) return rc;
+    if ((rc = bf16 ? p2s_launch_chain_bf16(a, s) : p2s_launch_chain(a, s))) return rc;
     const int ev3 = p2s_prof_mark(m, s);
     m->counters.launches_chain += 2;
 

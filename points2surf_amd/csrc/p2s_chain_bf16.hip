@@ -1,0 +1,258 @@
+// bf16 variant of the fused point-wise MLP chain + max-pool (BASELINE.json configs[3]: "bf16 encoder + fp32 decoder").
+//
+// Same work split as p2s_chain_kernel (one 256-lane workgroup per (item, encoder), 64-point tiles in LDS as
+// [point][channel], points on the MFMA rows, max-pool in registers), but the per-point layers run on
+// v_mfma_f32_32x32x16_bf16: activations are rounded to bf16 (nearest even) when they are written to LDS, weights are
+// bf16 B fragments, accumulation / bias / ReLU / max stay fp32.  The first layer (K = 3), the STN / QSTN heads, the
+// fold W1' = W1 . trans2 and the decoder stay fp32 (the fold result is re-packed to bf16 fragments per item).
+//
+// Fragment layout (A from LDS, B from the packed weights): lane l holds 8 consecutive k of row / column l & 31,
+// k = 16 * kb + 8 * (l >> 5) + [0, 8)  -- one 16-byte load each.  Any permutation of k inside a fragment cancels as long
+// as A and B use the same one.  C / D: column l & 31, rows (i & 3) + 8 * (i >> 2) + 4 * (l >> 5), as for 32x32x2.
+//
+// conv3 (128 -> 1024) dominates: a wave keeps the A fragments of both row blocks for all 8 k-blocks in registers
+// (64 VGPRs) and streams its 8 column tiles of weights from L2 (64 KB per wave and tile) -- this variant is bound by
+// that stream, not by the MFMA pipe (16x the fp32 rate).
+#include "p2s_common.h"
+#include <cmath>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MT = 64;          // points per tile
+constexpr int HA = 64 + 8;      // halfs per row of the 64-channel buffer (16-byte rows, bank spread)
+constexpr int HB = 128 + 8;     // halfs per row of the 128-channel buffer
+
+__device__ __forceinline__ unsigned short f2bf(float f) {       // round to nearest even (finite inputs)
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ u32x4 bufld(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+}
+
+// A fragment of rows row0 .. row0+31, k-block kb
+__device__ __forceinline__ u32x4 lds_a(const unsigned short *buf, int H, int row0, int kb, int lane) {
+    return *reinterpret_cast<const u32x4 *>(buf + (row0 + (lane & 31)) * H + 16 * kb + 8 * (lane >> 5));
+}
+
+// acc (+ bias, ReLU) -> bf16 into buf[row0 + r][col0 + c]
+__device__ __forceinline__ void store_tile(const f32x16 &acc, unsigned short *buf, int H, int row0, int col0,
+                                           const float *__restrict__ bias, int lane) {
+    const int c = col0 + (lane & 31);
+    const float b = bias[c];
+    unsigned short *dst = buf + (row0 + 4 * (lane >> 5)) * H + c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = (i & 3) + 8 * (i >> 2);
+        dst[r * H] = f2bf(fmaxf(acc[i] + b, 0.0f));
+    }
+}
+
+__global__ __launch_bounds__(256, 4) void p2s_chain_bf16_kernel(ChainArgs args) {
+    __shared__ __attribute__((aligned(16))) unsigned short bufA[MT * HA];
+    __shared__ __attribute__((aligned(16))) unsigned short bufB[MT * HB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int item = blockIdx.x, bsel = 0;
+    if (item >= args.br[0].n_items) {
+        item -= args.br[0].n_items;
+        bsel = 1;
+    }
+    const ChainBranch &br = args.br[bsel];
+    const int P = br.P, P1 = br.P1;
+    const bool short_chain = br.short_chain != 0;
+    const float *__restrict__ w0a = br.w0a;
+    const float *__restrict__ b0a = br.b0a;
+    // bf16 fragment arrays (the ChainBranch pointer fields are reused for them)
+    // buffer descriptors (wave-uniform SGPRs) + scalar offsets + 16 * lane: no 64-bit VALU address math, no address VGPRs
+    const unsigned short *w1p = reinterpret_cast<const unsigned short *>(br.w1) + (long long)item * br.w1_item_stride;
+    const __amdgpu_buffer_rsrc_t rs0b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(br.w0b), 0, 4096 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(w1p), 0, 4096 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(br.w2), 0, 8192 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(br.w3), 0, 128 * 1024 * 2, 0x00020000);
+    const int lane16 = lane * 16;
+
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (br.center) {
+        cx = br.center[item * 3 + 0];
+        cy = br.center[item * 3 + 1];
+        cz = br.center[item * 3 + 2];
+    }
+    float R[9];
+    const bool has_rot = br.rot != nullptr;
+    if (has_rot) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = br.rot[item * 9 + i];
+    }
+    float rmax[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rmax[i] = -INFINITY;
+    bool bad = false;       // non-finite input poisons the item (torch propagates NaN through conv / ReLU / max)
+
+    const int ntiles = (P + MT - 1) / MT;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        // ---- this lane's point (all 4 waves load the same 64 points; past the end: the last point again) ----
+        float x0, x1, x2;
+        {
+            int p = tile * MT + lane;
+            if (p >= P) p = P - 1;
+            if (p < P1) {
+                const float *src = br.ptsA + ((long long)item * P1 + p) * 3;
+                x0 = src[0]; x1 = src[1]; x2 = src[2];
+            } else {
+                const float *src = br.ptsB + ((long long)item * (P - P1) + (p - P1)) * 3;
+                x0 = src[0] - cx; x1 = src[1] - cy; x2 = src[2] - cz;
+            }
+        }
+        if (has_rot) {
+            const float y0 = R[0] * x0 + R[1] * x1 + R[2] * x2;
+            const float y1 = R[3] * x0 + R[4] * x1 + R[5] * x2;
+            const float y2 = R[6] * x0 + R[7] * x1 + R[8] * x2;
+            x0 = y0; x1 = y1; x2 = y2;
+        }
+        bad = bad || !(fabsf(x0) <= 3.0e38f) || !(fabsf(x1) <= 3.0e38f) || !(fabsf(x2) <= 3.0e38f);
+        // ---- first layer (K = 3, fp32 VALU): wave w -> channels [16w, 16w+16) of bufA ----
+        {
+            unsigned short *dst = bufA + lane * HA + 16 * wave;
+#pragma unroll
+            for (int c = 0; c < 16; c += 2) {
+                float s[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int o = 16 * wave + c + u;     // wave-uniform -> scalar loads
+                    float v = b0a[o];
+                    v = fmaf(w0a[o], x0, v);
+                    v = fmaf(w0a[64 + o], x1, v);
+                    v = fmaf(w0a[128 + o], x2, v);
+                    s[u] = fmaxf(v, 0.0f);
+                }
+                *reinterpret_cast<unsigned *>(dst + c) = (unsigned)f2bf(s[0]) | ((unsigned)f2bf(s[1]) << 16);
+            }
+        }
+        __syncthreads();          // bufA ready; every wave is past its conv3 reads of bufB (previous tile)
+
+        if (!short_chain) {
+            // ---- conv0b: bufA -> bufB[:, 0:64]; wave = (row block, column tile) ----
+            {
+                const int rt = wave >> 1, nt = wave & 1;
+                f32x16 acc = {};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) acc = mfma_bf16(lds_a(bufA, HA, 32 * rt, kb, lane), bufld(rs0b, lane16, (nt * 4 + kb) * 1024), acc);
+                store_tile(acc, bufB, HB, 32 * rt, 32 * nt, br.b0b, lane);
+            }
+            __syncthreads();
+            // ---- conv1 (STN pass: shared weights; main pass: this item's W1' = W1 . trans2): bufB -> bufA ----
+            {
+                const int rt = wave >> 1, nt = wave & 1;
+                f32x16 acc = {};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) acc = mfma_bf16(lds_a(bufB, HB, 32 * rt, kb, lane), bufld(rs1, lane16, (nt * 4 + kb) * 1024), acc);
+                store_tile(acc, bufA, HA, 32 * rt, 32 * nt, br.b1, lane);
+            }
+            __syncthreads();
+        }
+        // ---- conv2 (64 -> 128): bufA -> bufB; wave = column tile, both row blocks ----
+        {
+            f32x16 acc0 = {}, acc1 = {};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const u32x4 b = bufld(rs2, lane16, (wave * 4 + kb) * 1024);
+                acc0 = mfma_bf16(lds_a(bufA, HA, 0, kb, lane), b, acc0);
+                acc1 = mfma_bf16(lds_a(bufA, HA, 32, kb, lane), b, acc1);
+            }
+            store_tile(acc0, bufB, HB, 0, 32 * wave, br.b2, lane);
+            store_tile(acc1, bufB, HB, 32, 32 * wave, br.b2, lane);
+        }
+        __syncthreads();
+        // ---- conv3 (128 -> 1024) + max over the 64 points: wave w owns column tiles [8w, 8w+8) ----
+        {
+            u32x4 a0[8], a1[8];
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                a0[kb] = lds_a(bufB, HB, 0, kb, lane);
+                a1[kb] = lds_a(bufB, HB, 32, kb, lane);
+            }
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+                const int soff = (wave * 8 + ct) * 8 * 1024;        // bytes: 8 k-blocks of 64 lanes x 16 B per column tile
+                f32x16 acc0 = {}, acc1 = {};
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) {
+                    const u32x4 b = bufld(rs3, lane16, soff + kb * 1024);
+                    acc0 = mfma_bf16(a0[kb], b, acc0);
+                    acc1 = mfma_bf16(a1[kb], b, acc1);
+                }
+                float m = fmaxf(acc0[0], acc1[0]);
+#pragma unroll
+                for (int i = 1; i < 16; ++i) m = fmaxf(m, fmaxf(acc0[i], acc1[i]));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                rmax[ct] = fmaxf(rmax[ct], m);
+                // keep the weight loads of the next column tile below this point: hoisting all 64 of them spills
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // (the next tile's first layer writes bufA, last read before the barrier above)
+    }
+    // ---- pooled output: bias (and ReLU for the STN trunks) commute with the max ----
+    if (lane < 32) {
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            const int c = (wave * 8 + ct) * 32 + lane;
+            float v = rmax[ct] + br.b3[c];
+            if (br.relu_out) v = fmaxf(v, 0.0f);
+            if (bad) v = __int_as_float(0x7fc00000);
+            br.out[(long long)item * 1024 + c] = v;
+        }
+    }
+}
+
+// fp32 packed B fragments ([N/32][K/8][2][32][4]: k = 8 kg + 4 kk + t, n = 32 nt + j) -> bf16 fragments
+// ([N/32][K/16][64 lanes][8]: k = 16 kb + 8 (lane >> 5) + t, n = 32 nt + (lane & 31)); one thread per output element
+__global__ void p2s_pack_bf16_kernel(const float *__restrict__ src, unsigned short *__restrict__ dst, int K, int N,
+                                     long long src_stride, long long dst_stride, int n_items) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)K * N;
+    if (e >= per * n_items) return;
+    const int item = (int)(e / per);
+    int r = (int)(e % per);
+    const int t = r & 7;
+    r >>= 3;
+    const int lane = r & 63;
+    r >>= 6;
+    const int KB = K / 16;
+    const int kb = r % KB, nt = r / KB;
+    const int k = 16 * kb + 8 * (lane >> 5) + t, j = lane & 31;
+    const int kg = k >> 3, kk = (k >> 2) & 1, ts = k & 3;
+    const long long si = ((((long long)nt * (K / 8) + kg) * 2 + kk) * 32 + j) * 4 + ts;
+    dst[(long long)item * dst_stride + (e % per)] = f2bf(src[(long long)item * src_stride + si]);
+}
+
+}  // namespace
+
+int p2s_launch_chain_bf16(const ChainArgs &args, hipStream_t stream) {
+    const int n = args.br[0].n_items + args.br[1].n_items;
+    if (n <= 0) return P2S_OK;
+    hipLaunchKernelGGL(p2s_chain_bf16_kernel, dim3(n), dim3(256), 0, stream, args);
+    P2S_LAUNCH_CHECK("p2s_chain_bf16_kernel");
+    return P2S_OK;
+}
+
+int p2s_launch_pack_bf16(const float *src, unsigned short *dst, int K, int N, long long src_stride, long long dst_stride,
+                         int n_items, hipStream_t stream) {
+    const long long total = (long long)K * N * n_items;
+    if (total <= 0) return P2S_OK;
+    hipLaunchKernelGGL(p2s_pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, K, N,
+                       src_stride, dst_stride, n_items);
+    P2S_LAUNCH_CHECK("p2s_pack_bf16_kernel");
+    return P2S_OK;
+}

@@ -9,6 +9,9 @@ struct p2s_model_s {
     int device = 0;
     float *blob = nullptr;
     size_t n_floats = 0;
+    // bf16 encoder (cfg.encoder_bf16): bf16 B fragments of the per-point layers, converted once at creation
+    unsigned short *blob_h = nullptr;
+    size_t h_w0b[2] = {}, h_s1[2] = {}, h_s2[2] = {}, h_s3[2] = {}, h_m2[2] = {}, h_m3[2] = {}, h_qc2 = 0, h_qc3 = 0;
     float *ws = nullptr;      // per-chunk workspace, grown on demand
     int ws_chunk = 0;
     int max_chunk = 4096;     // queries per internal batch

@@ -108,7 +108,9 @@ def _engine_cfg(train_opt, pred_dim):
         use_point_stn=bool(train_opt.use_point_stn), use_feat_stn=bool(train_opt.use_feat_stn),
         sym_op=train_opt.sym_op, single_transformer=bool(train_opt.single_transformer),
         shared_transformer=bool(train_opt.shared_transformer),
-        uniform_subsample=bool(getattr(train_opt, 'uniform_subsample', 0)))
+        uniform_subsample=bool(getattr(train_opt, 'uniform_subsample', 0)),
+        # opt-in reduced precision (BASELINE configs[3]): per-point encoder layers on bf16 MFMA, everything else fp32
+        encoder_bf16=os.environ.get('P2S_ENCODER', 'fp32') == 'bf16')
 
 
 def _load_points(indir, shape_name):

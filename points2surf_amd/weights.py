@@ -42,7 +42,8 @@ class ModelCfg(ctypes.Structure):
     _fields_ = [('net_size', ctypes.c_int32), ('points_per_patch', ctypes.c_int32),
                 ('sub_sample_size', ctypes.c_int32), ('output_dim', ctypes.c_int32),
                 ('use_point_stn', ctypes.c_int32), ('shared_transformer', ctypes.c_int32),
-                ('weighted_subsample', ctypes.c_int32), ('reserved', ctypes.c_int32 * 9)]
+                ('weighted_subsample', ctypes.c_int32), ('encoder_bf16', ctypes.c_int32),
+                ('reserved', ctypes.c_int32 * 8)]
 
 
 def _np(v):
@@ -176,6 +177,7 @@ def build_blob(state_dict, cfg):
     mc.use_point_stn = int(use_point_stn)
     mc.shared_transformer = int(shared)
     mc.weighted_subsample = int(not bool(cfg.get('uniform_subsample', False)))
+    mc.encoder_bf16 = int(bool(cfg.get('encoder_bf16', False)))
     if mc.output_dim != 2:
         raise ValueError('engine supports outputs imp_surf_magnitude + imp_surf_sign (pred_dim 2)')
     return blob.finish(), offs, mc

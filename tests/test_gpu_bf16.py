@@ -1,0 +1,85 @@
+"""bf16 encoder mode (BASELINE.json configs[3]: "bf16 encoder + fp32 decoder"; cfg encoder_bf16=1): the kernel against
+an executable model of its arithmetic, and its deviation from the exact fp32 path on the reference fixture."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch
+
+
+def _models(name):
+    from points2surf_amd import engine, synth
+    w, cfg = synth.make_weights(name)
+    cfg16 = dict(cfg)
+    cfg16['encoder_bf16'] = True
+    return w, cfg, engine.Model(w, cfg), engine.Model(w, cfg16)
+
+
+def test_bf16_encoder_matches_its_arithmetic_model(fixture_cloud, torch_cuda):
+    from oracle import p2s_oracle as O
+    from tests import bf16_model as bm
+    w, cfg, m32, m16 = _models('p2s_max')
+    rng = np.random.default_rng(2)
+    B = 24
+    q = (fixture_cloud[rng.integers(0, fixture_cloud.shape[0], B)] + rng.normal(0, 0.01, (B, 3))).astype(np.float32)
+    ids = O.knn_ids(fixture_cloud, q, 300)
+    _, ps = O.patch_radius_and_ps(fixture_cloud, ids, q)
+    sub = fixture_cloud[rng.integers(0, fixture_cloud.shape[0], (B, 1000))]
+    t = lambda a: torch_cuda.from_numpy(np.ascontiguousarray(a)).cuda()
+    fl, fg = m16.features(t(ps), t(sub), t(q))
+    w32 = {k: np.asarray(v, dtype=np.float32) for k, v in w.items()}
+    ref_l = bm.encoder_features(w32, 'feat_local', ps.astype(np.float32))
+    ref_g = bm.encoder_features(w32, 'feat_global', (sub - q[:, None, :]).astype(np.float32))
+    el = np.abs(fl.cpu().numpy() - ref_l).max() / np.abs(ref_l).max()
+    eg = np.abs(fg.cpu().numpy() - ref_g).max() / np.abs(ref_g).max()
+    f32l, f32g = m32.features(t(ps), t(sub), t(q))
+    dl = np.abs(fl.cpu().numpy() - f32l.cpu().numpy()).max() / np.abs(ref_l).max()
+    dg = np.abs(fg.cpu().numpy() - f32g.cpu().numpy()).max() / np.abs(ref_g).max()
+    print('bf16 kernel vs its model: rel err local %.3g global %.3g ; bf16 vs fp32 features: %.3g %.3g' % (el, eg, dl, dg))
+    # the model differs from the kernel only by fp32 summation order (which can flip single bf16 roundings)
+    assert el < 4e-3 and eg < 4e-3
+    assert dl < 0.1 and dg < 0.1
+
+
+@pytest.mark.parametrize('name', ['p2s_max', 'p2s_vanilla'])
+def test_bf16_deviation_from_fp32_on_reference_fixture(name, fixture_cloud, golden_dir, torch_cuda):
+    """whole shape (2976 queries, grid 32) against the unmodified reference's SDF: the deviation of the two logits is
+    bounded; the sign (hence the SDF, = magnitude * sign) can only flip where the reference's sign logit is itself
+    within that deviation of zero"""
+    from points2surf_amd import engine
+    w, cfg, m32, m16 = _models(name)
+    with open(os.path.join(golden_dir, 'meta.json')) as f:
+        meta = json.load(f)
+    ref = np.load(os.path.join(golden_dir, 'ref_%s_grid32.npz' % name))['sdf_full']
+    cloud = engine.Cloud(fixture_cloud)
+    q = cloud.query_grid(32, 3)
+    _, patch, rad = cloud.knn_patch(q, 300)
+    rng = engine.Rng(meta['seed_data'])
+    if cfg.get('uniform_subsample'):
+        _, sub = rng.subsample_uniform(cloud, int(q.shape[0]), 1000)
+    else:
+        _, sub = rng.subsample_weighted(cloud, q, 1000)
+    l32, s32 = m32.forward(patch, sub, q, rad, want_logits=True, want_sdf=True)
+    l16, s16 = m16.forward(patch, sub, q, rad, want_logits=True, want_sdf=True)
+    l32, l16, s32, s16 = (t.cpu().numpy() for t in (l32, l16, s32, s16))
+    assert np.abs(s32 - ref).max() < 1e-5                      # the fp32 path is the reference
+    dl = np.abs(l16 - l32)
+    flips = np.sign(s16) != np.sign(ref)
+    dm = np.abs(np.abs(s16) - np.abs(ref))
+    print('%s bf16 encoder vs reference: max|dlogit| %.3g mean %.3g (logit range %.2f); |SDF| magnitude max dev %.3g mean '
+          '%.3g; sign flips %d / %d, largest |sign logit| among them %.3g'
+          % (name, dl.max(), dl.mean(), np.abs(l32).max(), dm.max(), dm.mean(), int(flips.sum()), ref.size,
+             np.abs(l32[flips, 1]).max() if flips.any() else 0.0))
+    assert np.isfinite(s16).all()
+    assert dl.max() < 0.25 and dl.mean() < 0.04          # measured: 0.088 / 0.014 (p2s_max), logit range 7.7
+    assert not flips.any() or np.abs(l32[flips, 1]).max() <= dl.max()
+    assert flips.mean() < 0.03
