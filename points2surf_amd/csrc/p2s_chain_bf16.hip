@@ -11,8 +11,8 @@
 // as A and B use the same one.  C / D: column l & 31, rows (i & 3) + 8 * (i >> 2) + 4 * (l >> 5), as for 32x32x2.
 //
 // conv3 (128 -> 1024) dominates: a wave keeps the A fragments of both row blocks for all 8 k-blocks in registers
-// (64 VGPRs) and streams its 8 column tiles of weights from L2 (64 KB per wave and tile) -- this variant is bound by
-// that stream, not by the MFMA pipe (16x the fp32 rate).
+// (64 VGPRs) and streams its 8 column tiles of weights from L2 (64 KB per wave and tile).  Measured ~40 % of the bf16
+// MFMA peak; 128-point tiles (-DP2S_BF16_MT=128: half the weight stream, 2 workgroups/CU) are no faster.
 #include "p2s_common.h"
 #include <cmath>
 
@@ -21,7 +21,13 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MT = 64;          // points per tile
+#ifndef P2S_BF16_MT
+#define P2S_BF16_MT 64
+#endif
+constexpr int MT = P2S_BF16_MT;  // points per tile (64 or 128: larger tiles halve the L2 weight stream of conv3)
+constexpr int NB = MT / 32;      // 32-row blocks per tile
+constexpr int PPL = MT / 64;     // points per lane in the first layer
+static_assert(MT == 64 || MT == 128, "tile of 64 or 128 points");
 constexpr int HA = 64 + 8;      // halfs per row of the 64-channel buffer (16-byte rows, bank spread)
 constexpr int HB = 128 + 8;     // halfs per row of the 128-channel buffer
 
@@ -57,7 +63,7 @@ __device__ __forceinline__ void store_tile(const f32x16 &acc, unsigned short *bu
     }
 }
 
-__global__ __launch_bounds__(256, 4) void p2s_chain_bf16_kernel(ChainArgs args) {
+__global__ __launch_bounds__(256, MT == 64 ? 4 : 2) void p2s_chain_bf16_kernel(ChainArgs args) {
     __shared__ __attribute__((aligned(16))) unsigned short bufA[MT * HA];
     __shared__ __attribute__((aligned(16))) unsigned short bufB[MT * HB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -101,32 +107,33 @@ __global__ __launch_bounds__(256, 4) void p2s_chain_bf16_kernel(ChainArgs args) 
 
     const int ntiles = (P + MT - 1) / MT;
     for (int tile = 0; tile < ntiles; ++tile) {
-        // ---- this lane's point (all 4 waves load the same 64 points; past the end: the last point again) ----
-        float x0, x1, x2;
-        {
-            int p = tile * MT + lane;
-            if (p >= P) p = P - 1;
-            if (p < P1) {
-                const float *src = br.ptsA + ((long long)item * P1 + p) * 3;
-                x0 = src[0]; x1 = src[1]; x2 = src[2];
-            } else {
-                const float *src = br.ptsB + ((long long)item * (P - P1) + (p - P1)) * 3;
-                x0 = src[0] - cx; x1 = src[1] - cy; x2 = src[2] - cz;
+        // ---- this lane's point(s) (all 4 waves load the same points; past the end: the last point again) ----
+#pragma unroll
+        for (int pp = 0; pp < PPL; ++pp) {
+            float x0, x1, x2;
+            {
+                int p = tile * MT + pp * 64 + lane;
+                if (p >= P) p = P - 1;
+                if (p < P1) {
+                    const float *src = br.ptsA + ((long long)item * P1 + p) * 3;
+                    x0 = src[0]; x1 = src[1]; x2 = src[2];
+                } else {
+                    const float *src = br.ptsB + ((long long)item * (P - P1) + (p - P1)) * 3;
+                    x0 = src[0] - cx; x1 = src[1] - cy; x2 = src[2] - cz;
+                }
             }
-        }
-        if (has_rot) {
-            const float y0 = R[0] * x0 + R[1] * x1 + R[2] * x2;
-            const float y1 = R[3] * x0 + R[4] * x1 + R[5] * x2;
-            const float y2 = R[6] * x0 + R[7] * x1 + R[8] * x2;
-            x0 = y0; x1 = y1; x2 = y2;
-        }
-        bad = bad || !(fabsf(x0) <= 3.0e38f) || !(fabsf(x1) <= 3.0e38f) || !(fabsf(x2) <= 3.0e38f);
-        // ---- first layer (K = 3, fp32 VALU): wave w -> channels [16w, 16w+16) of bufA ----
-        {
-            unsigned short *dst = bufA + lane * HA + 16 * wave;
+            if (has_rot) {
+                const float y0 = R[0] * x0 + R[1] * x1 + R[2] * x2;
+                const float y1 = R[3] * x0 + R[4] * x1 + R[5] * x2;
+                const float y2 = R[6] * x0 + R[7] * x1 + R[8] * x2;
+                x0 = y0; x1 = y1; x2 = y2;
+            }
+            bad = bad || !(fabsf(x0) <= 3.0e38f) || !(fabsf(x1) <= 3.0e38f) || !(fabsf(x2) <= 3.0e38f);
+            // ---- first layer (K = 3, fp32 VALU): wave w -> channels [16w, 16w+16) of bufA ----
+            unsigned short *dst = bufA + (pp * 64 + lane) * HA + 16 * wave;
 #pragma unroll
             for (int c = 0; c < 16; c += 2) {
-                float s[2];
+                float sv[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int o = 16 * wave + c + u;     // wave-uniform -> scalar loads
@@ -134,9 +141,9 @@ __global__ __launch_bounds__(256, 4) void p2s_chain_bf16_kernel(ChainArgs args) 
                     v = fmaf(w0a[o], x0, v);
                     v = fmaf(w0a[64 + o], x1, v);
                     v = fmaf(w0a[128 + o], x2, v);
-                    s[u] = fmaxf(v, 0.0f);
+                    sv[u] = fmaxf(v, 0.0f);
                 }
-                *reinterpret_cast<unsigned *>(dst + c) = (unsigned)f2bf(s[0]) | ((unsigned)f2bf(s[1]) << 16);
+                *reinterpret_cast<unsigned *>(dst + c) = (unsigned)f2bf(sv[0]) | ((unsigned)f2bf(sv[1]) << 16);
             }
         }
         __syncthreads();          // bufA ready; every wave is past its conv3 reads of bufB (previous tile)
@@ -144,57 +151,76 @@ __global__ __launch_bounds__(256, 4) void p2s_chain_bf16_kernel(ChainArgs args) 
         if (!short_chain) {
             // ---- conv0b: bufA -> bufB[:, 0:64]; wave = (row block, column tile) ----
             {
-                const int rt = wave >> 1, nt = wave & 1;
-                f32x16 acc = {};
+                const int rt = wave >> 1, nt = wave & 1;          // row blocks rt, rt + 2, ...; column tile nt
+                f32x16 acc[NB / 2];
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) acc = mfma_bf16(lds_a(bufA, HA, 32 * rt, kb, lane), bufld(rs0b, lane16, (nt * 4 + kb) * 1024), acc);
-                store_tile(acc, bufB, HB, 32 * rt, 32 * nt, br.b0b, lane);
+                for (int r = 0; r < NB / 2; ++r) acc[r] = f32x16{};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const u32x4 b = bufld(rs0b, lane16, (nt * 4 + kb) * 1024);
+#pragma unroll
+                    for (int r = 0; r < NB / 2; ++r) acc[r] = mfma_bf16(lds_a(bufA, HA, 32 * (rt + 2 * r), kb, lane), b, acc[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < NB / 2; ++r) store_tile(acc[r], bufB, HB, 32 * (rt + 2 * r), 32 * nt, br.b0b, lane);
             }
             __syncthreads();
             // ---- conv1 (STN pass: shared weights; main pass: this item's W1' = W1 . trans2): bufB -> bufA ----
             {
                 const int rt = wave >> 1, nt = wave & 1;
-                f32x16 acc = {};
+                f32x16 acc[NB / 2];
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) acc = mfma_bf16(lds_a(bufB, HB, 32 * rt, kb, lane), bufld(rs1, lane16, (nt * 4 + kb) * 1024), acc);
-                store_tile(acc, bufA, HA, 32 * rt, 32 * nt, br.b1, lane);
+                for (int r = 0; r < NB / 2; ++r) acc[r] = f32x16{};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const u32x4 b = bufld(rs1, lane16, (nt * 4 + kb) * 1024);
+#pragma unroll
+                    for (int r = 0; r < NB / 2; ++r) acc[r] = mfma_bf16(lds_a(bufB, HB, 32 * (rt + 2 * r), kb, lane), b, acc[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < NB / 2; ++r) store_tile(acc[r], bufA, HA, 32 * (rt + 2 * r), 32 * nt, br.b1, lane);
             }
             __syncthreads();
         }
         // ---- conv2 (64 -> 128): bufA -> bufB; wave = column tile, both row blocks ----
         {
-            f32x16 acc0 = {}, acc1 = {};
+            f32x16 acc[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) acc[r] = f32x16{};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 const u32x4 b = bufld(rs2, lane16, (wave * 4 + kb) * 1024);
-                acc0 = mfma_bf16(lds_a(bufA, HA, 0, kb, lane), b, acc0);
-                acc1 = mfma_bf16(lds_a(bufA, HA, 32, kb, lane), b, acc1);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) acc[r] = mfma_bf16(lds_a(bufA, HA, 32 * r, kb, lane), b, acc[r]);
             }
-            store_tile(acc0, bufB, HB, 0, 32 * wave, br.b2, lane);
-            store_tile(acc1, bufB, HB, 32, 32 * wave, br.b2, lane);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) store_tile(acc[r], bufB, HB, 32 * r, 32 * wave, br.b2, lane);
         }
         __syncthreads();
         // ---- conv3 (128 -> 1024) + max over the 64 points: wave w owns column tiles [8w, 8w+8) ----
         {
-            u32x4 a0[8], a1[8];
+            u32x4 af[NB][8];
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                a0[kb] = lds_a(bufB, HB, 0, kb, lane);
-                a1[kb] = lds_a(bufB, HB, 32, kb, lane);
-            }
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) af[r][kb] = lds_a(bufB, HB, 32 * r, kb, lane);
 #pragma unroll
             for (int ct = 0; ct < 8; ++ct) {
                 const int soff = (wave * 8 + ct) * 8 * 1024;        // bytes: 8 k-blocks of 64 lanes x 16 B per column tile
-                f32x16 acc0 = {}, acc1 = {};
+                f32x16 acc[NB];
+#pragma unroll
+                for (int r = 0; r < NB; ++r) acc[r] = f32x16{};
 #pragma unroll
                 for (int kb = 0; kb < 8; ++kb) {
                     const u32x4 b = bufld(rs3, lane16, soff + kb * 1024);
-                    acc0 = mfma_bf16(a0[kb], b, acc0);
-                    acc1 = mfma_bf16(a1[kb], b, acc1);
-                }
-                float m = fmaxf(acc0[0], acc1[0]);
 #pragma unroll
-                for (int i = 1; i < 16; ++i) m = fmaxf(m, fmaxf(acc0[i], acc1[i]));
+                    for (int r = 0; r < NB; ++r) acc[r] = mfma_bf16(af[r][kb], b, acc[r]);
+                }
+                float m = acc[0][0];
+#pragma unroll
+                for (int r = 0; r < NB; ++r)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[r][i]);
                 m = fmaxf(m, __shfl_xor(m, 32));
                 rmax[ct] = fmaxf(rmax[ct], m);
                 // keep the weight loads of the next column tile below this point: hoisting all 64 of them spills
