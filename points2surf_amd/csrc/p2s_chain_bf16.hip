@@ -31,10 +31,18 @@ static_assert(MT == 64 || MT == 128, "tile of 64 or 128 points");
 constexpr int HA = 64 + 8;      // halfs per row of the 64-channel buffer (16-byte rows, bank spread)
 constexpr int HB = 128 + 8;     // halfs per row of the 128-channel buffer
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ unsigned short f2bf(float f) {       // round to nearest even (finite inputs)
     unsigned u = __float_as_uint(f);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
+}
+// two values at once: one v_cvt_pk_bf16_f32 (hardware round-to-nearest-even); a in the low half
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
@@ -57,9 +65,11 @@ __device__ __forceinline__ void store_tile(const f32x16 &acc, unsigned short *bu
     const float b = bias[c];
     unsigned short *dst = buf + (row0 + 4 * (lane >> 5)) * H + c;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int r = (i & 3) + 8 * (i >> 2);
-        dst[r * H] = f2bf(fmaxf(acc[i] + b, 0.0f));
+    for (int i = 0; i < 16; i += 2) {
+        const int r = (i & 3) + 8 * (i >> 2);             // rows r and r + 1
+        const unsigned u = pack_bf16(fmaxf(acc[i] + b, 0.0f), fmaxf(acc[i + 1] + b, 0.0f));
+        dst[r * H] = (unsigned short)u;
+        dst[(r + 1) * H] = (unsigned short)(u >> 16);
     }
 }
 
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(256, MT == 64 ? 4 : 2) void p2s_chain_bf16_kernel(C
                     v = fmaf(w0a[128 + o], x2, v);
                     sv[u] = fmaxf(v, 0.0f);
                 }
-                *reinterpret_cast<unsigned *>(dst + c) = (unsigned)f2bf(sv[0]) | ((unsigned)f2bf(sv[1]) << 16);
+                *reinterpret_cast<unsigned *>(dst + c) = pack_bf16(sv[0], sv[1]);
             }
         }
         __syncthreads();          // bufA ready; every wave is past its conv3 reads of bufB (previous tile)
