@@ -102,3 +102,26 @@ def test_model_cfg_carries_the_sub_sample_mode():
         _, _, mc = weights.build_blob(w, cfg)
         assert mc.weighted_subsample == weighted
         assert mc.use_point_stn == weighted
+
+
+def test_bf16_fragment_repacking_index_math():
+    """mirror of p2s_pack_bf16_kernel (p2s_chain_bf16.hip): fp32 B fragments [N/32][K/8][2][32][4] -> bf16 fragments
+    [N/32][K/16][64 lanes][8] with k = 16 kb + 8 (lane >> 5) + t, n = 32 nt + (lane & 31)"""
+    from points2surf_amd import weights
+    rng = np.random.default_rng(3)
+    for K, N in ((64, 64), (64, 128), (128, 1024)):
+        W = rng.standard_normal((K, N)).astype(np.float32)
+        src = weights.pack_b(W)
+        e = np.arange(K * N)
+        t = e & 7
+        lane = (e >> 3) & 63
+        r = e >> 9
+        kb, nt = r % (K // 16), r // (K // 16)
+        k = 16 * kb + 8 * (lane >> 5) + t
+        j = lane & 31
+        kg, kk, ts = k >> 3, (k >> 2) & 1, k & 3
+        si = (((nt * (K // 8) + kg) * 2 + kk) * 32 + j) * 4 + ts
+        dst = src[si]                                             # what the kernel writes (before rounding)
+        assert np.array_equal(dst, W[k, 32 * nt + j])
+        # every (k, n) exactly once
+        assert np.unique(k * N + 32 * nt + j).size == K * N
