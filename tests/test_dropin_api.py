@@ -126,3 +126,26 @@ def test_sdf_bridge_reexports_reference_and_overrides_two_functions():
         for k in [k for k in sys.modules if k == 'source' or k.startswith('source.')]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_query_range_parts_are_assembled_once_and_in_order(dropin_source, tmp_path):
+    """P2S_SHARD=queries: each rank leaves its ordered piece; whoever completes the set writes the reference's output
+    files exactly once (lock), pieces concatenated in rank order, part files removed"""
+    import numpy as np
+    ev, _ = dropin_source
+    out = str(tmp_path / 'rec')
+    world = 3
+    rng = np.random.default_rng(0)
+    pieces = [(rng.standard_normal(n).astype(np.float32), rng.standard_normal((n, 3)).astype(np.float32)) for n in (5, 0, 7)]
+    for rank in (2, 0):                                   # out of order, one rank still missing
+        ev._write_part(out, 'shapeA', rank, *pieces[rank])
+        assert ev._assemble_if_complete(out, 'shapeA', world) is False
+    ev._write_part(out, 'shapeA', 1, *pieces[1])
+    assert ev._assemble_if_complete(out, 'shapeA', world) is True
+    assert ev._assemble_if_complete(out, 'shapeA', world) is False          # parts gone, lock taken
+    sdf = np.load(os.path.join(out, 'dist_ms', 'shapeA.xyz.npy'))
+    q = np.load(os.path.join(out, 'query_pts_ms', 'shapeA.xyz.npy'))
+    assert np.array_equal(sdf, np.concatenate([p[0] for p in pieces]))
+    assert np.array_equal(q, np.concatenate([p[1] for p in pieces]))
+    assert np.array_equal(np.load(os.path.join(out, 'eval', 'shapeA.xyz.npy')), sdf)
+    assert not [f for f in os.listdir(os.path.join(out, '.parts')) if f.endswith('.npz')]
