@@ -61,3 +61,12 @@ def test_no_device_is_a_loud_error(lib):
     rc = lib.p2s_model_create(ctypes.byref(mc), blob.ctypes.data_as(ctypes.c_void_p), blob.size, ctypes.byref(offs), 0,
                               ctypes.byref(h))
     assert rc == -5 and b'device' in lib.p2s_last_error()
+
+
+def test_integration_stub_uses_only_declared_entry_points():
+    """the reference-side ctypes stub in INTEGRATION.md binds symbols that include/p2s_hip.h declares"""
+    text = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    used = set(re.findall(r'\b(p2s_[a-z0-9_]+)\b', text))
+    declared = set(_declared_symbols()) | {'p2s_hip', 'p2s_model_cfg', 'p2s_mi355x', 'p2s_max', 'p2s_vanilla'}   # + non-symbols
+    unknown = {u for u in used if u not in declared and not u.endswith('_t')}
+    assert not unknown, unknown
