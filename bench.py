@@ -1,24 +1,35 @@
 #!/usr/bin/env python
 """Headline benchmark: SDF queries/s per GPU, p2s_max, 256^3 query grid (BASELINE.json metric).
 
-A *step* = one complete shape: near-surface query grid of a 256^3 volume -> for every query the
+A *step* = one complete shape per rank: near-surface query grid of a 256^3 volume -> for every query the
 300-NN patch (fp64-exact), the 1000-point global sub-sample (numpy-legacy MT19937 stream), the
-PointNet encoders + decoder -> SDF.  The cloud is resident in HBM when the timed region starts
-(config 3 of BASELINE.json with a synthetic stand-in cloud: the Famous set cannot be downloaded).
+PointNet encoders + decoder -> SDF.  The workload is the committed ``abc_minimal`` test shape
+(tests/golden/abc_minimal/04_pts/00994122..., 34,693 points, Q = 307,237 queries at 256^3, eps 3) -- the input the
+parity tests pin against the unmodified reference -- with seeded random-init weights (no pretrained weights offline).
+The cloud is resident in HBM when the timed region starts.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--rng-mode dataset|per_shape]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU; shapes shard across ranks (every rank processes its own shape per
-step -> weak scaling, no data-path collective); the per-shape SDF arrays are gathered to rank 0
-over RCCL at the end of the timed region (the path's only exchange step).  Rank 0 prints ONE JSON
-line.  ``roofline`` is for the dominant kernel (p2s_chain_kernel, MFMA-bound) from HIP events
-recorded on the launch stream during the timed steps; ``cpu_baseline`` times the torch-CPU port of
-the reference's path (oracle/torch_port.py) on this box's host cores on a bounded sample.
+N > 1: one process per GPU (``--gpus N`` without a torchrun environment re-executes itself under
+``torch.distributed.run`` with N ranks; fewer than N visible devices is an error, never a silent 1-GPU run).  The
+dataset is ``N x (W + K)`` copies of the shape in one list; shape i belongs to rank i mod N (weak scaling).
+  --rng-mode dataset (default, exact): ONE sub-sample stream over the whole dataset, as the reference's
+      ``--workers 0`` run: every rank also consumes the draws of the shapes it does not own
+      (sharding.skip_shape_stream), so every shape's SDF is bit-identical to the single-process run.
+  --rng-mode per_shape: shape i is seeded with seed + i (no cross-shape dependency; a declared deviation from the
+      reference from the second shape on).
+The per-shape SDF arrays are gathered to rank 0 over RCCL at the end of every step (sharding.gather_variable, the
+path's only exchange).  Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (p2s_chain_kernel,
+MFMA-bound) from HIP events recorded on the launch stream during the timed steps; ``cpu_baseline`` times the
+torch-CPU port of the reference's path (oracle/torch_port.py) on this box's host cores on a bounded sample;
+``self_check`` (after the timed region, rank 0) compares a fresh device run of the same shape with that port's
+output and with the full-grid golden written by the unmodified reference.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,6 +46,9 @@ BYTES_PER_QUERY = 15620             # minimal HBM traffic per query, SURVEY.md 8
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md
 GRID_RES, EPSILON = 256, 3
 SEED_DATA = 40938661
+FIXTURE_SHAPE = '00994122_57d9d4755722f9d2d7436f0a_trimesh_000'
+FIXTURE_CLOUD = os.path.join(REPO, 'tests', 'golden', 'abc_minimal', '04_pts', FIXTURE_SHAPE + '.xyz.npy')
+GOLDEN_256 = os.path.join(REPO, 'tests', 'golden', 'ref_rec_p2s_max_testset_grid256.npz')
 
 
 def parse():
@@ -42,19 +56,24 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--points', type=int, default=50000, help='points of the synthetic cloud')
+    ap.add_argument('--points', type=int, default=0,
+                    help='0 (default): the abc_minimal fixture cloud; > 0: synthetic cloud of that many points')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='target CPU-baseline duration (0 = skip)')
     ap.add_argument('--chunk', type=int, default=0)
+    ap.add_argument('--rng-mode', choices=['dataset', 'per_shape'], default='dataset')
     ap.add_argument('--bf16', action='store_true',
                     help='secondary mode (BASELINE configs[3]): bf16 encoder + fp32 decoder; NOT the headline metric')
     ap.add_argument('--res', type=int, default=GRID_RES,
                     help='query-grid resolution; the headline metric is quoted at 256 (other values: BASELINE configs 1/4)')
+    ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
     return ap.parse_args()
 
 
 def cpu_baseline(w, cfg, cloud, queries, target_seconds, grid_res=GRID_RES):
+    """the torch-CPU port on the first n queries of the same workload; returns (record, sdf[:n])"""
     import torch
     from oracle.torch_port import TorchPort
+    torch.set_num_threads(os.cpu_count())
     port = TorchPort(w, cfg)
     threads = torch.get_num_threads()
     rng = np.random.RandomState(SEED_DATA)
@@ -66,40 +85,65 @@ def cpu_baseline(w, cfg, cloud, queries, target_seconds, grid_res=GRID_RES):
     n = int(min(max(target_seconds / max(dt0 / n0, 1e-6), n0), 4096, queries.shape[0]))
     rng = np.random.RandomState(SEED_DATA)
     t0 = time.time()
-    port.infer_queries(cloud, queries[:n], rng, batch=500)
+    sdf = port.infer_queries(cloud, queries[:n], rng, batch=500)
     dt = time.time() - t0
-    return {'value': n / dt, 'unit': 'queries/s', 'cores': int(threads), 'kind': 'port',
-            'sample': 'first %d of the same %d^3-grid queries (kNN cKDTree + RandomState sub-sample + torch-CPU '
-                      'forward, batch 500), %.1f s' % (n, grid_res, dt),
-            'host_cpus': os.cpu_count()}
+    rec = {'value': n / dt, 'unit': 'queries/s', 'cores': int(threads), 'kind': 'port',
+           'sample': 'first %d of the same %d^3-grid queries (kNN cKDTree + RandomState sub-sample + torch-CPU '
+                     'forward, batch 500), %.1f s' % (n, grid_res, dt),
+           'host_cpus': os.cpu_count(), 'torch': torch.__version__,
+           'torch_threads': int(threads), 'blas': 'mkl' if torch.backends.mkl.is_available() else 'other'}
+    return rec, sdf
+
+
+def respawn(args):
+    """``python bench.py --gpus N`` without a torchrun environment: N ranks on this node, or a loud error"""
+    import socket
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and (args.backend or 'nccl') == 'nccl':
+        raise SystemExit('bench.py --gpus %d: %d ranks requested but %d device(s) visible -- refusing to report a '
+                         '%d-GPU number from fewer GPUs' % (args.gpus, args.gpus, have, args.gpus))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        respawn(args)
     import torch
     import torch.distributed as dist
-    from points2surf_amd import engine, synth
+    from points2surf_amd import engine, synth, sharding
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world and world > 1:
+    world, rank, local_rank = sharding.dist_env()
+    if args.gpus != world:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the HIP engine has no CPU fallback')
+    if world > torch.cuda.device_count():
+        raise SystemExit('bench.py: %d ranks, %d device(s)' % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        sharding.init_process_group(args.backend)
 
     w, cfg = synth.make_weights('p2s_max')
     if args.bf16:
         cfg = dict(cfg, encoder_bf16=True)
     model = engine.Model(w, cfg)
     model.set_profiling(True)
-    # every rank owns its own shapes (seeded by rank): shape-level sharding
-    pts = synth.make_cloud(args.points, seed=1000 + rank)
+    if args.points > 0:
+        pts = synth.make_cloud(args.points, seed=1000)
+        workload = 'synthetic %d-point cloud' % args.points
+    else:
+        pts = np.ascontiguousarray(np.load(FIXTURE_CLOUD)[:, :3], dtype=np.float32)
+        workload = 'abc_minimal test shape %s (%d points; tests/golden/abc_minimal)' % (FIXTURE_SHAPE, pts.shape[0])
     cloud = engine.Cloud(pts)
+    n_sub = model.sub_sample_size
     rng = engine.Rng(SEED_DATA)
 
     def barrier():
@@ -108,27 +152,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # dataset = world x (warmup + steps) copies of the shape; shape i -> rank i mod world
+    def run_step(step):
+        """all shapes of dataset round ``step``: mine is inferred, the others' draws are skipped (exact mode)"""
+        out = None
+        for r in range(world):
+            shape_ind = step * world + r
+            if args.rng_mode == 'per_shape':
+                if r != rank:
+                    continue
+                key = np.random.RandomState((SEED_DATA + shape_ind) & 0xffffffff).get_state()[1]   # init_genrand
+                rng.set_state(key, 624)
+            if r == rank:
+                out, _ = engine.infer_shape(model, cloud, rng, args.res, EPSILON, chunk=args.chunk, want_queries=False)
+            else:
+                sharding.skip_shape_stream(cloud, rng, cfg, args.res, EPSILON, n_sub)
+        return out
+
     sdf = None
-    for _ in range(args.warmup):
-        sdf, _ = engine.infer_shape(model, cloud, rng, args.res, EPSILON, chunk=args.chunk, want_queries=False)
+    for s in range(args.warmup):
+        sdf = run_step(s)
     barrier()
     t0 = time.time()
     n_queries = 0
     acc = {}
-    for _ in range(args.steps):
-        sdf, _ = engine.infer_shape(model, cloud, rng, args.res, EPSILON, chunk=args.chunk, want_queries=False)
+    gathered = 0
+    for s in range(args.steps):
+        sdf = run_step(args.warmup + s)
         n_queries += int(sdf.shape[0])
         for k, v in model.counters().items():
             acc[k] = acc.get(k, 0) + v
         if world > 1:
-            # final gather of the variable-length per-shape SDF to rank 0 (RCCL over xGMI)
-            sizes = [torch.zeros(1, dtype=torch.int64, device='cuda') for _ in range(world)]
-            dist.all_gather(sizes, torch.tensor([sdf.shape[0]], dtype=torch.int64, device='cuda'))
-            cap = int(max(int(s.item()) for s in sizes))
-            padded = torch.zeros(cap, dtype=torch.float32, device='cuda')
-            padded[:sdf.shape[0]] = sdf
-            bufs = [torch.empty(cap, dtype=torch.float32, device='cuda') for _ in range(world)] if rank == 0 else None
-            dist.gather(padded, bufs, dst=0)
+            # final gather of the variable-length per-shape SDF to rank 0 (RCCL over xGMI): the only exchange
+            parts = sharding.gather_variable(sdf, dst=0)
+            if rank == 0:
+                gathered += sum(int(p.shape[0]) for p in parts)
     barrier()
     dt = time.time() - t0
 
@@ -139,6 +197,8 @@ def main():
         nq = torch.tensor([n_queries], dtype=torch.int64, device='cuda')
         dist.all_reduce(nq, op=dist.ReduceOp.SUM)
         total_queries = int(nq.item())
+        if rank == 0 and gathered != total_queries:
+            raise SystemExit('gather returned %d SDF values, ranks produced %d' % (gathered, total_queries))
     else:
         total_queries = n_queries
 
@@ -153,15 +213,17 @@ def main():
         # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
         # committed under profiles/; they cannot be collected from inside this process
         traffic, traffic_src = None, None
-        try:
-            with open(os.path.join(REPO, 'profiles', 'r01', 'pmc_summary.json')) as f:
-                ck = json.load(f)['chain_kernel']
-            traffic = ck['hbm_traffic_bytes_per_launch'] * (2.0 * n_queries / launches) / ck['queries_per_launch']
-            if args.bf16:
-                traffic, traffic_src = None, None        # counters were collected for the fp32 kernel only
-            traffic_src = 'profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, scaled to this launch size)'
-        except Exception:
-            pass
+        if not args.bf16:
+            for rnd in ('r02', 'r01'):
+                try:
+                    with open(os.path.join(REPO, 'profiles', rnd, 'pmc_summary.json')) as f:
+                        ck = json.load(f)['chain_kernel']
+                    traffic = ck['hbm_traffic_bytes_per_launch'] * (2.0 * n_queries / launches) / ck['queries_per_launch']
+                    traffic_src = ('profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, scaled '
+                                   'to this launch size)' % rnd)
+                    break
+                except Exception:
+                    continue
         out = {
             'metric': 'SDF queries/sec/GPU (p2s_max, %d^3 grid%s)' % (args.res, ', bf16 encoder' if args.bf16 else ''),
             'value': value, 'unit': 'queries/s',
@@ -169,9 +231,10 @@ def main():
             'ms_per_step': dt / max(args.steps, 1) * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16' if args.bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[2]: p2s_max, grid_res=%d, eps=3, kNN patch=300 / global ' % args.res +
-                                   'sub=1000, fp32; synthetic %d-point cloud per rank (Famous set not available '
-                                   'offline), seeded random-init weights' % args.points,
+                                   'sub=1000, fp32; %s, one shape per rank per step; seeded random-init weights '
+                                   '(Famous set / pretrained weights not available offline)' % workload,
                        'queries_per_shape_rank0': int(sdf.shape[0]), 'parallelism': 'shape-sharded x%d' % world,
+                       'rng_mode': args.rng_mode,
                        'shapes_per_hour': world * args.steps / dt * 3600.0,
                        'queries_per_s_per_gpu': value / world},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
@@ -181,11 +244,37 @@ def main():
                          'hbm_algorithmic_GBps': value / world * BYTES_PER_QUERY / 1e9},
             'stage_ms_rank0': {k: acc[k] for k in sorted(acc) if k.startswith('ms_')},
         }
+        # ---- after the timed region: the output of this very workload against the checkers --------------------
+        check = {}
+        rng_chk = engine.Rng(SEED_DATA)
+        sdf_chk, _ = engine.infer_shape(model, cloud, rng_chk, args.res, EPSILON, chunk=args.chunk, want_queries=False)
+        sdf_chk = sdf_chk.cpu().numpy()
+        tol = 0.25 if args.bf16 else 1e-4      # north_star: SDF within 1e-4 fp32 of the reference (bf16 mode: reported only)
+        if args.points == 0 and args.res == GRID_RES and os.path.isfile(GOLDEN_256):
+            ref = np.load(GOLDEN_256)['rec_0']
+            ok = ref.shape == sdf_chk.shape
+            check['vs_reference_golden'] = {
+                'file': os.path.relpath(GOLDEN_256, REPO), 'queries': int(ref.shape[0]),
+                'max_abs_dsdf': float(np.abs(ref - sdf_chk).max()) if ok else None,
+                'sign_flips': int((np.sign(ref) != np.sign(sdf_chk)).sum()) if ok else None}
+            if not ok or check['vs_reference_golden']['max_abs_dsdf'] > tol or \
+                    (not args.bf16 and check['vs_reference_golden']['sign_flips'] != 0):
+                out['self_check'] = check
+                print(json.dumps(out), flush=True)
+                raise SystemExit('bench.py self-check FAILED against the reference golden: %s' % check)
         if args.cpu_seconds > 0 and world == 1:
             q = cloud.query_grid(args.res, EPSILON).cpu().numpy()
-            out['cpu_baseline'] = cpu_baseline(w, cfg, pts, q, args.cpu_seconds, args.res)
+            out['cpu_baseline'], sdf_cpu = cpu_baseline(w, cfg, pts, q, args.cpu_seconds, args.res)
+            n = sdf_cpu.shape[0]
+            check['vs_cpu_port'] = {'queries': int(n), 'max_abs_dsdf': float(np.abs(sdf_cpu - sdf_chk[:n]).max()),
+                                    'sign_flips': int((np.sign(sdf_cpu) != np.sign(sdf_chk[:n])).sum())}
+            if check['vs_cpu_port']['max_abs_dsdf'] > tol or (not args.bf16 and check['vs_cpu_port']['sign_flips']):
+                out['self_check'] = check
+                print(json.dumps(out), flush=True)
+                raise SystemExit('bench.py self-check FAILED against the CPU port: %s' % check)
         elif world == 1:
             out['cpu_baseline'] = None
+        out['self_check'] = check
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define P2S_ABI_VERSION 1
+#define P2S_ABI_VERSION 2
 
 #define P2S_OK            0
 #define P2S_EINVAL       -1   /* bad argument / unsupported configuration */
@@ -192,6 +192,29 @@ int p2s_gather_points(p2s_cloud_t c, const int32_t *ids_dev, int64_t n_ids, floa
 int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int grid_resolution, int epsilon,
                     int64_t q_begin, int64_t q_end, int chunk, float *sdf_out_dev, float *q_out_dev,
                     int64_t *n_done, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GT-query evaluation pass: the batch loop of points_to_surf_eval with reconstruction=False, the pass
+ * full_eval.py:31-33 runs first when <indir>/05_query_dist exists (reference source/data_loader.py:365-393).
+ * Query points are given (05_query_pts/<shape>.ply.npy), and every query draws a random rotation
+ *     rand_rot = trimesh.transformations.random_rotation_matrix(self.rng.rand(3))     (data_loader.py:384)
+ * from the dataset's FIRST RandomState (self.rng, :272; the sub-sample uses the second one, :277), applied in
+ * float64 to the sub-sample (model space), the patch (patch space) and the query point, each cast back to float32
+ * (:385-393).  r_rot = NULL: no rotation (plain inference at given query points).  sdf_out_dev [n_queries].
+ * Synchronises `stream`.
+ * ------------------------------------------------------------------------------------------ */
+int p2s_infer_queries(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r_sub, p2s_rng_t r_rot, const float *q_dev,
+                      int64_t n_queries, int chunk, float *sdf_out_dev, void *stream);
+/* the two building blocks, for stage-wise parity tests:
+ *   n rotations from the stream of r (6 raw words each): rot_out_dev [n][9] float64 row-major upper-left 3x3 of
+ *   random_rotation_matrix(r.rand(3)); needs the jump tables */
+int p2s_random_rotations(p2s_rng_t r, int64_t n, double *rot_out_dev, void *stream);
+/*   trimesh.transformations.transform_points(pts, M).astype(float32) per item: pts_in_dev / pts_out_dev
+ *   [n_items][points_per_item][3] (may alias), rot_dev [n_items][9] float64 */
+int p2s_rotate_points(const double *rot_dev, const float *pts_in_dev, int points_per_item, int64_t n_items,
+                      float *pts_out_dev, void *stream);
+/* test hook: the next pipeline call on this model fails with P2S_EHIP before chunk `chunk_index` (-1 = off) */
+int p2s_debug_fault_chunk(p2s_model_t m, int chunk_index);
 
 /* ------------------------------------------------------------------------------------------
  * "next" row: the consumer of the SDF samples.  add_samples_to_volume + propagate_sign

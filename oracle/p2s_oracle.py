@@ -460,6 +460,44 @@ def infer_shape(w, cfg, pts, grid_resolution, epsilon, rng, points_per_patch=300
     return q, sdf
 
 
+def infer_queries(w, cfg, pts, queries, rng_sub, rng_rot=None, points_per_patch=300, sub_sample_size=1000, chunk=32,
+                  return_all=False):
+    """The GT-query evaluation pass for one shape (reference source/data_loader.py:322-421 with
+    reconstruction=False, driven by source/points_to_surf_eval.py:358-404): query points are given
+    (05_query_pts), and every query is augmented with a random rotation
+        rand_rot = trimesh.transformations.random_rotation_matrix(self.rng.rand(3))        (:384)
+    applied in float64 to the sub-sample (model space), the patch (patch space) and the query point (:385-391),
+    each cast back to float32.  ``rng_sub`` = dataset.rng_global_sample, ``rng_rot`` = dataset.rng (both
+    LegacyMT19937(seed), carried across shapes); rng_rot None = no rotation.  trimesh is restated in
+    oracle/trimesh_restated.py (absent from the image)."""
+    from oracle import trimesh_restated as trafo
+    pts = np.asarray(pts, dtype=np.float32)
+    q = np.asarray(queries, dtype=np.float32).reshape(-1, 3)
+    ids = knn_ids(pts, q, points_per_patch)
+    r, patch_ps = patch_radius_and_ps(pts, ids, q)
+    uniform = bool(cfg.get('uniform_subsample', False))
+    fixed = bool(cfg.get('fixed_subsample', False))
+    n = q.shape[0]
+    sub = np.zeros((n, sub_sample_size, 3), np.float32)
+    q_rot = q.copy()
+    patch_rot = patch_ps.copy()
+    rots = np.zeros((n, 3, 3))
+    for i in range(n):
+        sub_ids = subsample_ids(rng_sub, pts, q[i], sub_sample_size, uniform, fixed)
+        sub[i] = pts[sub_ids]
+        if rng_rot is not None:
+            rand_rot = trafo.random_rotation_matrix(rng_rot.rand(3))
+            rots[i] = rand_rot[:3, :3]
+            sub[i] = trafo.transform_points(sub[i], rand_rot).astype(np.float32)
+            patch_rot[i] = trafo.transform_points(patch_ps[i], rand_rot).astype(np.float32)
+            q_rot[i] = trafo.transform_points(np.expand_dims(q[i], 0), rand_rot)[0].astype(np.float32)
+    logits = model_forward(w, cfg, patch_rot, sub, q_rot, chunk=chunk)
+    sdf = post_process(logits, r)
+    if return_all:
+        return dict(radius=r, patch_ps=patch_rot, sub=sub, q=q_rot, rot=rots, logits=logits, sdf=sdf)
+    return sdf
+
+
 # --------------------------------------------------------------------------------------
 # "next" row f-1 (SURVEY 8f): SDF samples -> dense volume -> iterative sign propagation
 # --------------------------------------------------------------------------------------

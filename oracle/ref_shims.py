@@ -15,6 +15,9 @@ are applied from the outside; no reference file is touched:
                                 source/sdf.py:4, source/base/point_cloud.py:3)
                                 + no-op ``sdf.visualize_query_points``
                                 (source/points_to_surf_eval.py:219-222,230-234)
+                                + ``trimesh.transformations.random_rotation_matrix`` /
+                                ``transform_points`` restated (oracle/trimesh_restated.py) for the
+                                GT-query evaluation pass (source/data_loader.py:381-393)
  3. ``cKDTree.query(n_jobs=)`` -> ``workers=`` (source/base/point_cloud.py:175,177)
  4. ``.cuda()`` no-ops on CPU  (source/points_to_surf_eval.py:167,362)
  5. ``torch.load(weights_only=False)`` (source/points_to_surf_eval.py:169,316)
@@ -49,6 +52,12 @@ def _install_trimesh_stub():
         m = types.ModuleType('trimesh.' + sub)
         setattr(tm, sub, m)
         sys.modules['trimesh.' + sub] = m
+    # the GT-query evaluation pass (source/data_loader.py:381-393) needs two real functions: restated from
+    # the published formulas (oracle/trimesh_restated.py -- parity pinned to that restatement, not to trimesh)
+    from oracle import trimesh_restated as _tr
+    for fn in ('random_rotation_matrix', 'random_quaternion', 'quaternion_matrix', 'transform_points',
+               'identity_matrix'):
+        setattr(tm.transformations, fn, getattr(_tr, fn))
     sys.modules['trimesh'] = tm
 
 

@@ -52,6 +52,10 @@ PROTOTYPES = {
     'p2s_gather_points': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'p2s_infer_shape': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_void_p,
                                 c_void_p, ctypes.POINTER(c_int64), c_void_p]),
+    'p2s_infer_queries': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    'p2s_random_rotations': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    'p2s_rotate_points': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    'p2s_debug_fault_chunk': (c_int, [c_void_p, c_int]),
     'p2s_sdf_volume': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, ctypes.c_float, c_int, c_int, c_void_p,
                                ctypes.POINTER(ctypes.c_int32), c_void_p]),
     'p2s_set_profiling': (c_int, [c_void_p, c_int]),

@@ -112,6 +112,7 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
 int p2s_model_destroy(p2s_model_t m) {
     if (!m) return P2S_OK;
     (void)hipSetDevice(m->device);
+    p2s_pipe_free(m);
     if (m->ws) (void)hipFree(m->ws);
     if (m->blob) (void)hipFree(m->blob);
     if (m->blob_h) (void)hipFree(m->blob_h);

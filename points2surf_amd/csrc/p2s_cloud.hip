@@ -620,6 +620,7 @@ int p2s_cloud_destroy(p2s_cloud_t c) {
     if (c->occ) (void)hipFree(c->occ);
     if (c->blk_cnt) (void)hipFree(c->blk_cnt);
     if (c->totals) (void)hipFree(c->totals);
+    if (c->qcache) (void)hipFree(c->qcache);
     if (c->wc_plan) (void)hipFree(c->wc_plan);
     delete c;
     return P2S_OK;
@@ -629,12 +630,39 @@ int p2s_cloud_num_points(p2s_cloud_t c) { return c ? c->d.n : P2S_EINVAL; }
 
 int p2s_query_grid(p2s_cloud_t c, int res, int eps, float *q_out_dev, int64_t capacity, int64_t *n_queries,
                    void *stream) {
-    if (!c || res < 2 || res > 1024 || eps < 1 || eps > 16 || !n_queries || (capacity > 0 && !q_out_dev)) {
+    if (!c || !n_queries || (capacity > 0 && !q_out_dev)) {
         p2s_set_error("p2s_query_grid: bad argument (res=%d eps=%d)", res, eps);
         return P2S_EINVAL;
     }
+    const float *q = nullptr;
+    long long n = 0;
+    const int rc = p2s_cloud_grid(c, res, eps, &q, &n, (hipStream_t)stream);
+    if (rc) return rc;
+    *n_queries = n;
+    if (capacity <= 0) return n > 0 ? P2S_ECAPACITY : P2S_OK;
+    if (n > capacity) {
+        p2s_set_error("p2s_query_grid: capacity %lld < %lld queries", (long long)capacity, n);
+        return P2S_ECAPACITY;
+    }
+    if (n > 0)
+        P2S_HIP_CHECK(hipMemcpyAsync(q_out_dev, q, (size_t)n * 12, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return P2S_OK;
+}
+
+}  // extern "C"
+
+int p2s_cloud_grid(p2s_cloud_s *c, int res, int eps, const float **q_out, long long *n_out, hipStream_t s) {
+    if (!c || res < 2 || res > 1024 || eps < 1 || eps > 16) {
+        p2s_set_error("p2s_query_grid: bad argument (res=%d eps=%d)", res, eps);
+        return P2S_EINVAL;
+    }
+    if (c->qc_n >= 0 && c->qc_res == res && c->qc_eps == eps) {
+        *q_out = c->qcache;
+        *n_out = c->qc_n;
+        return P2S_OK;
+    }
     P2S_HIP_CHECK(hipSetDevice(c->device));
-    hipStream_t s = (hipStream_t)stream;
+    c->qc_n = -1;
     const size_t vox = (size_t)res * res * res;
     const size_t words = (vox + 31) / 32;
     const long long rm = res - 1;
@@ -644,6 +672,7 @@ int p2s_query_grid(p2s_cloud_t c, int res, int eps, float *q_out_dev, int64_t ca
         c->occ = nullptr;
         c->occ_words = 0;
         if (hipMalloc(&c->occ, words * 4) != hipSuccess) {
+            (void)hipGetLastError();
             p2s_set_error("p2s_query_grid: hipMalloc(%zu bytes) failed", words * 4);
             return P2S_ENOMEM;
         }
@@ -655,6 +684,7 @@ int p2s_query_grid(p2s_cloud_t c, int res, int eps, float *q_out_dev, int64_t ca
         c->blk_cap = 0;
         // counts (int) followed by offsets (long long)
         if (hipMalloc(&c->blk_cnt, (size_t)nblk * 4 + (size_t)nblk * 8 + 64) != hipSuccess) {
+            (void)hipGetLastError();
             p2s_set_error("p2s_query_grid: hipMalloc(block scan) failed");
             return P2S_ENOMEM;
         }
@@ -671,7 +701,7 @@ int p2s_query_grid(p2s_cloud_t c, int res, int eps, float *q_out_dev, int64_t ca
     go.n = eps;
     for (int j = 0; j < eps; ++j) go.o[j] = eps / 2 - j;   // scipy.ndimage.convolve, origin 0
     hipLaunchKernelGGL(p2s_grid_compact_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, s, c->occ, res, go, c->blk_cnt,
-                       blk_off, q_out_dev, (long long)capacity);
+                       blk_off, (float *)nullptr, 0LL);
     P2S_LAUNCH_CHECK("p2s_grid_compact_kernel<0>");
     hipLaunchKernelGGL(p2s_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, c->blk_cnt, nblk, blk_off, c->totals);
     P2S_LAUNCH_CHECK("p2s_scan_blocks_kernel");
@@ -682,17 +712,33 @@ int p2s_query_grid(p2s_cloud_t c, int res, int eps, float *q_out_dev, int64_t ca
         p2s_set_error("p2s_query_grid: point outside the [-1,1) volume (IndexError in the reference)");
         return P2S_EINVAL;
     }
-    *n_queries = host_tot[0];
-    if (capacity <= 0) return host_tot[0] > 0 ? P2S_ECAPACITY : P2S_OK;
-    hipLaunchKernelGGL(p2s_grid_compact_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, c->occ, res, go, c->blk_cnt,
-                       blk_off, q_out_dev, (long long)capacity);
-    P2S_LAUNCH_CHECK("p2s_grid_compact_kernel<1>");
-    if (host_tot[0] > capacity) {
-        p2s_set_error("p2s_query_grid: capacity %lld < %lld queries", (long long)capacity, host_tot[0]);
-        return P2S_ECAPACITY;
+    const long long n = host_tot[0];
+    if (n > c->qc_cap) {
+        if (c->qcache) (void)hipFree(c->qcache);
+        c->qcache = nullptr;
+        c->qc_cap = 0;
+        if (hipMalloc(&c->qcache, (size_t)n * 12) != hipSuccess) {
+            (void)hipGetLastError();
+            p2s_set_error("p2s_query_grid: hipMalloc(%lld query points) failed", n);
+            return P2S_ENOMEM;
+        }
+        c->qc_cap = n;
     }
+    if (n > 0) {
+        hipLaunchKernelGGL(p2s_grid_compact_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, c->occ, res, go, c->blk_cnt,
+                           blk_off, c->qcache, n);
+        P2S_LAUNCH_CHECK("p2s_grid_compact_kernel<1>");
+        P2S_HIP_CHECK(hipStreamSynchronize(s));    // the grid may be consumed on other streams from here on
+    }
+    c->qc_res = res;
+    c->qc_eps = eps;
+    c->qc_n = n;
+    *q_out = c->qcache;
+    *n_out = n;
     return P2S_OK;
 }
+
+extern "C" {
 
 int p2s_knn_patch(p2s_cloud_t c, const float *query_dev, int64_t nq, int k, int32_t *ids_out_dev,
                   float *patch_ps_out_dev, float *radius_out_dev, void *stream) {

@@ -3,6 +3,21 @@
 #include "p2s_common.h"
 #include <vector>
 
+// per-shape pipeline buffers (p2s_pipeline.hip): owned by the model handle, grown on demand, reused across
+// shapes, released by p2s_model_destroy -- no allocation and no leak on the per-shape path
+struct PipeBuffers {
+    float *patch[2] = {};           // [C][k][3]
+    float *radius[2] = {};          // [C]
+    int32_t *sub_ids[2] = {};       // [C][n]
+    float *sub[2] = {};             // [C][n][3]
+    float *qrot[2] = {};            // [C][3]   rotated query points (GT-query pass)
+    double *rot[2] = {};            // [C][9]   per-query rotation (GT-query pass)
+    hipEvent_t ready[2] = {};       // data path of the buffer finished (aux stream)
+    hipEvent_t freed[2] = {};       // encoders finished reading the buffer (main stream)
+    hipEvent_t grid = nullptr;
+    int cap_chunk = 0, cap_k = 0, cap_n = 0;
+};
+
 struct p2s_model_s {
     p2s_model_cfg cfg;
     p2s_weight_offsets offs;
@@ -25,7 +40,10 @@ struct p2s_model_s {
     // auxiliary stream: the data path (kNN, sub-sample) of chunk i+1, i+2 overlaps the encoders of chunk i
     hipStream_t aux = nullptr;     // high-priority stream of the sub-sample generator
     bool overlap = true;
+    PipeBuffers pipe;
+    int fault_chunk = -1;          // test hook (p2s_debug_fault_chunk): fail with P2S_EHIP before this chunk
 };
+void p2s_pipe_free(p2s_model_s *m);
 
 enum P2SStage { ST_CHAIN_STN = 0, ST_HEAD, ST_CHAIN_MAIN, ST_DECODER, ST_KNN, ST_SUB, ST_GRID };
 int p2s_prof_mark(p2s_model_s *m, hipStream_t s);                 // event index or -1
@@ -65,6 +83,10 @@ struct p2s_cloud_s {
     int *blk_cnt = nullptr;
     size_t blk_cap = 0;
     long long *totals = nullptr;   // [2] device: total count, error flag
+    // the last query grid stays on the handle: the pipeline and the callers that size their outputs share it
+    float *qcache = nullptr;
+    int qc_res = 0, qc_eps = 0;
+    long long qc_n = -1, qc_cap = 0;
     // summation plan of np.sum(float32[n]) for the weighted sub-sample (p2s_wchoice.hip), built on first use
     int *wc_plan = nullptr;        // device: leaves [L][3], ops [O][3], level offsets [levels+1]
     int wc_leaves = 0, wc_ops_at = 0, wc_lvl_at = 0, wc_levels = 0, wc_root = 0;
@@ -97,6 +119,10 @@ struct p2s_rng_s {
     double *wc_stot = nullptr;     // [C]
     size_t wc_cap_q = 0, wc_cap_n = 0, wc_cap_k = 0;
 };
+
+// query grid of (res, eps), computed once per cloud handle and kept on the device (p2s_cloud.hip); *q is owned by
+// the handle and valid until the next call with other parameters; synchronises `s`
+int p2s_cloud_grid(p2s_cloud_s *c, int res, int eps, const float **q, long long *n, hipStream_t s);
 
 // serial generator (p2s_cloud.hip) and parallel generator (p2s_rng.hip)
 int p2s_rng_serial_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s);

@@ -1,36 +1,31 @@
-// p2s_infer_shape: the batch loop of the reference's points_to_surf_eval for ONE shape in
-// reconstruction mode (source/points_to_surf_eval.py:358-404), entirely on the device:
-//   query grid -> per chunk { kNN patch + radius, MT19937 sub-sample + gather, encoders + decoder } -> sdf
+// The batch loop of the reference's points_to_surf_eval for ONE shape (source/points_to_surf_eval.py:358-404),
+// entirely on the device:
+//   p2s_infer_shape    reconstruction pass: query grid -> per chunk { kNN patch + radius, sub-sample + gather,
+//                      encoders + decoder } -> sdf
+//   p2s_infer_queries  GT-query evaluation pass (full_eval.py:31-33): the same for caller-provided query points, with
+//                      the per-query random rotation of source/data_loader.py:381-393 (second RandomState ->
+//                      rand(3) -> rotation matrix -> float64 transform of patch, sub-sample and query point)
 //
 // Two HIP streams: the data path of chunks i+1, i+2 (latency-bound select/gather work that needs a
 // handful of CUs; the MT19937 recurrence is serial) runs on an auxiliary stream while the MFMA-bound
-// encoders of chunk i own the rest of the chip.  Double-buffered; events order buffer reuse.
+// encoders of chunk i own the rest of the chip.  Double-buffered; events order buffer reuse.  The buffers live on
+// the model handle (grown on demand, reused across shapes, released by p2s_model_destroy): the per-shape path
+// allocates nothing, and every error path leaves through fail(), which drains both streams first.
 #include "p2s_common.h"
 #include "p2s_internal.h"
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
 
-namespace {
-
-struct PipeBuffers {
-    float *q = nullptr;             // [Q][3]
-    float *patch[2] = {};           // [C][k][3]
-    float *radius[2] = {};          // [C]
-    int32_t *sub_ids[2] = {};       // [C][n]
-    float *sub[2] = {};             // [C][n][3]
-    hipEvent_t ready[2] = {};       // data path of the buffer finished (aux stream)
-    hipEvent_t freed[2] = {};       // encoders finished reading the buffer (main stream)
-    hipEvent_t grid = nullptr;
-};
-
-void free_pipe(PipeBuffers &b) {
-    if (b.q) (void)hipFree(b.q);
+void p2s_pipe_free(p2s_model_s *m) {
+    PipeBuffers &b = m->pipe;
     for (int i = 0; i < 2; ++i) {
         if (b.patch[i]) (void)hipFree(b.patch[i]);
         if (b.radius[i]) (void)hipFree(b.radius[i]);
         if (b.sub_ids[i]) (void)hipFree(b.sub_ids[i]);
         if (b.sub[i]) (void)hipFree(b.sub[i]);
+        if (b.qrot[i]) (void)hipFree(b.qrot[i]);
+        if (b.rot[i]) (void)hipFree(b.rot[i]);
         if (b.ready[i]) (void)hipEventDestroy(b.ready[i]);
         if (b.freed[i]) (void)hipEventDestroy(b.freed[i]);
     }
@@ -38,18 +33,159 @@ void free_pipe(PipeBuffers &b) {
     b = PipeBuffers();
 }
 
+namespace {
+
+int pipe_reserve(p2s_model_s *m, int C, int k, int n) {
+    PipeBuffers &b = m->pipe;
+    if (b.cap_chunk >= C && b.cap_k == k && b.cap_n == n) return P2S_OK;
+    P2S_HIP_CHECK(hipDeviceSynchronize());
+    p2s_pipe_free(m);
+    bool ok = hipEventCreateWithFlags(&b.grid, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) {
+        ok = hipMalloc(&b.patch[i], (size_t)C * k * 12) == hipSuccess && hipMalloc(&b.radius[i], (size_t)C * 4) == hipSuccess &&
+             hipMalloc(&b.sub_ids[i], (size_t)C * n * 4) == hipSuccess && hipMalloc(&b.sub[i], (size_t)C * n * 12) == hipSuccess &&
+             hipMalloc(&b.qrot[i], (size_t)C * 12) == hipSuccess && hipMalloc(&b.rot[i], (size_t)C * 72) == hipSuccess &&
+             hipEventCreateWithFlags(&b.ready[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&b.freed[i], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        p2s_pipe_free(m);
+        p2s_set_error("p2s pipeline: allocation of the chunk buffers failed (chunk %d)", C);
+        return P2S_ENOMEM;
+    }
+    b.cap_chunk = C;
+    b.cap_k = k;
+    b.cap_n = n;
+    return P2S_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GT-query pass: random rotation per query (reference source/data_loader.py:381-393).
+//   rand3 = self.rng.rand(3)                       numpy legacy: (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53 per double
+//   M = trimesh.transformations.random_rotation_matrix(rand3)   = quaternion_matrix(random_quaternion(rand3))
+// (trimesh = Gohlke's transformations.py; restated in oracle/trimesh_restated.py).  All float64, no contraction.
+// ---------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void p2s_rand_rot_kernel(const uint32_t *__restrict__ words, const long long *__restrict__ meta,
+                                                           long long cap_words, long long n, double *__restrict__ rot,
+                                                           long long *__restrict__ err) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long c0 = meta[0];
+    if (c0 + 6 * n > cap_words) {
+        if (i == 0) err[0] = 2;          // random words exhausted (host-side accounting makes this unreachable)
+        return;
+    }
+    const uint32_t *w = words + c0 + 6 * i;
+    double rnd[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double a = (double)(w[2 * j] >> 5), b = (double)(w[2 * j + 1] >> 6);
+        rnd[j] = (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+    const double r1 = sqrt(1.0 - rnd[0]), r2 = sqrt(rnd[0]);
+    const double pi2 = 3.141592653589793 * 2.0;
+    const double t1 = pi2 * rnd[1], t2 = pi2 * rnd[2];
+    double q[4] = {cos(t2) * r2, sin(t1) * r1, cos(t1) * r1, sin(t2) * r2};
+    const double nn = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
+    double *R = rot + 9 * i;
+    if (nn < 2.220446049250313e-16 * 4.0) {
+        R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+        return;
+    }
+    const double sc = sqrt(2.0 / nn);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] *= sc;
+    const double q11 = q[1] * q[1], q22 = q[2] * q[2], q33 = q[3] * q[3];
+    const double q12 = q[1] * q[2], q13 = q[1] * q[3], q23 = q[2] * q[3];
+    const double q10 = q[1] * q[0], q20 = q[2] * q[0], q30 = q[3] * q[0];
+    R[0] = 1.0 - q22 - q33; R[1] = q12 - q30;       R[2] = q13 + q20;
+    R[3] = q12 + q30;       R[4] = 1.0 - q11 - q33; R[5] = q23 - q10;
+    R[6] = q13 - q20;       R[7] = q23 + q10;       R[8] = 1.0 - q11 - q22;
+}
+
+__global__ void p2s_advance_cursor_kernel(long long *meta, long long words) { meta[0] += words; }
+
+// trimesh.transformations.transform_points(points, M).astype(np.float32): float64 homogeneous product, row c of
+// the result = sum_k M[c][k] * [x y z 1][k]  (M[c][3] = 0).  One thread per point.
+__global__ __launch_bounds__(256) void p2s_rotate_points_kernel(const double *__restrict__ rot, const float *__restrict__ in,
+                                                                float *__restrict__ out, int P, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const double *R = rot + 9 * (i / P);
+    const double x = in[3 * i + 0], y = in[3 * i + 1], z = in[3 * i + 2];
+    // identity shortcut of transform_points (|M - I|.max() < 1e-8 returns the points unchanged)
+    double dev = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) dev = fmax(dev, fabs(R[j] - ((j % 4 == 0) ? 1.0 : 0.0)));
+    if (dev < 1e-8) {
+        out[3 * i + 0] = (float)x; out[3 * i + 1] = (float)y; out[3 * i + 2] = (float)z;
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double acc = R[3 * c + 0] * x;
+        acc = __builtin_fma(R[3 * c + 1], y, acc);
+        acc = __builtin_fma(R[3 * c + 2], z, acc);
+        out[3 * i + c] = (float)acc;
+    }
+}
+
 }  // namespace
 
-extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int res, int eps, int64_t q_begin,
-                               int64_t q_end, int chunk, float *sdf_out_dev, float *q_out_dev, int64_t *n_done,
-                               void *stream) {
-    if (!m || !c || !r || !sdf_out_dev) {
-        p2s_set_error("p2s_infer_shape: null argument");
+extern "C" int p2s_random_rotations(p2s_rng_t r, int64_t n, double *rot_out_dev, void *stream) {
+    if (!r || n < 0 || (n > 0 && !rot_out_dev)) {
+        p2s_set_error("p2s_random_rotations: bad argument");
         return P2S_EINVAL;
     }
-    const bool weighted = m->cfg.weighted_subsample != 0;   // p2s_vanilla: choice(p, replace=False) per query
-    P2S_HIP_CHECK(hipSetDevice(m->device));
+    if (r->levels_max == 0) {
+        p2s_set_error("p2s_random_rotations: needs the jump-ahead tables (p2s_rng_set_jump_tables)");
+        return P2S_EINVAL;
+    }
+    if (n == 0) return P2S_OK;
+    P2S_HIP_CHECK(hipSetDevice(r->device));
     hipStream_t s = (hipStream_t)stream;
+    const long long cap = p2s_rng_session_words(r);
+    const long long per = std::max<long long>(1, std::min<long long>(n, (cap - 1024) / 6));
+    for (int64_t done = 0; done < n;) {
+        const long long cur = std::min<long long>(per, n - done);
+        const int rc = p2s_rng_session_raw(r, 6 * cur, s);
+        if (rc) return rc;
+        long long *meta = p2s_rng_raw_meta(r);
+        hipLaunchKernelGGL(p2s_rand_rot_kernel, dim3((unsigned)((cur + 255) / 256)), dim3(256), 0, s, r->tmp, meta, cap, cur,
+                           rot_out_dev + (size_t)done * 9, meta + 1);
+        hipLaunchKernelGGL(p2s_advance_cursor_kernel, dim3(1), dim3(1), 0, s, meta, 6 * cur);
+        P2S_LAUNCH_CHECK("p2s_rand_rot_kernel");
+        done += cur;
+    }
+    return P2S_OK;
+}
+
+extern "C" int p2s_rotate_points(const double *rot_dev, const float *pts_in_dev, int points_per_item, int64_t n_items,
+                                 float *pts_out_dev, void *stream) {
+    if (!rot_dev || !pts_in_dev || !pts_out_dev || points_per_item < 1 || n_items < 0) {
+        p2s_set_error("p2s_rotate_points: bad argument");
+        return P2S_EINVAL;
+    }
+    const long long total = (long long)n_items * points_per_item;
+    if (total == 0) return P2S_OK;
+    hipLaunchKernelGGL(p2s_rotate_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rot_dev, pts_in_dev, pts_out_dev, points_per_item, total);
+    P2S_LAUNCH_CHECK("p2s_rotate_points_kernel");
+    return P2S_OK;
+}
+
+extern "C" int p2s_debug_fault_chunk(p2s_model_t m, int chunk_index) {
+    if (!m) return P2S_EINVAL;
+    m->fault_chunk = chunk_index;
+    return P2S_OK;
+}
+
+// queries q_all[q_begin, q_end) through the double-buffered pipeline.  r_rot != NULL: GT-query pass (rotation).
+static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s *r_rot, const float *q_all, int64_t q_begin,
+                        int64_t q_end, int chunk, float *sdf_out_dev, hipStream_t s) {
+    const bool weighted = m->cfg.weighted_subsample != 0;   // p2s_vanilla: choice(p, replace=False) per query
     const int k = m->cfg.points_per_patch, n = m->cfg.sub_sample_size;
     if (chunk <= 0) chunk = m->max_chunk;
     chunk = std::min(chunk, m->max_chunk);
@@ -63,51 +199,37 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
         P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, hi));
     }
     hipStream_t sa = m->overlap ? m->aux : s;
-
-    p2s_prof_reset(m);
-
-    int64_t Q = 0;
-    const int eg0 = p2s_prof_mark(m, s);
-    int rc = p2s_query_grid(c, res, eps, nullptr, 0, &Q, stream);
-    if (rc != P2S_OK && rc != P2S_ECAPACITY) return rc;
-    if (q_end < 0) q_end = Q;
-    if (q_begin < 0 || q_begin > q_end || q_end > Q) {
-        p2s_set_error("p2s_infer_shape: query range [%lld,%lld) outside [0,%lld]", (long long)q_begin,
-                      (long long)q_end, (long long)Q);
-        return P2S_EINVAL;
-    }
-    PipeBuffers b;
+    const int64_t nq = q_end - q_begin;
+    if (nq <= 0) return P2S_OK;
+    const int C = (int)std::min<int64_t>(chunk, nq);
+    int rc = pipe_reserve(m, C, k, n);
+    if (rc) return rc;
+    rc = p2s_model_reserve(m, C);
+    if (rc) return rc;
+    PipeBuffers &b = m->pipe;
+    const int nbuf = (nq > C) ? 2 : 1;
+    // every exit after the first launch: both streams drained, so the caller may free / reuse its buffers and the
+    // model-owned chunk buffers are idle again
     auto fail = [&](int code) {
-        (void)hipStreamSynchronize(s);
-        if (sa != s) (void)hipStreamSynchronize(sa);
-        free_pipe(b);
+        const hipError_t e1 = hipStreamSynchronize(s);
+        const hipError_t e2 = (sa != s) ? hipStreamSynchronize(sa) : hipSuccess;
+        if (code == P2S_OK && (e1 != hipSuccess || e2 != hipSuccess)) {
+            p2s_set_error("p2s pipeline: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            return (int)P2S_EHIP;
+        }
         return code;
     };
-    const int64_t nq = q_end - q_begin;
-    if (n_done) *n_done = 0;
-    if (Q == 0 || nq == 0) return fail(P2S_OK);
-    const int C = (int)std::min<int64_t>(chunk, nq);
-    const int nbuf = (nq > C) ? 2 : 1;
-    bool ok = hipMalloc(&b.q, (size_t)Q * 12) == hipSuccess && hipEventCreateWithFlags(&b.grid, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < nbuf && ok; ++i) {
-        ok = hipMalloc(&b.patch[i], (size_t)C * k * 12) == hipSuccess && hipMalloc(&b.radius[i], (size_t)C * 4) == hipSuccess &&
-             hipMalloc(&b.sub_ids[i], (size_t)C * n * 4) == hipSuccess && hipMalloc(&b.sub[i], (size_t)C * n * 12) == hipSuccess &&
-             hipEventCreateWithFlags(&b.ready[i], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&b.freed[i], hipEventDisableTiming) == hipSuccess;
-    }
-    if (!ok) {
-        p2s_set_error("p2s_infer_shape: allocation of pipeline buffers failed");
-        (void)hipGetLastError();
-        return fail(P2S_ENOMEM);
-    }
-    rc = p2s_query_grid(c, res, eps, b.q, Q, &Q, stream);
-    if (rc) return fail(rc);
-    p2s_prof_span(m, ST_GRID, eg0, p2s_prof_mark(m, s));
-    rc = p2s_model_reserve(m, C);
-    if (rc) return fail(rc);
+#define PIPE_HIP(expr)                                                                                     \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) {                                                                            \
+            p2s_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);      \
+            return fail(P2S_EHIP);                                                                         \
+        }                                                                                                  \
+    } while (0)
     if (sa != s) {
-        P2S_HIP_CHECK(hipEventRecord(b.grid, s));
-        P2S_HIP_CHECK(hipStreamWaitEvent(sa, b.grid, 0));
+        PIPE_HIP(hipEventRecord(b.grid, s));
+        PIPE_HIP(hipStreamWaitEvent(sa, b.grid, 0));
     }
 
     const int64_t nchunks = (nq + C - 1) / C;
@@ -115,47 +237,109 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
         const int bi = (int)(ci % nbuf);
         const int64_t q0 = q_begin + ci * C;
         const int cur = (int)std::min<int64_t>(C, q_end - q0);
-        if (ci >= nbuf && sa != s) P2S_HIP_CHECK(hipStreamWaitEvent(sa, b.freed[bi], 0));
+        if (ci >= nbuf && sa != s) PIPE_HIP(hipStreamWaitEvent(sa, b.freed[bi], 0));
         const int e0 = p2s_prof_mark(m, sa);
-        const int rc2 = weighted ? p2s_subsample_weighted(r, c, b.q + (size_t)q0 * 3, cur, n, b.sub_ids[bi], nullptr, sa)
+        const int rc2 = weighted ? p2s_subsample_weighted(r, c, q_all + (size_t)q0 * 3, cur, n, b.sub_ids[bi], nullptr, sa)
                                  : p2s_subsample_uniform(r, c, cur, n, b.sub_ids[bi], nullptr, sa);
-        if (rc2) return rc2;
+        if (rc2) return fail(rc2);
         p2s_prof_span(m, ST_SUB, e0, p2s_prof_mark(m, sa));
-        if (sa != s) P2S_HIP_CHECK(hipEventRecord(b.ready[bi], sa));
+        if (sa != s) PIPE_HIP(hipEventRecord(b.ready[bi], sa));
         return P2S_OK;
     };
 
     // prologue: up to nbuf chunks of ids in flight
     for (int64_t ci = 0; ci < std::min<int64_t>(nbuf, nchunks); ++ci)
-        if ((rc = produce(ci))) return fail(rc);
+        if ((rc = produce(ci))) return rc;
     for (int64_t ci = 0; ci < nchunks; ++ci) {
         const int bi = (int)(ci % nbuf);
         const int64_t q0 = q_begin + ci * C;
         const int cur = (int)std::min<int64_t>(C, q_end - q0);
-        const float *qc = b.q + (size_t)q0 * 3;
+        const float *qc = q_all + (size_t)q0 * 3;
+        if (m->fault_chunk == (int)ci) {
+            m->fault_chunk = -1;
+            p2s_set_error("p2s pipeline: injected fault before chunk %lld (p2s_debug_fault_chunk)", (long long)ci);
+            return fail(P2S_EHIP);
+        }
         const int ek0 = p2s_prof_mark(m, s);
         rc = p2s_knn_patch(c, qc, cur, k, nullptr, b.patch[bi], b.radius[bi], s);
         if (rc) return fail(rc);
         p2s_prof_span(m, ST_KNN, ek0, p2s_prof_mark(m, s));
-        if (sa != s) P2S_HIP_CHECK(hipStreamWaitEvent(s, b.ready[bi], 0));
+        if (sa != s) PIPE_HIP(hipStreamWaitEvent(s, b.ready[bi], 0));
         rc = p2s_gather_points(c, b.sub_ids[bi], (int64_t)cur * n, b.sub[bi], s);
         if (rc) return fail(rc);
-        if (sa != s) P2S_HIP_CHECK(hipEventRecord(b.freed[bi], s));
+        // the producer only writes sub_ids: free for chunk ci + nbuf as soon as the gather has read them
+        if (sa != s) PIPE_HIP(hipEventRecord(b.freed[bi], s));
+        if (r_rot) {
+            // data_loader.py:381-393: rotate sub-sample (model space), patch (patch space) and the query point
+            if ((rc = p2s_random_rotations(r_rot, cur, b.rot[bi], s))) return fail(rc);
+            if ((rc = p2s_rotate_points(b.rot[bi], b.sub[bi], n, cur, b.sub[bi], s))) return fail(rc);
+            if ((rc = p2s_rotate_points(b.rot[bi], b.patch[bi], k, cur, b.patch[bi], s))) return fail(rc);
+            if ((rc = p2s_rotate_points(b.rot[bi], qc, 1, cur, b.qrot[bi], s))) return fail(rc);
+            qc = b.qrot[bi];
+        }
         rc = p2s_run_chunk(m, b.patch[bi], b.sub[bi], qc, b.radius[bi], cur, nullptr, sdf_out_dev + (q0 - q_begin),
                            nullptr, nullptr, s);
         if (rc) return fail(rc);
         if (ci + nbuf < nchunks)
-            if ((rc = produce(ci + nbuf))) return fail(rc);
+            if ((rc = produce(ci + nbuf))) return rc;
     }
-    if (q_out_dev)
-        P2S_HIP_CHECK(hipMemcpyAsync(q_out_dev, b.q + (size_t)q_begin * 3, (size_t)nq * 12, hipMemcpyDeviceToDevice, s));
+#undef PIPE_HIP
     m->counters.queries += nq;
-    // buffers are freed below: both streams must be done with them
-    P2S_HIP_CHECK(hipStreamSynchronize(s));
-    if (sa != s) P2S_HIP_CHECK(hipStreamSynchronize(sa));
+    return fail(P2S_OK);
+}
+
+extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int res, int eps, int64_t q_begin,
+                               int64_t q_end, int chunk, float *sdf_out_dev, float *q_out_dev, int64_t *n_done,
+                               void *stream) {
+    if (!m || !c || !r || !sdf_out_dev) {
+        p2s_set_error("p2s_infer_shape: null argument");
+        return P2S_EINVAL;
+    }
+    P2S_HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    p2s_prof_reset(m);
+    const float *q_all = nullptr;
+    long long Q = 0;
+    const int eg0 = p2s_prof_mark(m, s);
+    int rc = p2s_cloud_grid(c, res, eps, &q_all, &Q, s);
+    if (rc) return rc;
+    p2s_prof_span(m, ST_GRID, eg0, p2s_prof_mark(m, s));
+    if (q_end < 0) q_end = Q;
+    if (q_begin < 0 || q_begin > q_end || q_end > Q) {
+        p2s_set_error("p2s_infer_shape: query range [%lld,%lld) outside [0,%lld]", (long long)q_begin,
+                      (long long)q_end, (long long)Q);
+        return P2S_EINVAL;
+    }
+    if (n_done) *n_done = 0;
+    const int64_t nq = q_end - q_begin;
+    if (nq == 0) return P2S_OK;
+    rc = run_pipeline(m, c, r, nullptr, q_all, q_begin, q_end, chunk, sdf_out_dev, s);
+    if (rc) return rc;
+    if (q_out_dev) {
+        P2S_HIP_CHECK(hipMemcpyAsync(q_out_dev, q_all + (size_t)q_begin * 3, (size_t)nq * 12, hipMemcpyDeviceToDevice, s));
+        P2S_HIP_CHECK(hipStreamSynchronize(s));
+    }
     p2s_prof_collect(m);
     rc = p2s_rng_check(r, s);
-    if (rc) return fail(rc);
+    if (rc) return rc;
     if (n_done) *n_done = nq;
-    return fail(P2S_OK);
+    return P2S_OK;
+}
+
+extern "C" int p2s_infer_queries(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r_sub, p2s_rng_t r_rot, const float *q_dev,
+                                 int64_t n_queries, int chunk, float *sdf_out_dev, void *stream) {
+    if (!m || !c || !r_sub || (n_queries > 0 && (!q_dev || !sdf_out_dev)) || n_queries < 0 || r_rot == r_sub) {
+        p2s_set_error("p2s_infer_queries: bad argument (the rotation generator must be a second handle)");
+        return P2S_EINVAL;
+    }
+    P2S_HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    p2s_prof_reset(m);
+    if (n_queries == 0) return P2S_OK;
+    int rc = run_pipeline(m, c, r_sub, r_rot, q_dev, 0, n_queries, chunk, sdf_out_dev, s);
+    if (rc) return rc;
+    p2s_prof_collect(m);
+    if ((rc = p2s_rng_check(r_sub, s))) return rc;
+    if (r_rot && (rc = p2s_rng_check(r_rot, s))) return rc;
+    return P2S_OK;
 }

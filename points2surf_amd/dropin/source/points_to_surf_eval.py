@@ -12,10 +12,12 @@ Deliberate differences (documented in INTEGRATION.md):
     results depend on the worker count through duplicated RNG streams);
   * ``--gpu_idx < 0`` raises: the reference's CPU branch does not run as written either
     (:167,362 call .cuda() unconditionally) and this engine has no CPU fallback;
-  * the debug visualisations ``rec/query_pts_ms_vis/*.ply`` and ``rec/vis/*.ply`` need trimesh and are
-    written only when trimesh is importable;
-  * the non-reconstruction pass (GT query points with random rotation augmentation,
-    source/data_loader.py:381-393) is outside the accelerated path and raises NotImplementedError;
+  * the debug visualisations ``<out>/vis/*.ply`` and ``rec/query_pts_ms_vis/*.ply`` (sdf.visualize_query_points,
+    source/sdf.py:269-285) are written by a dependency-free PLY writer (points2surf_amd/ply.py; trimesh is absent,
+    byte-identity with its exporter is unpinned);
+  * the GT-query pass (``reconstruction=False``: query points from ``05_query_pts``, one random rotation per query
+    from the dataset's first RandomState, source/data_loader.py:365-393) runs on the device too (p2s_infer_queries);
+    ``full_eval.py`` calls it first whenever ``<indir>/05_query_dist`` exists (:31-33);
   * with torchrun (WORLD_SIZE > 1) shapes are sharded over ranks (one process per GPU).  By default every
     rank also consumes the sub-sample draws of the shapes it does not own, so results stay identical to the
     single-process run (dataset-wide stream); ``P2S_RNG_MODE=per_shape`` instead seeds shape i with
@@ -98,6 +100,11 @@ def _engine_cfg(train_opt, pred_dim):
     outputs = list(train_opt.outputs)
     if 'imp_surf' in outputs or 'imp_surf_magnitude' not in outputs or 'imp_surf_sign' not in outputs:
         raise ValueError('the HIP engine supports outputs imp_surf_magnitude + imp_surf_sign (got %s)' % outputs)
+    pred_cols = [o for o in outputs if o in ('imp_surf', 'imp_surf_magnitude', 'imp_surf_sign')]
+    if pred_cols != ['imp_surf_magnitude', 'imp_surf_sign']:
+        # the reference maps prediction columns by the ORDER of train_opt.outputs (output_pred_ind, :81-103); the
+        # decoder tail of the engine is column 0 = magnitude, column 1 = sign
+        raise ValueError('the HIP engine expects outputs ordered imp_surf_magnitude, imp_surf_sign (got %s)' % outputs)
     if getattr(train_opt, 'patch_radius', 0.0) > 0.0:
         raise ValueError('fixed patch_radius (radius query) models are not supported by the HIP engine')
     if int(getattr(train_opt, 'fixed_subsample', 0)):
@@ -135,23 +142,35 @@ def _infer_one_shape(model, cloud, rng_dev, res, eps, chunk):
     return _engine.infer_shape(model, cloud, rng_dev, res, eps, chunk=chunk)
 
 
-def _save_shape(model_out_dir, shape_name, sdf_np, q_np):
-    """files of save_evaluation + save_reconstruction_data (reference :199-222, :263-282)"""
+def _visualize_query_points(query_pts_ms, query_dist_ms, file_out):
+    """sdf.visualize_query_points (reference source/sdf.py:269-285): red = negative, green = positive distance,
+    brightness = |d| / max|d|; written as a coloured point-cloud PLY"""
+    from points2surf_amd import ply
+    d = np.asarray(query_dist_ms)
+    d_abs = np.abs(d)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        d_norm = d_abs / d_abs.max()
+    col = np.zeros((d.shape[0], 3))
+    neg, pos = d < 0.0, d > 0.0
+    col[neg, 0] = 0.5 + 0.5 * d_norm[neg]
+    col[pos, 1] = 0.5 + 0.5 * d_norm[pos]
+    os.makedirs(os.path.dirname(file_out), exist_ok=True)
+    ply.write_ply(file_out, query_pts_ms, vertex_colors=col)
+
+
+def _save_shape(model_out_dir, shape_name, sdf_np, q_np, reconstruction=True):
+    """files of save_evaluation (+ save_reconstruction_data in reconstruction mode), reference :199-222, :263-282"""
     os.makedirs(os.path.join(model_out_dir, 'eval'), exist_ok=True)
     np.save(os.path.join(model_out_dir, 'eval', shape_name + '.xyz.npy'), sdf_np)
     np.savetxt(os.path.join(model_out_dir, 'eval', shape_name + '.xyz.txt'), sdf_np)
+    _visualize_query_points(q_np, sdf_np, os.path.join(model_out_dir, 'vis', shape_name + '.ply'))
+    if not reconstruction:
+        return
     os.makedirs(os.path.join(model_out_dir, 'query_pts_ms'), exist_ok=True)
     np.save(os.path.join(model_out_dir, 'query_pts_ms', shape_name + '.xyz.npy'), q_np)
     os.makedirs(os.path.join(model_out_dir, 'dist_ms'), exist_ok=True)
     np.save(os.path.join(model_out_dir, 'dist_ms', shape_name + '.xyz.npy'), sdf_np)
-    try:   # debug visualisations exist only where the reference's own dependencies are installed
-        import trimesh  # noqa: F401
-        from source import sdf as ref_sdf
-        for sub in ('vis', 'query_pts_ms_vis'):
-            os.makedirs(os.path.join(model_out_dir, sub), exist_ok=True)
-            ref_sdf.visualize_query_points(q_np, sdf_np, os.path.join(model_out_dir, sub, shape_name + '.ply'))
-    except Exception:
-        pass
+    _visualize_query_points(q_np, sdf_np, os.path.join(model_out_dir, 'query_pts_ms_vis', shape_name + '.ply'))
 
 
 def _write_part(model_out_dir, shape_name, rank, sdf_np, q_np):
@@ -163,16 +182,20 @@ def _write_part(model_out_dir, shape_name, rank, sdf_np, q_np):
     os.replace(tmp, os.path.join(pdir, '%s.%d.npz' % (shape_name, rank)))
 
 
-def _assemble_if_complete(model_out_dir, shape_name, world):
-    """the rank that finds all pieces of a shape (and wins the lock) writes the reference's output files"""
+def _try_assemble(model_out_dir, shape_name, world, rank):
+    """write the reference's output files of a shape from the ordered pieces of all ranks.  Called after the barrier
+    (all pieces on disk); exactly one rank wins the atomic rename of piece 0 and assembles, the pieces are removed.
+    Returns True if this rank assembled the shape."""
     pdir = os.path.join(model_out_dir, '.parts')
     parts = [os.path.join(pdir, '%s.%d.npz' % (shape_name, r)) for r in range(world)]
     if not all(os.path.isfile(p) for p in parts):
         return False
+    claimed = parts[0] + '.claimed%d' % rank
     try:
-        os.close(os.open(os.path.join(pdir, shape_name + '.lock'), os.O_CREAT | os.O_EXCL | os.O_WRONLY))
-    except FileExistsError:
+        os.rename(parts[0], claimed)
+    except OSError:
         return False
+    parts[0] = claimed
     loaded = [np.load(p) for p in parts]
     _save_shape(model_out_dir, shape_name, np.concatenate([d['sdf'] for d in loaded]),
                 np.concatenate([d['q'] for d in loaded]))
@@ -181,21 +204,30 @@ def _assemble_if_complete(model_out_dir, shape_name, world):
     return True
 
 
+def _load_query_points(indir, shape_name):
+    """GT query points of the evaluation pass (reference source/data_loader.py:439-452, :36-49)"""
+    q = np.load(os.path.join(indir, '05_query_pts', shape_name + '.ply.npy'))
+    if q.dtype != np.float32:
+        print('Warning: imp_surf_query_point_ms must be converted to float32')
+        q = q.astype(np.float32)
+    return np.ascontiguousarray(q)
+
+
 def points_to_surf_eval(eval_opt):
     models = eval_opt.models.split()
     if eval_opt.seed < 0:
         eval_opt.seed = random.randint(1, 10000)
     if eval_opt.gpu_idx < 0:
         raise RuntimeError('points2surf_amd: --gpu_idx < 0 (CPU) is not available; the HIP engine needs an MI355X')
-    if not eval_opt.reconstruction:
-        raise NotImplementedError('the GT-query evaluation pass (random-rotation augmentation, needs trimesh) is '
-                                  'outside the accelerated path; use the reference implementation for it')
+    reconstruction = bool(eval_opt.reconstruction)
     if eval_opt.sampling != 'full':
         raise ValueError('Unknown sampling strategy: %s' % eval_opt.sampling)
-    if eval_opt.query_grid_resolution is None or eval_opt.epsilon is None:
+    if reconstruction and (eval_opt.query_grid_resolution is None or eval_opt.epsilon is None):
         raise ValueError('reconstruction needs --query_grid_resolution and --epsilon')
 
     world, rank, local_rank = _sharding.dist_env()
+    if world > 1 and 'MASTER_PORT' in os.environ:        # launched by torchrun (tests run "ranks" one after the other)
+        _sharding.init_process_group()
     device = torch.device('cuda', eval_opt.gpu_idx if world == 1 else local_rank)
     torch.cuda.set_device(device)
 
@@ -215,12 +247,14 @@ def points_to_surf_eval(eval_opt):
         with open(os.path.join(eval_opt.indir, eval_opt.dataset)) as f:
             shape_names = [x.strip() for x in f.readlines()]
         shape_names = list(filter(None, shape_names))
-        model_out_dir = os.path.join(eval_opt.outdir, 'rec')
+        model_out_dir = os.path.join(eval_opt.outdir, 'rec' if reconstruction else 'eval')
         os.makedirs(model_out_dir, exist_ok=True)
         print('getting information for {} shapes'.format(len(shape_names)))
 
         # one RNG stream over all shapes in dataset order (--workers 0 semantics of the reference)
         rng_dev = _engine.Rng(eval_opt.seed, device=device)
+        # the dataset's FIRST RandomState (data_loader.py:272): rand(3) per query -> rotation, GT-query pass only
+        rng_rot = None if reconstruction else _engine.Rng(eval_opt.seed, device=device)
         mine = set(range(len(shape_names)))
         if world > 1:
             sizes = [os.path.getsize(os.path.join(eval_opt.indir, '04_pts', n + '.xyz.npy'))
@@ -236,8 +270,28 @@ def points_to_surf_eval(eval_opt):
         per_shape_rng = os.environ.get('P2S_RNG_MODE', 'dataset') == 'per_shape'
         # P2S_SHARD=queries: every rank takes a contiguous query range of EVERY shape (few, large shapes; 512^3 grids)
         # instead of whole shapes; the RNG stream is advanced past the other ranks' queries, results stay identical
-        shard_queries = world > 1 and os.environ.get('P2S_SHARD', 'shapes') == 'queries' and not per_shape_rng
+        shard_queries = world > 1 and os.environ.get('P2S_SHARD', 'shapes') == 'queries' and not per_shape_rng \
+            and reconstruction
+        if shard_queries:
+            # stale pieces of an earlier run into the same outdir must not be mistaken for this run's
+            if rank == 0:
+                import shutil
+                shutil.rmtree(os.path.join(model_out_dir, '.parts'), ignore_errors=True)
+            _sharding.barrier()
         for shape_ind, shape_name in enumerate(shape_names):
+            if not reconstruction:
+                # GT-query pass: a few thousand given queries per shape and two dataset-wide streams -- rank 0 runs it
+                # alone (sharding it would cost more in stream skipping than the pass itself)
+                if rank != 0:
+                    continue
+                cloud = _engine.Cloud(_load_points(eval_opt.indir, shape_name), device=device)
+                q_np = _load_query_points(eval_opt.indir, shape_name)
+                sdf = _engine.infer_queries(model, cloud, rng_dev, rng_rot, torch.from_numpy(q_np).to(device), chunk=chunk)
+                sdf_np = sdf.cpu().numpy()
+                total_q += sdf_np.shape[0]
+                pending.append(writers.submit(_save_shape, model_out_dir, shape_name, sdf_np, q_np, False))
+                cloud.close()
+                continue
             if shard_queries:
                 cloud = _engine.Cloud(_load_points(eval_opt.indir, shape_name), device=device)
                 q_all = cloud.query_grid(eval_opt.query_grid_resolution, eval_opt.epsilon)
@@ -248,7 +302,6 @@ def points_to_surf_eval(eval_opt):
                 _sharding.skip_queries(cloud, rng_dev, cfg, q_all[q1:], model.sub_sample_size)
                 total_q += int(sdf.shape[0])
                 _write_part(model_out_dir, shape_name, rank, sdf.cpu().numpy(), q.cpu().numpy())
-                _assemble_if_complete(model_out_dir, shape_name, world)
                 cloud.close()
                 continue
             if per_shape_rng:
@@ -275,6 +328,20 @@ def points_to_surf_eval(eval_opt):
         dt = time.time() - t0
         if world > 1:
             _sharding.barrier()
+        if shard_queries:
+            # every piece is on disk (barrier): rank r takes the shapes i = r mod world first; the claim is atomic,
+            # so ranks run one after the other (tests) work too: the last one finds all pieces
+            order = sorted(range(len(shape_names)), key=lambda i: ((i - rank) % world, i))
+            for shape_ind in order:
+                _try_assemble(model_out_dir, shape_names[shape_ind], world, rank)
+            _sharding.barrier()
+        if rank == 0 and (world == 1 or _sharding.is_initialized()):
+            # all writers of all ranks have finished (barrier): every shape must have its files
+            want = ['eval'] + (['dist_ms', 'query_pts_ms'] if reconstruction else [])
+            missing = [os.path.join(model_out_dir, d, n + '.xyz.npy') for n in shape_names for d in want
+                       if not os.path.isfile(os.path.join(model_out_dir, d, n + '.xyz.npy'))]
+            if missing:
+                raise RuntimeError('points_to_surf_eval: outputs missing after the run: %s' % missing[:4])
         print('evaluated %d patches of %d shapes in %.2f s (%.0f queries/s on rank %d)'
               % (total_q, len(mine), dt, total_q / max(dt, 1e-9), rank))
         model.close()

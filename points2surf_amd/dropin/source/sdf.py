@@ -47,7 +47,15 @@ def add_samples_to_volume(vol, pos_ms, val):
     return out
 
 
+_IMPORT_PID = os.getpid()
+
+
 def propagate_sign(vol, sigma=5, certainty_threshold=13):
+    if os.getpid() != _IMPORT_PID:
+        # HIP contexts do not survive fork(): the reference's multiprocessing.Pool meshing workers
+        # (source/base/utils_mp.py:33-35) must not touch the device
+        raise RuntimeError('points2surf_amd: propagate_sign called in a forked worker process; the device stage runs '
+                           'in the parent (use source.sdf.implicit_surface_to_mesh_directory of the drop-in)')
     samples = getattr(vol, '_p2s_samples', None)
     if samples is None:
         # called on an already populated volume (not the implicit_surface_to_mesh sequence): the samples are the
@@ -59,6 +67,24 @@ def propagate_sign(vol, sigma=5, certainty_threshold=13):
     from points2surf_amd import engine
     dev_vol, _ = engine.sdf_volume(samples[0], samples[1], vol.shape[0], sigma, certainty_threshold, clamp=False)
     return dev_vol.cpu().numpy().astype(np.float64)
+
+
+def implicit_surface_to_mesh_directory(imp_surf_dist_ms_dir, query_pts_ms_dir, vol_out_dir, mesh_out_dir,
+                                       grid_res, sigma, certainty_threshold, num_processes=1):
+    """reference source/sdf.py:240-266 with the per-shape calls made serially in THIS process: the volume stage
+    runs on the GPU, and a HIP context cannot be used from the forked ``multiprocessing.Pool`` workers the reference
+    starts for ``num_processes > 1`` (full_eval.py passes ``--workers``).  ``num_processes`` is accepted and ignored:
+    one shape's propagation takes milliseconds on the device (149 s on a CPU core at 256^3)."""
+    from source.base import file_utils
+    os.makedirs(vol_out_dir, exist_ok=True)
+    os.makedirs(mesh_out_dir, exist_ok=True)
+    dist_files = [f for f in os.listdir(imp_surf_dist_ms_dir)
+                  if os.path.isfile(os.path.join(imp_surf_dist_ms_dir, f)) and f[-8:] == '.xyz.npy']
+    for f in dist_files:
+        f_dist, f_query = os.path.join(imp_surf_dist_ms_dir, f), os.path.join(query_pts_ms_dir, f)
+        f_vol, f_mesh = os.path.join(vol_out_dir, f[:-8] + '.off'), os.path.join(mesh_out_dir, f[:-8] + '.ply')
+        if file_utils.call_necessary([f_dist, f_query], [f_vol, f_mesh]):
+            _ref.implicit_surface_to_mesh_file(f_dist, f_query, f_vol, f_mesh, grid_res, sigma, certainty_threshold)
 
 
 # the reference's implicit_surface_to_mesh resolves both names in ITS module globals

@@ -98,6 +98,10 @@ class Model:
                                                     _stream_ptr(dev)))
         return fl, fg
 
+    def debug_fault_chunk(self, chunk_index):
+        """test hook: the next pipeline call fails with P2S_EHIP before chunk ``chunk_index`` (-1 = off)"""
+        _lib.check(self.lib.p2s_debug_fault_chunk(self.handle, int(chunk_index)))
+
     def set_profiling(self, on):
         _lib.check(self.lib.p2s_set_profiling(self.handle, int(bool(on))))
 
@@ -235,6 +239,14 @@ class Rng:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.p2s_rng_check(self.handle, _stream_ptr(self.device)))
 
+    def random_rotations(self, n):
+        """``n`` times ``trimesh.transformations.random_rotation_matrix(rng.rand(3))[:3, :3]`` from this stream
+        (reference source/data_loader.py:384) -> [n, 3, 3] float64 device tensor"""
+        rot = torch.empty((int(n), 3, 3), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_random_rotations(self.handle, int(n), _ptr(rot), _stream_ptr(self.device)))
+        return rot
+
     def subsample_uniform(self, cloud, n_queries, n, want_pts=True):
         """a6 (uniform): ids [Q,n] int32 (+ gathered points [Q,n,3])"""
         ids = torch.empty((n_queries, n), dtype=torch.int32, device=self.device)
@@ -287,6 +299,37 @@ def infer_shape(model, cloud, rng, grid_resolution, epsilon, q_begin=0, q_end=-1
                                        int(q_begin), int(qe), int(chunk), _ptr(sdf), _ptr(q), ctypes.byref(done),
                                        _stream_ptr(dev)))
     return sdf[:nq], (q[:nq] if q is not None else None)
+
+
+def rotate_points(rot, pts):
+    """``trimesh.transformations.transform_points(pts[i], M[i]).astype(float32)`` per item (reference
+    source/data_loader.py:385-393): rot [n,3,3] float64, pts [n,P,3] float32 device tensors -> [n,P,3] float32"""
+    lib = _lib.load()
+    dev = pts.device
+    pts = _f32c(pts, dev)
+    rot = rot.to(dev, torch.float64).contiguous()
+    n, P = int(pts.shape[0]), int(pts.shape[1])
+    if rot.shape != (n, 3, 3) or pts.shape != (n, P, 3):
+        raise ValueError('bad shapes %s %s' % (tuple(rot.shape), tuple(pts.shape)))
+    out = torch.empty_like(pts)
+    with torch.cuda.device(dev):
+        _lib.check(lib.p2s_rotate_points(_ptr(rot), _ptr(pts), P, n, _ptr(out), _stream_ptr(dev)))
+    return out
+
+
+def infer_queries(model, cloud, rng_sub, rng_rot, queries, chunk=0):
+    """GT-query evaluation pass for one shape (p2s_infer_queries): SDF at the given query points, with the
+    reference's per-query random rotation when ``rng_rot`` is given (reference source/data_loader.py:365-393).
+    Returns sdf [n] device tensor."""
+    dev = model.device
+    q = _f32c(queries, dev).reshape(-1, 3)
+    nq = int(q.shape[0])
+    sdf = torch.empty((max(nq, 1),), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(model.lib.p2s_infer_queries(model.handle, cloud.handle, rng_sub.handle,
+                                               rng_rot.handle if rng_rot is not None else None, _ptr(q), nq,
+                                               int(chunk), _ptr(sdf), _stream_ptr(dev)))
+    return sdf[:nq]
 
 
 def sdf_volume(query_pts_ms, query_dist_ms, grid_resolution, sigma, certainty_threshold, clamp=True):

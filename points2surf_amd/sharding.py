@@ -34,6 +34,11 @@ def assign_lpt(costs, world):
     return [sorted(x) for x in out]
 
 
+def is_initialized():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
@@ -101,15 +106,12 @@ def skip_queries(cloud, rng_dev, cfg, queries, sub_sample_size, chunk=4096):
 
 
 def skip_shape_stream(cloud, rng_dev, cfg, grid_resolution, epsilon, sub_sample_size, chunk=4096):
-    """Advance the dataset-wide RNG stream past one shape without running the encoders."""
+    """Advance the dataset-wide RNG stream past one shape without running the encoders and without
+    materialising ids (NULL-ids path of the C ABI: p2s_max = a count of session values, p2s_vanilla = tables +
+    offsets pass only)."""
     import torch
     q = cloud.query_grid(grid_resolution, epsilon)
-    Q = int(q.shape[0])
-    for s in range(0, Q, chunk):
-        if cfg.get('uniform_subsample'):
-            rng_dev.subsample_uniform(cloud, min(chunk, Q - s), sub_sample_size, want_pts=False)
-        else:
-            rng_dev.subsample_weighted(cloud, q[s:s + chunk], sub_sample_size, want_pts=False)
+    skip_queries(cloud, rng_dev, cfg, q, sub_sample_size, chunk=chunk)
     torch.cuda.synchronize()
     rng_dev.check()
-    return Q
+    return int(q.shape[0])

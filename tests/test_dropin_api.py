@@ -111,7 +111,9 @@ def test_sdf_bridge_reexports_reference_and_overrides_two_functions():
         assert ref.__file__.startswith(ref_shims.REFERENCE_ROOT)
         # re-exported reference functions (query grid helper is the reference's own object)
         assert sdf.get_voxel_centers_grid_smaller_pc is ref.get_voxel_centers_grid_smaller_pc
-        assert sdf.implicit_surface_to_mesh_directory is ref.implicit_surface_to_mesh_directory
+        assert sdf.implicit_surface_to_mesh_file is ref.implicit_surface_to_mesh_file
+        # the directory driver is the drop-in's serial one (HIP contexts do not survive the reference's fork pool)
+        assert sdf.implicit_surface_to_mesh_directory is not ref.implicit_surface_to_mesh_directory
         # the two overridden names are patched into the reference module too
         assert ref.propagate_sign is sdf.propagate_sign and ref.add_samples_to_volume is sdf.add_samples_to_volume
         v = sdf.add_samples_to_volume(np.zeros((8, 8, 8)), np.zeros((1, 3), np.float32), np.ones(1, np.float32))
@@ -129,23 +131,30 @@ def test_sdf_bridge_reexports_reference_and_overrides_two_functions():
 
 
 def test_query_range_parts_are_assembled_once_and_in_order(dropin_source, tmp_path):
-    """P2S_SHARD=queries: each rank leaves its ordered piece; whoever completes the set writes the reference's output
-    files exactly once (lock), pieces concatenated in rank order, part files removed"""
+    """P2S_SHARD=queries: each rank leaves its ordered piece; once the set is complete exactly one rank wins the
+    atomic claim and writes the reference's output files, pieces concatenated in rank order, part files removed --
+    and a second run into the same directory is not blocked by leftovers (no lock files)"""
     import numpy as np
     ev, _ = dropin_source
     out = str(tmp_path / 'rec')
     world = 3
     rng = np.random.default_rng(0)
-    pieces = [(rng.standard_normal(n).astype(np.float32), rng.standard_normal((n, 3)).astype(np.float32)) for n in (5, 0, 7)]
-    for rank in (2, 0):                                   # out of order, one rank still missing
-        ev._write_part(out, 'shapeA', rank, *pieces[rank])
-        assert ev._assemble_if_complete(out, 'shapeA', world) is False
-    ev._write_part(out, 'shapeA', 1, *pieces[1])
-    assert ev._assemble_if_complete(out, 'shapeA', world) is True
-    assert ev._assemble_if_complete(out, 'shapeA', world) is False          # parts gone, lock taken
-    sdf = np.load(os.path.join(out, 'dist_ms', 'shapeA.xyz.npy'))
-    q = np.load(os.path.join(out, 'query_pts_ms', 'shapeA.xyz.npy'))
-    assert np.array_equal(sdf, np.concatenate([p[0] for p in pieces]))
-    assert np.array_equal(q, np.concatenate([p[1] for p in pieces]))
-    assert np.array_equal(np.load(os.path.join(out, 'eval', 'shapeA.xyz.npy')), sdf)
-    assert not [f for f in os.listdir(os.path.join(out, '.parts')) if f.endswith('.npz')]
+    for run in range(2):
+        pieces = [(rng.standard_normal(n).astype(np.float32), rng.standard_normal((n, 3)).astype(np.float32)) for n in (5, 0, 7)]
+        for rank in (2, 0):                                   # out of order, one rank still missing
+            ev._write_part(out, 'shapeA', rank, *pieces[rank])
+            assert ev._try_assemble(out, 'shapeA', world, rank) is False
+        ev._write_part(out, 'shapeA', 1, *pieces[1])
+        assert ev._try_assemble(out, 'shapeA', world, 1) is True
+        assert ev._try_assemble(out, 'shapeA', world, 0) is False          # parts gone
+        sdf = np.load(os.path.join(out, 'dist_ms', 'shapeA.xyz.npy'))
+        q = np.load(os.path.join(out, 'query_pts_ms', 'shapeA.xyz.npy'))
+        assert np.array_equal(sdf, np.concatenate([p[0] for p in pieces]))
+        assert np.array_equal(q, np.concatenate([p[1] for p in pieces]))
+        assert np.array_equal(np.load(os.path.join(out, 'eval', 'shapeA.xyz.npy')), sdf)
+        assert os.listdir(os.path.join(out, '.parts')) == []
+        # the visualisations of the file contract (sdf.visualize_query_points) are written without trimesh
+        from points2surf_amd import ply
+        v, f = ply.read_ply(os.path.join(out, 'query_pts_ms_vis', 'shapeA.ply'))
+        assert np.array_equal(v.astype(np.float32), q) and f.shape[0] == 0
+        assert os.path.isfile(os.path.join(out, 'vis', 'shapeA.ply'))
