@@ -73,7 +73,9 @@ def cpu_baseline(w, cfg, cloud, queries, target_seconds, grid_res=GRID_RES):
     """the torch-CPU port on the first n queries of the same workload; returns (record, sdf[:n])"""
     import torch
     from oracle.torch_port import TorchPort
-    torch.set_num_threads(os.cpu_count())
+    # torch's default intra-op pool = the physical cores (128 on the MI355X host); all 256 SMT threads measured 13x
+    # slower (5.6 vs 75 queries/s).  Pinned explicitly so the figure does not depend on the environment.
+    torch.set_num_threads(int(os.environ.get('P2S_CPU_THREADS', max(1, (os.cpu_count() or 2) // 2))))
     port = TorchPort(w, cfg)
     threads = torch.get_num_threads()
     rng = np.random.RandomState(SEED_DATA)

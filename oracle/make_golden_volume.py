@@ -21,14 +21,14 @@ def main():
     out = {}
     for model in ('p2s_max', 'p2s_vanilla'):
         sdf = np.load(os.path.join(GOLDEN, 'ref_%s_grid32.npz' % model))['sdf_full']
-        for sigma, thr in ((5, 13), (3, 5)):
+        for sigma, thr in ((5, 13), (3, 5), (4, 9.5), (2, 3), (6, 40)):   # even sigma: scipy's convolve origin
             vol = np.zeros((32, 32, 32))
             vol = ref_sdf.add_samples_to_volume(vol, q, sdf)
             vol = ref_sdf.propagate_sign(vol, sigma, thr)
             vol[vol < -1.0] = -1.0
             vol[vol > 1.0] = 1.0
             assert np.array_equal(vol.astype(np.float32).astype(np.float64), vol)   # float32 is lossless here
-            out['%s_s%d_t%d' % (model, sigma, thr)] = vol.astype(np.float32)
+            out['%s_s%d_t%g' % (model, sigma, thr)] = vol.astype(np.float32)
             print(model, sigma, thr, 'neg/zero/pos', (vol < 0).sum(), (vol == 0).sum(), (vol > 0).sum())
     np.savez_compressed(os.path.join(GOLDEN, 'ref_volume_grid32.npz'), **out)
 

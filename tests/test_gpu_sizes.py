@@ -1,0 +1,88 @@
+"""GPU parity at the sizes the metric is quoted on (VERDICT r1 'next' item 1): full query grids against goldens the
+UNMODIFIED reference wrote on CPU (oracle/make_golden_sizes.py) -- every query of the 128^3 grid (BASELINE
+configs[1]) and of the 256^3 grid (configs[2]) of the abc_minimal test shape, and the three abc_minimal clouds in one
+dataset (one RNG stream across shapes) at grids 32 and 64.  Tolerance: the north_star's 1e-4 on the SDF, and ZERO
+sign flips (what the mesh depends on)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+FIX = os.path.join(GOLDEN, 'abc_minimal')
+SEED = 40938661
+
+
+def _names(dataset):
+    with open(os.path.join(FIX, dataset + '.txt')) as f:
+        return [x.strip() for x in f if x.strip()]
+
+
+def _golden(job, model, dataset, res):
+    key = 'ref_%s_%s_%s_grid%d' % (job, model, dataset, res)
+    path = os.path.join(GOLDEN, key + '.npz')
+    if not os.path.isfile(path):
+        pytest.skip('%s not generated (hours of reference CPU time; see oracle/make_golden_sizes.py)' % key)
+    with open(os.path.join(GOLDEN, 'meta_sizes.json')) as f:
+        meta = json.load(f)[key]
+    return np.load(path), meta
+
+
+def _run_dataset(model_name, dataset, res):
+    """what points_to_surf_eval does for a dataset in reconstruction mode: one stream over all shapes"""
+    import torch
+    from points2surf_amd import engine, synth
+    w, cfg = synth.make_weights(model_name)
+    model = engine.Model(w, cfg)
+    rng = engine.Rng(SEED)
+    out = []
+    for n in _names(dataset):
+        cloud = engine.Cloud(np.load(os.path.join(FIX, '04_pts', n + '.xyz.npy')))
+        sdf, q = engine.infer_shape(model, cloud, rng, res, 3)
+        torch.cuda.synchronize()
+        out.append((sdf.cpu().numpy(), q.cpu().numpy()))
+        cloud.close()
+    rng.check()
+    model.close()
+    return out
+
+
+def _compare(out, g, meta, tol=1e-4):
+    worst, flips, total = 0.0, 0, 0
+    for i, (sdf, q) in enumerate(out):
+        ref = g['rec_%d' % i]
+        assert sdf.shape == ref.shape, (sdf.shape, ref.shape)
+        assert hashlib.sha256(np.ascontiguousarray(q).tobytes()).hexdigest() == meta['shapes'][i]['query_sha256']
+        worst = max(worst, float(np.abs(sdf - ref).max()))
+        flips += int((np.sign(sdf) != np.sign(ref)).sum())
+        total += sdf.size
+    print('max|dSDF| %.3g, sign flips %d / %d queries' % (worst, flips, total))
+    assert worst < tol and flips == 0, (worst, flips)
+
+
+@pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
+def test_full_grid128_matches_reference(model):
+    """BASELINE configs[1]: every one of the 68,088 queries of the 128^3 grid"""
+    g, meta = _golden('rec', model, 'testset', 128)
+    _compare(_run_dataset(model, 'testset', 128), g, meta)
+
+
+@pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
+def test_full_grid256_matches_reference(model):
+    """BASELINE configs[2] (the benchmarked workload): every one of the 307,237 queries of the 256^3 grid"""
+    g, meta = _golden('rec', model, 'testset', 256)
+    _compare(_run_dataset(model, 'testset', 256), g, meta)
+
+
+@pytest.mark.parametrize('res', [32, 64])
+@pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
+def test_three_clouds_one_stream_matches_reference(model, res):
+    """all three abc_minimal clouds (34,693 / 59,979 / 86,648 points) as ONE dataset: the second and third shape
+    depend on the stream position the previous ones left (data_loader.py:274-277)"""
+    job = 'fulleval' if res == 32 else 'rec'
+    g, meta = _golden(job, model, 'abc3', res)
+    _compare(_run_dataset(model, 'abc3', res), g, meta)

@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
-@pytest.mark.parametrize('sigma,thr', [(5, 13), (3, 5)])
+@pytest.mark.parametrize('sigma,thr', [(5, 13), (3, 5), (4, 9.5), (2, 3), (6, 40)])   # odd and EVEN kernels
 def test_sdf_volume_matches_reference_golden(golden_dir, model, sigma, thr):
     from points2surf_amd import engine
     g = np.load(os.path.join(golden_dir, 'ref_volume_grid32.npz'))
@@ -16,7 +16,7 @@ def test_sdf_volume_matches_reference_golden(golden_dir, model, sigma, thr):
     sdf = np.load(os.path.join(golden_dir, 'ref_%s_grid32.npz' % model))['sdf_full']
     vol, iters = engine.sdf_volume(q, sdf, 32, sigma, thr)
     assert iters >= 1
-    assert np.array_equal(vol.cpu().numpy(), g['%s_s%d_t%d' % (model, sigma, thr)])   # bit-exact
+    assert np.array_equal(vol.cpu().numpy(), g['%s_s%d_t%g' % (model, sigma, thr)])   # bit-exact
 
 
 @pytest.mark.parametrize('res,sigma,thr', [(64, 5, 13.0), (48, 4, 9.5), (96, 5, 13.0)])

@@ -131,7 +131,7 @@ def test_torch_port_matches_reference(golden_dir, fixture_cloud, meta, model):
 
 
 @pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
-@pytest.mark.parametrize('sigma,thr', [(5, 13), (3, 5)])
+@pytest.mark.parametrize('sigma,thr', [(5, 13), (3, 5), (4, 9.5), (2, 3), (6, 40)])   # odd and EVEN kernels
 def test_sdf_volume_matches_reference(golden_dir, model, sigma, thr):
     """row f-1: add_samples_to_volume + propagate_sign + clamp vs the unmodified reference"""
     g = np.load(os.path.join(golden_dir, 'ref_volume_grid32.npz'))
@@ -139,4 +139,4 @@ def test_sdf_volume_matches_reference(golden_dir, model, sigma, thr):
     sdf = np.load(os.path.join(golden_dir, 'ref_%s_grid32.npz' % model))['sdf_full']
     vol = O.sdf_volume(q, sdf, 32, sigma, thr)
     assert vol.dtype == np.float64
-    assert np.array_equal(vol, g['%s_s%d_t%d' % (model, sigma, thr)].astype(np.float64))
+    assert np.array_equal(vol, g['%s_s%d_t%g' % (model, sigma, thr)].astype(np.float64))
