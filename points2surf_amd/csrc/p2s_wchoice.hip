@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
                                                         WcPlanDev plan, int K, float *__restrict__ dist_all,
                                                         double *__restrict__ S_all, WcRec *__restrict__ R_all,
                                                         double *__restrict__ stot_all, float *__restrict__ pmax_all,
-                                                        long long *__restrict__ err) {
+                                                        float *__restrict__ mu_all, int nsel, long long *__restrict__ err) {
     __shared__ float nodes[WC_MAX_NODES];
     __shared__ float red_f[4];
     __shared__ double red_d[4];
@@ -129,25 +129,40 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
     const float sum = nodes[plan.root];
 
     // pass 3: p_i = pc_i / sum (float32, kept in place of the distance) and the total mass S_N (exact in any order)
-    double acc = 0.0;
+    double acc = 0.0, acc2 = 0.0, acc3 = 0.0;
     float pm = 0.0f;
     for (int i = tid; i < n; i += 256) {
         const float pi = wc_clip_prob(dist[i], dmax) / sum;
         dist[i] = pi;
         acc += (double)pi;
+        acc2 += (double)pi * (double)pi;              // power sums: expected collisions of the first round (below)
+        acc3 += (double)pi * (double)pi * (double)pi;
         pm = fmaxf(pm, pi);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         acc += __shfl_xor(acc, off);
+        acc2 += __shfl_xor(acc2, off);
+        acc3 += __shfl_xor(acc3, off);
         pm = fmaxf(pm, __shfl_xor(pm, off));
     }
+    __shared__ double red_2[4], red_3[4];
     if (lane == 0) {
         red_d[wave] = acc;
+        red_2[wave] = acc2;
+        red_3[wave] = acc3;
         red_f[wave] = pm;
     }
     __syncthreads();
     const double Stot = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
+    if (tid == 0) {
+        // E[nsel - #distinct bins of nsel draws] = C(nsel,2) sum p^2 - C(nsel,3) sum p^3 + ...: where the speculation
+        // windows of the offsets pass are centred (a prediction only -- never part of the result)
+        const double s2 = ((red_2[0] + red_2[1]) + (red_2[2] + red_2[3])) / (Stot * Stot);
+        const double s3 = ((red_3[0] + red_3[1]) + (red_3[2] + red_3[3])) / (Stot * Stot * Stot);
+        const double ns = (double)nsel;
+        mu_all[qi] = (float)(0.5 * ns * (ns - 1.0) * s2 - ns * (ns - 1.0) * (ns - 2.0) / 6.0 * s3);
+    }
     if (tid == 0) {
         // pmax, and the number of cells of the close-pair grid of the serial kernel: pitch 1/G >= pmax / S_N
         const float pmx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
@@ -565,6 +580,7 @@ struct WcArgs {
     int32_t *ids_out;         // [nq][nsel]
     long long *meta;          // [0] words consumed (out), [1] sticky error
     long long *stats;         // development counters (null = off): [0] fallbacks, [1] window misses
+    const long long *ctl;     // serial kernel: start at query ctl[0], word ctl[1] (null = query 0, word meta[0])
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -628,7 +644,21 @@ __host__ __device__ inline size_t wc_offsets_lds_bytes(int n) {
     return wc_lds_bytes(n) + (size_t)WC_RING * 4 + 2 * WC_SLOTS * 4 + WC_LIST * 16;
 }
 
-__global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
+__global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a_in) {
+    WcArgs a = a_in;
+    long long ctl_base = -1;
+    if (a.ctl) {
+        // remainder after the speculative passes (normally nothing): continue at query ctl[0], word ctl[1]
+        const long long q0 = a.ctl[0];
+        if (q0 >= a.nq) return;
+        ctl_base = a.ctl[1];
+        a.S += (size_t)q0 * a.n;
+        a.R += (size_t)q0 * a.K;
+        a.stot += q0;
+        a.pmax += 2 * q0;
+        a.base += q0;
+        a.nq -= (int)q0;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
     __shared__ int wsum[16];
     __shared__ double wsumd[16];
@@ -659,7 +689,7 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
     }
 
     // ring: words [.., r_hi) of the request are resident at ring[w & (RING-1)]
-    const long long base0 = a.meta[0];              // word cursor of the session: where this call's first query starts
+    const long long base0 = ctl_base >= 0 ? ctl_base : a.meta[0];   // word cursor: where this call's first query starts
     long long r_hi = base0 & ~3LL;
     auto ring_fill = [&](long long upto) {           // synchronous (prologue / after falling behind)
         upto = upto < a.cap_words ? upto : a.cap_words;
@@ -995,6 +1025,300 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a) {
     if (a.stats && tid < 16) a.stats[tid] = s_stats[tid];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// offsets, parallel: speculation tables + a light chain (default; the serial kernel above remains as the fallback).
+//
+// The only serial dependence is the word offset: query q starts at s_q = s_{q-1} + 2 (nsel + R_{q-1}), R = redraws.
+// R_q is a function of the start alone: with X_k the k-th double of the stream and bin_q() the query's cdf look-up,
+//     m2(s) = nsel - #distinct{ bin_q(X_k) : s <= k < s + nsel }          (first-round draws hitting a taken bin)
+// and round 3 is impossible when the m2 redraws X_{s+nsel} .. X_{s+nsel+m2-1} are pairwise farther apart than the
+// widest bin of the modified cdf (same tests as the serial kernel), so R(s) = m2(s) for such s.
+//   wc_spec_kernel   one workgroup per query of a block of SP_B queries, all CUs: R_q(s) for the SP_W candidate
+//                    starts around the predicted one (block start, exact, + sum of the expected collision counts mu
+//                    of the queries before it, from the tables kernel).  m2 over a sliding window: every draw e with
+//                    an earlier draw prev(e) in the same bin adds 1 to the starts in (e - nsel, prev(e)] -- a difference
+//                    array + scan; draws sharing a bin are found through an LDS hash.  255 = undecided here.
+//   wc_chain_kernel  one workgroup: s -> s + 2 (nsel + R_q(s)) is a table look-up per query; undecided candidates
+//                    (~1-5 % of the queries) run the complete algorithm in place (wc_full_query); a start outside the
+//                    window ends the block early, the next (spec, chain) pair resumes there.
+// The ids kernel re-derives every query's consumption and flags any disagreement (meta[1] = 4).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SP_B = 512;                            // queries per speculation block
+constexpr int SP_W = 1024;                           // candidate starts per query
+constexpr int SP_LOOK = 64;                          // round-2 draws decided by the distance test
+constexpr int SP_NB = SP_W + WC_MAX_SEL;             // draws whose bin is needed
+constexpr int SP_NX = SP_NB + 2 * SP_LOOK;           // doubles held
+constexpr int SP_HASH = 4096;
+constexpr int SP_DMAX = 1024;                        // draws that share their bin with another draw of the window
+struct WcSpec {
+    unsigned char *rtab;      // [SP_B][SP_W] redraws for candidate start klo + 2 d; 255 = undecided
+    long long *klo;           // [SP_B] word offset of candidate 0
+    long long *ctl;           // [0] first unresolved query, [1] its word offset
+    const float *mu;          // [nq] expected first-round collisions
+};
+
+__global__ void wc_ctl_init_kernel(long long *ctl, const long long *meta) {
+    ctl[0] = 0;
+    ctl[1] = meta[0];
+}
+
+__global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
+    __shared__ double xs[SP_NX];
+    __shared__ int bins[SP_NB];
+    __shared__ __attribute__((aligned(16))) uint32_t hkey[SP_HASH];      // later: diff[SP_W + 1] and nd[SP_W + SP_LOOK]
+    __shared__ int2 dl[SP_DMAX];
+    __shared__ int s_ndup, wsum[4];
+    __shared__ float redf[4];
+    if (a.meta[1] != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long qb = sp.ctl[0], sb = sp.ctl[1];
+    const int i = blockIdx.x;
+    const long long q = qb + i;
+    if (q >= a.nq) return;
+    // predicted start: the block start (exact) + the expected redraws of the queries before this one
+    float part = 0.0f;
+    for (int j = tid; j < i; j += 256) part += sp.mu[qb + j];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) redf[wave] = part;
+    if (tid == 0) s_ndup = 0;
+    for (int h = tid; h < SP_HASH; h += 256) hkey[h] = 0xffffffffu;
+    __syncthreads();
+    long long dpre = (long long)((redf[0] + redf[1]) + (redf[2] + redf[3]) + 0.5f) - SP_W / 2;
+    dpre = dpre < 0 ? 0 : dpre;
+    const long long klo = sb + 2 * ((long long)i * a.nsel + dpre);
+    if (tid == 0) sp.klo[i] = klo;
+    const int nsel = a.nsel, nb = SP_W + nsel, nx = nb + 2 * SP_LOOK;
+    const double *Sq = a.S + (size_t)q * a.n;
+    const WcRec *Rq = a.R + (size_t)q * a.K;
+    const double Stot = a.stot[q];
+    // ---- doubles of the window and their bins (first-round look-up, as wc_window_sync)
+    for (int e = tid; e < nx; e += 256) {
+        const long long w = klo + 2LL * e;
+        double x = 2.0;                               // past the request: never "far" from anything -> undecided
+        int bin = -1;
+        if (w + 1 < a.cap_words) {
+            const uint2 wp = *(const uint2 *)(a.words + w);
+            x = wc_double(wp.x, wp.y);
+            if (e < nb) {
+                int bk = (int)(x * (double)a.K);
+                bk = bk > a.K - 1 ? a.K - 1 : bk;
+                const WcRec rec = Rq[bk];
+                bin = wc_quick_bin(rec.c0, rec.i, rec.more, x);
+                if (bin < 0) bin = wc_finish(Sq, a.n, rec.i + 1, 0, a.n, 0.0, Stot, x).bin;
+            }
+        }
+        xs[e] = x;
+        if (e < nb) bins[e] = bin;
+    }
+    __syncthreads();
+    // ---- draws that share their bin with another draw of the window: hash bin -> count
+    constexpr int PER = (SP_NB + 255) / 256;
+    int slot[PER];
+    bool overflow = false;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int e = tid + 256 * j;
+        slot[j] = -1;
+        if (e < nb && bins[e] >= 0) {
+            const uint32_t bin = (uint32_t)bins[e];
+            uint32_t h = (bin * 2654435761u) >> 20;
+            for (;;) {
+                uint32_t cur = hkey[h];
+                if (cur == 0xffffffffu) {
+                    const uint32_t old = atomicCAS(&hkey[h], 0xffffffffu, (bin << 10) | 1u);
+                    if (old == 0xffffffffu) break;
+                    cur = old;
+                }
+                if ((cur >> 10) == bin) {
+                    if ((atomicAdd(&hkey[h], 1u) & 1023u) >= 1000u) overflow = true;     // count field about to overflow
+                    break;
+                }
+                h = (h + 1) & (SP_HASH - 1);
+            }
+            slot[j] = (int)h;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        if (slot[j] >= 0 && (hkey[slot[j]] & 1023u) >= 2u) {
+            const int k = atomicAdd(&s_ndup, 1);
+            if (k < SP_DMAX) dl[k] = make_int2(tid + 256 * j, bins[tid + 256 * j]);
+        }
+    }
+    const bool any_over = __syncthreads_or(overflow ? 1 : 0) != 0;
+    const bool undecidable = any_over || s_ndup > SP_DMAX;
+    const int ndup = s_ndup < SP_DMAX ? s_ndup : SP_DMAX;
+    int *diff = (int *)hkey;                                       // [SP_W + 1]
+    unsigned char *nd = (unsigned char *)(diff + SP_W + 4);        // [SP_W + SP_LOOK]
+    for (int d = tid; d <= SP_W; d += 256) diff[d] = 0;
+    __syncthreads();
+    // ---- m2(d): draw e with an earlier same-bin draw prev counts for the starts d in (e - nsel, prev]
+    for (int t = tid; t < ndup; t += 256) {
+        const int e = dl[t].x, b = dl[t].y;
+        int prev = -1;
+        for (int u = 0; u < ndup; ++u) {
+            const int2 o = dl[u];
+            if (o.y == b && o.x < e && o.x > prev) prev = o.x;
+        }
+        if (prev >= 0) {
+            const int lo = e - nsel + 1 > 0 ? e - nsel + 1 : 0;
+            const int hi = prev < SP_W - 1 ? prev : SP_W - 1;
+            if (lo <= hi) {
+                atomicAdd(&diff[lo], 1);
+                atomicAdd(&diff[hi + 1], -1);
+            }
+        }
+    }
+    // ---- nd[e - nsel]: distance to the first later draw within reach of the widest bin of the modified cdf
+    const double pm = (double)a.pmax[2 * q];
+    const double denom = Stot - (double)nsel * pm;
+    const bool dist_ok = denom > 0.25 * Stot;
+    const double wmax = dist_ok ? (pm / denom) * (1.0 + 1e-9) : 2.0;
+    for (int r = tid; r < SP_W + SP_LOOK; r += 256) {
+        const int e = nsel + r;
+        const double x = xs[e];
+        int best = 255;
+        for (int j = 1; j < SP_LOOK; ++j) {
+            if (fabs(x - xs[e + j]) <= wmax) {
+                best = j;
+                break;
+            }
+        }
+        nd[r] = (unsigned char)best;
+    }
+    __syncthreads();
+    // ---- scan of the difference array (4 candidates per lane) and the verdict per candidate
+    const int d0 = 4 * tid;
+    int c[4];
+    c[0] = diff[d0];
+    c[1] = c[0] + diff[d0 + 1];
+    c[2] = c[1] + diff[d0 + 2];
+    c[3] = c[2] + diff[d0 + 3];
+    int v = c[3];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(v, off);
+        if (lane >= off) v += u;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int run = v - c[3];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) run += wsum[w];
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int d = d0 + j;
+        const int m2 = run + c[j];
+        unsigned r = 255u;
+        const long long s = klo + 2LL * d;
+        if (!undecidable && s + 2LL * (nsel + m2) <= a.cap_words) {
+            if (m2 == 0) {
+                r = 0u;
+            } else if (m2 <= SP_LOOK && dist_ok) {
+                bool bad = false;
+                for (int e = 0; e < m2; ++e) {
+                    const int reach = nd[d + e];
+                    bad |= (reach != 255) && (e + reach < m2);
+                }
+                if (!bad) r = (unsigned)m2;
+            }
+        }
+        packed |= r << (8 * j);
+    }
+    ((uint32_t *)(sp.rtab + (size_t)i * SP_W))[tid] = packed;
+}
+
+__global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
+    __shared__ int wsum[16];
+    __shared__ double wsumd[16];
+    __shared__ long long s_klo[SP_B];
+    __shared__ long long s_ev[3];
+    if (a.meta[1] != 0) return;
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    const long long qb = sp.ctl[0];
+    if (qb >= a.nq) return;
+    const WcLds l = wc_carve(wc_lds, a.n);
+    const int BW = (a.n + 31) >> 5;
+    for (int i = tid; i < BW; i += 256) l.bitmap[i] = 0;
+    const int lim = (int)(a.nq - qb < SP_B ? a.nq - qb : SP_B);
+    for (int i = tid; i < lim; i += 256) s_klo[i] = sp.klo[i];
+    long long s = sp.ctl[1];
+    int i = 0;
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) {
+            int ev = 2;                               // 1 undecided candidate, 2 end of block / outside the window, 3 words exhausted
+            while (i < lim) {
+                if (s + 2LL * a.nsel > a.cap_words) {
+                    ev = 3;
+                    break;
+                }
+                const long long d = (s - s_klo[i]) >> 1;
+                if (d < 0 || d >= SP_W) break;
+                const unsigned r = sp.rtab[(size_t)i * SP_W + d];
+                if (r == 255u) {
+                    ev = 1;
+                    break;
+                }
+                a.base[qb + i] = s;
+                s += 2LL * (a.nsel + (int)r);
+                ++i;
+            }
+            s_ev[0] = ev;
+            s_ev[1] = i;
+            s_ev[2] = s;
+        }
+        __syncthreads();
+        const int ev = (int)s_ev[0];
+        i = (int)s_ev[1];
+        s = s_ev[2];
+        __syncthreads();
+        if (ev == 3) {
+            if (tid == 0) {
+                a.meta[1] = 2;
+                a.meta[0] = s;
+            }
+            return;
+        }
+        if (ev != 1) break;
+        WcQuery qa;
+        qa.Sq = a.S + (size_t)(qb + i) * a.n;
+        qa.Rq = a.R + (size_t)(qb + i) * a.K;
+        qa.Stot = a.stot[qb + i];
+        qa.words = a.words + s;
+        qa.words_left = a.cap_words - s;
+        qa.n = a.n;
+        qa.K = a.K;
+        qa.nsel = a.nsel;
+        const long long used = wc_full_query<false>(qa, l, wsum, wsumd, nullptr);
+        if (used < 0) {
+            if (tid == 0) {
+                a.meta[1] = 3;
+                a.meta[0] = s;
+            }
+            return;
+        }
+        if (tid == 0) a.base[qb + i] = s;
+        s += used;
+        ++i;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        sp.ctl[0] = qb + i;
+        sp.ctl[1] = s;
+        if (qb + i >= a.nq) a.meta[0] = s;
+        if (a.stats) {
+            atomicAdd((unsigned long long *)&a.stats[11], 1ull);            // (spec, chain) pairs that did work
+        }
+    }
+}
+
 // ids: one workgroup per query, every query's word offset known -> the full algorithm in parallel
 __global__ __launch_bounds__(256) void wc_ids_kernel(WcArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
@@ -1125,7 +1449,8 @@ int wc_reserve(p2s_rng_s *r, size_t nq, size_t n, size_t K) {
     r->wc_cap_q = r->wc_cap_n = r->wc_cap_k = 0;
     nq = std::max(nq, r->wc_cap_q);
     if (hipMalloc(&r->wc_dist, nq * n * 4) != hipSuccess || hipMalloc(&r->wc_S, nq * n * 8) != hipSuccess ||
-        hipMalloc(&r->wc_T, nq * K * sizeof(WcRec)) != hipSuccess || hipMalloc(&r->wc_stot, nq * 24) != hipSuccess) {
+        hipMalloc(&r->wc_T, nq * K * sizeof(WcRec)) != hipSuccess ||
+        hipMalloc(&r->wc_stot, nq * 32 + (size_t)SP_B * SP_W + (size_t)SP_B * 8 + 64) != hipSuccess) {
         (void)hipGetLastError();
         p2s_set_error("weighted sub-sample: hipMalloc of the per-query tables failed (%zu queries x %zu points)", nq, n);
         return P2S_ENOMEM;
@@ -1194,10 +1519,18 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
     plan.n_leaves = c->wc_leaves;
     plan.n_levels = c->wc_levels;
     plan.root = c->wc_root;
-    // per-query scalars share one allocation: [stot f64][base i64][pmax f32, cells i32]
+    // per-query scalars share one allocation: [stot f64][base i64][pmax f32, cells i32][mu f32, pad], followed by the
+    // speculation block: [ctl i64 x 8][klo i64 x SP_B][rtab u8 x SP_B x SP_W]
     double *stot = r->wc_stot;
     long long *base = (long long *)(stot + r->wc_cap_q);
     float *pmax = (float *)(base + r->wc_cap_q);
+    float *mu = pmax + 2 * r->wc_cap_q;
+    WcSpec sp;
+    sp.ctl = (long long *)(mu + 2 * r->wc_cap_q);
+    sp.klo = sp.ctl + 8;
+    sp.rtab = (unsigned char *)(sp.klo + SP_B);
+    sp.mu = mu;
+    const bool serial_only = getenv("P2S_WC_SERIAL") != nullptr;            // development / A-B: the serial kernel alone
     const size_t lds_ids = wc_lds_bytes(n);
     size_t lds_off = wc_offsets_lds_bytes(n);
     // the offsets kernel is one latency-bound workgroup running next to the MFMA-saturated encoders: give it a CU of
@@ -1211,6 +1544,7 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
     {   // per device (a process may drive several); the call is cheap
         (void)hipFuncSetAttribute((const void *)wc_offsets_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         (void)hipFuncSetAttribute((const void *)wc_ids_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void *)wc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     }
     long long *meta = p2s_rng_raw_meta(r);
     static long long *stats_dev = nullptr;
@@ -1221,7 +1555,7 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
         rc = p2s_rng_session_raw(r, (long long)(2.0 * n_sel * 1.15 * cur) + margin, s);
         if (rc) return rc;
         hipLaunchKernelGGL(wc_tables_kernel, dim3(cur), dim3(256), 0, s, c->d.pts, n, q_dev + (size_t)done * 3, plan, K,
-                           r->wc_dist, r->wc_S, (WcRec *)r->wc_T, stot, pmax, meta);
+                           r->wc_dist, r->wc_S, (WcRec *)r->wc_T, stot, pmax, mu, n_sel, meta);
         WcArgs a;
         a.S = r->wc_S;
         a.R = (const WcRec *)r->wc_T;
@@ -1238,11 +1572,26 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
         a.ids_out = ids_out_dev ? ids_out_dev + (size_t)done * n_sel : nullptr;
         a.meta = meta;
         a.stats = nullptr;
+        a.ctl = nullptr;
         if (want_stats) {
             (void)hipMemsetAsync(stats_dev, 0, 16 * 8, s);
             a.stats = stats_dev;
         }
-        hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(WC_NT), lds_off, s, a);
+        if (serial_only) {
+            hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(WC_NT), lds_off, s, a);
+        } else {
+            // speculation tables on all CUs + a light chain per block of SP_B queries; two spare pairs for blocks that
+            // end early (start outside the window); whatever is still unresolved then goes through the serial kernel
+            hipLaunchKernelGGL(wc_ctl_init_kernel, dim3(1), dim3(1), 0, s, sp.ctl, meta);
+            const int pairs = (cur + SP_B - 1) / SP_B + (cur > SP_B / 2 ? 2 : 0);
+            for (int pr = 0; pr < pairs; ++pr) {
+                hipLaunchKernelGGL(wc_spec_kernel, dim3(std::min(cur, SP_B)), dim3(256), 0, s, a, sp);
+                hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), lds_ids, s, a, sp);
+            }
+            a.ctl = sp.ctl;
+            hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(WC_NT), wc_offsets_lds_bytes(n), s, a);
+            a.ctl = nullptr;
+        }
         if (ids_out_dev) hipLaunchKernelGGL(wc_ids_kernel, dim3(cur), dim3(256), lds_ids, s, a);   // NULL: advance the stream only
         P2S_LAUNCH_CHECK("weighted sub-sample kernels");
         if (want_stats) {
@@ -1251,7 +1600,7 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
             (void)hipStreamSynchronize(s);
             fprintf(stderr, "[wc stats] %d queries: %lld full-algorithm fallbacks, %lld window misses; 10-ns ticks: "
                             "A %lld issue %lld mark %lld sepcheck %lld clear+fallback %lld B %lld ring %lld; kernel %lld ticks = "
-                            "%lld shader clocks\n", cur, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
+                            "%lld shader clocks; chain passes that did work %lld\n", cur, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
         }
         done += cur;
     }

@@ -19,6 +19,7 @@ def test_failing_chunk_is_reported_and_nothing_leaks(fixture_cloud):
     mt0, pos0 = rng.get_state()
     ref, _ = engine.infer_shape(model, cloud, rng, 32, 3, chunk=512)
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     free0 = torch.cuda.mem_get_info()[0]
     for trial in range(6):
         model.debug_fault_chunk(trial % 3 + 1)
@@ -30,7 +31,7 @@ def test_failing_chunk_is_reported_and_nothing_leaks(fixture_cloud):
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     free1 = torch.cuda.mem_get_info()[0]
-    assert abs(free0 - free1) < (8 << 20), (free0, free1)        # pipeline buffers are model-owned: no per-call growth
+    assert free0 - free1 < (8 << 20), (free0, free1)             # pipeline buffers are model-owned: no per-call growth
     rng.set_state(mt0, pos0)
     again, _ = engine.infer_shape(model, cloud, rng, 32, 3, chunk=512)
     torch.cuda.synchronize()
@@ -49,6 +50,7 @@ def test_pipeline_buffers_are_reused_across_shapes_and_chunk_sizes(fixture_cloud
     a, _ = engine.infer_shape(model, cloud, rng, 32, 3, chunk=1000)
     engine.infer_shape(model, small, rng, 24, 3, chunk=300)       # smaller chunk: same buffers
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     free0 = torch.cuda.mem_get_info()[0]
     for _ in range(5):
         engine.infer_shape(model, small, rng, 24, 3, chunk=300)
@@ -56,5 +58,5 @@ def test_pipeline_buffers_are_reused_across_shapes_and_chunk_sizes(fixture_cloud
         b, _ = engine.infer_shape(model, cloud, rng, 32, 3, chunk=1000)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
-    assert abs(free0 - torch.cuda.mem_get_info()[0]) < (8 << 20)
+    assert free0 - torch.cuda.mem_get_info()[0] < (8 << 20)
     assert torch.equal(a, b)

@@ -178,3 +178,31 @@ def test_rng_sessions_mixed_calls_match_numpy(fixture_cloud, torch_cuda):
     assert np.array_equal(mt, st[1]) and pos == st[2]
     uni(cloud, n_pts, 2, 5)               # serial kernel on the committed state
     r.check()
+
+
+def test_speculative_offsets_across_blocks_match_numpy_and_serial_kernel(fixture_cloud, torch_cuda, monkeypatch):
+    """the parallel offsets pass (wc_spec_kernel + wc_chain_kernel, blocks of 512 queries) against numpy's stream for
+    1,300 consecutive grid queries (three blocks), and against the serial kernel (P2S_WC_SERIAL) including the skip path
+    (NULL ids: stream advanced only)"""
+    from points2surf_amd import engine
+    cloud = engine.Cloud(fixture_cloud)
+    q = cloud.query_grid(64, 3)[2000:3300].contiguous()
+    nq = int(q.shape[0])
+    r = engine.Rng(4242)
+    got = r.subsample_weighted(cloud, q, 1000, want_pts=False)[0].cpu().numpy()
+    r.check()
+    ref, rs = _numpy_reference(4242, fixture_cloud, q.cpu().numpy(), 1000)
+    assert np.array_equal(got, ref)
+    tail = r.subsample_uniform(cloud, 1, 777, want_pts=False)[0].cpu().numpy().reshape(-1)
+    assert np.array_equal(tail, rs.randint(0, fixture_cloud.shape[0], 777))
+    # skip path: no ids kernel cross-check behind it -> compare the stream position with the full path
+    r2 = engine.Rng(4242)
+    r2.skip(cloud, 1000, query_ms=q)
+    r2.check()
+    tail2 = r2.subsample_uniform(cloud, 1, 777, want_pts=False)[0].cpu().numpy().reshape(-1)
+    assert np.array_equal(tail2, tail)
+    monkeypatch.setenv('P2S_WC_SERIAL', '1')
+    r3 = engine.Rng(4242)
+    got3 = r3.subsample_weighted(cloud, q, 1000, want_pts=False)[0].cpu().numpy()
+    r3.check()
+    assert np.array_equal(got3, got) and nq == 1300

@@ -37,3 +37,32 @@ def test_cumsum_is_exact_and_choice_matches_numpy_legacy():
         ref = g2.choice(pts.shape[0], size=1000, replace=False, p=p)
         assert np.array_equal(ids, ref)
         assert g1.randint(1 << 20, 4).tolist() == g2.randint(0, 1 << 20, 4).tolist()   # same stream position
+
+
+@pytest.mark.parametrize('n_pts,seed', [(20000, 5), (34693, 6), (6000, 7)])
+def test_speculation_table_equals_actual_redraws(n_pts, seed):
+    """wc_spec_kernel's claim: the redraw count of choice() as a function of where its draws start in the stream --
+    every candidate the table decides must equal what the complete algorithm consumes from that start"""
+    rs = np.random.RandomState(seed)
+    pts = rs.uniform(-0.7, 0.7, (n_pts, 3)).astype(np.float32)
+    q = rs.uniform(-0.5, 0.5, 3).astype(np.float32)
+    tb = wm.Tables(orc.dist_prob(pts, q))
+    nsel, W = 1000, 96
+    xs = orc.LegacyMT19937(seed).rand(W + 4 * nsel)
+    table = wm.spec_redraws(tb, xs, nsel, W)
+    decided = 0
+    for d in range(0, W, 5):
+        pos = [d]
+
+        def rand(m):
+            out = xs[pos[0]:pos[0] + m]
+            pos[0] += m
+            return out
+        wm.choice_noreplace(tb, rand, nsel)
+        actual = pos[0] - d - nsel
+        if table[d] != 255:
+            assert table[d] == actual, (d, table[d], actual)
+            decided += 1
+        else:
+            assert actual > 0
+    assert decided > 0 or n_pts < 10000

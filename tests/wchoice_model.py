@@ -174,3 +174,45 @@ def choice_noreplace(tb, rand, size):
         V = sS - C
         Stot_cur = tb.Stot - C[-1]
     return np.array(found, dtype=np.int64)
+
+
+def spec_redraws(tb, xs, nsel, W, look=64):
+    """Model of wc_spec_kernel: for the candidate starts d = 0..W-1 (in doubles) of one query, the number of
+    redraws R(d) of ``choice`` when its first draw is xs[d], or 255 where the kernel leaves the decision to the
+    complete algorithm.  xs: at least W + nsel + 2*look doubles of the stream."""
+    cdf = tb.S / tb.Stot
+    nb = W + nsel
+    bins = np.searchsorted(cdf, xs[:nb], side='right')
+    last = {}
+    prev = np.full(nb, -1, dtype=np.int64)
+    for e, b in enumerate(bins):
+        prev[e] = last.get(b, -1)
+        last[b] = e
+    diff = np.zeros(W + 1, dtype=np.int64)
+    for e in np.nonzero(prev >= 0)[0]:
+        lo, hi = max(0, e - nsel + 1), min(prev[e], W - 1)
+        if lo <= hi:
+            diff[lo] += 1
+            diff[hi + 1] -= 1
+    m2 = np.cumsum(diff)[:W]
+    p = np.diff(np.concatenate([[0.0], tb.S]))
+    pm = float(p.max())
+    denom = tb.Stot - nsel * pm
+    ok = denom > 0.25 * tb.Stot
+    wmax = (pm / denom) * (1.0 + 1e-9) if ok else 2.0
+    nd = np.full(W + look, 255, dtype=np.int64)
+    for r in range(W + look):
+        e = nsel + r
+        close = np.nonzero(np.abs(xs[e + 1:e + look] - xs[e]) <= wmax)[0]
+        if close.size:
+            nd[r] = close[0] + 1
+    out = np.full(W, 255, dtype=np.int64)
+    for d in range(W):
+        m = int(m2[d])
+        if m == 0:
+            out[d] = 0
+        elif m <= look and ok:
+            bad = any(nd[d + e] != 255 and e + nd[d + e] < m for e in range(m))
+            if not bad:
+                out[d] = m
+    return out
