@@ -58,6 +58,9 @@ PROTOTYPES = {
     'p2s_debug_fault_chunk': (c_int, [c_void_p, c_int]),
     'p2s_sdf_volume': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, ctypes.c_float, c_int, c_int, c_void_p,
                                ctypes.POINTER(ctypes.c_int32), c_void_p]),
+    'p2s_marching_cubes': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, ctypes.POINTER(c_int64),
+                                   ctypes.POINTER(c_int64), c_int, c_int, ctypes.POINTER(c_int), c_int, c_void_p]),
+    'p2s_mc_table_entry': (c_int, [c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     'p2s_set_profiling': (c_int, [c_void_p, c_int]),
     'p2s_get_counters': (c_int, [c_void_p, ctypes.POINTER(Counters)]),
 }

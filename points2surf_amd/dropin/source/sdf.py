@@ -1,23 +1,31 @@
-"""Drop-in ``source.sdf``: the reference module with ``add_samples_to_volume`` +
-``propagate_sign`` (reference source/sdf.py:82-178) executed on the MI355X.
+"""Drop-in ``source.sdf``: the reference module with the whole consumer stage of the SDF samples on
+the MI355X -- ``add_samples_to_volume`` + ``propagate_sign`` (reference source/sdf.py:82-178), the iso-surface the
+reference obtains from scikit-image's ``marching_cubes_lewiner`` (:211-215), the vertex transform (:223),
+``trimesh.repair.fix_inversion`` (:224-225) and the mesh export (:226-227, dependency-free PLY writer).
 
-Everything else -- ``implicit_surface_to_mesh*`` (:181-266), marching cubes via scikit-image, mesh export via
-trimesh, the query-grid helpers -- is the reference's own code: this module loads the reference's
-``source/sdf.py`` from the other ``source`` directory on ``sys.path`` (see ``source/__init__.py``) and
-re-exports it, swapping only the two functions.  ``implicit_surface_to_mesh`` calls them back to back
-(:192-198), so ``add_samples_to_volume`` just remembers its arguments on the returned array and
-``propagate_sign`` runs scatter + propagation on the device in one go (p2s_sdf_volume, C ABI).
-No CPU fallback: without a GPU ``propagate_sign`` raises.
+Everything else -- the query-grid helpers, ``get_query_pts_for_mesh`` (dataset generation), ... -- is the reference's
+own code: this module loads the reference's ``source/sdf.py`` from the other ``source`` directory on ``sys.path`` (see
+``source/__init__.py``) when one is there and re-exports it.  The functions ``full_eval.py`` calls
+(``implicit_surface_to_mesh_directory`` -> ``implicit_surface_to_mesh_file`` -> ``implicit_surface_to_mesh``, and
+``visualize_query_points``) are this module's own and need neither the reference checkout nor scikit-image / trimesh.
+No CPU fallback: without a GPU they raise.
+
+Differences from the reference, all declared in INTEGRATION.md: the iso-surface is marching cubes with the asymptotic
+decider (scikit-image's Lewiner tables are unavailable offline: vertex / face counts are not pinned to skimage's);
+``implicit_surface_to_mesh_directory`` runs the shapes serially in this process whatever ``num_processes`` says (a HIP
+context cannot be used from the forked ``multiprocessing.Pool`` workers of source/base/utils_mp.py:33-35).
 """
 import importlib.util
 import os
 import sys
+import time
 
 import numpy as np
 
 import source as _pkg
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+_IMPORT_PID = os.getpid()
 
 
 def _load_reference_sdf():
@@ -27,13 +35,26 @@ def _load_reference_sdf():
             spec = importlib.util.spec_from_file_location('source._reference_sdf', cand)
             mod = importlib.util.module_from_spec(spec)
             sys.modules['source._reference_sdf'] = mod
-            spec.loader.exec_module(mod)
+            try:
+                spec.loader.exec_module(mod)           # needs the reference's own imports (trimesh at module level)
+            except ImportError:
+                del sys.modules['source._reference_sdf']
+                return None
             return mod
-    raise ImportError('points2surf_amd drop-in: the reference checkout (its source/sdf.py) must also be on sys.path')
+    return None
 
 
 _ref = _load_reference_sdf()
-globals().update({k: v for k, v in vars(_ref).items() if not k.startswith('__')})
+if _ref is not None:
+    globals().update({k: v for k, v in vars(_ref).items() if not k.startswith('__')})
+
+
+def _check_process():
+    if os.getpid() != _IMPORT_PID:
+        # HIP contexts do not survive fork(): the reference's multiprocessing.Pool meshing workers
+        # (source/base/utils_mp.py:33-35) must not touch the device
+        raise RuntimeError('points2surf_amd: device stage called in a forked worker process; it runs in the parent '
+                           '(use source.sdf.implicit_surface_to_mesh_directory of the drop-in)')
 
 
 class _VolumeWithSamples(np.ndarray):
@@ -47,15 +68,8 @@ def add_samples_to_volume(vol, pos_ms, val):
     return out
 
 
-_IMPORT_PID = os.getpid()
-
-
 def propagate_sign(vol, sigma=5, certainty_threshold=13):
-    if os.getpid() != _IMPORT_PID:
-        # HIP contexts do not survive fork(): the reference's multiprocessing.Pool meshing workers
-        # (source/base/utils_mp.py:33-35) must not touch the device
-        raise RuntimeError('points2surf_amd: propagate_sign called in a forked worker process; the device stage runs '
-                           'in the parent (use source.sdf.implicit_surface_to_mesh_directory of the drop-in)')
+    _check_process()
     samples = getattr(vol, '_p2s_samples', None)
     if samples is None:
         # called on an already populated volume (not the implicit_surface_to_mesh sequence): the samples are the
@@ -69,24 +83,106 @@ def propagate_sign(vol, sigma=5, certainty_threshold=13):
     return dev_vol.cpu().numpy().astype(np.float64)
 
 
+def visualize_query_points(query_pts_ms, query_dist_ms, file_out_off):
+    """reference :269-285: red = negative, green = positive distance, brightness = |d| / max|d|; coloured point-cloud PLY"""
+    from points2surf_amd import ply
+    d = np.asarray(query_dist_ms)
+    d_abs = np.abs(d)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        d_norm = d_abs / d_abs.max()
+    col = np.zeros((d.shape[0], 3))
+    neg, pos = d < 0.0, d > 0.0
+    col[neg, 0] = 0.5 + 0.5 * d_norm[neg]
+    col[pos, 1] = 0.5 + 0.5 * d_norm[pos]
+    if os.path.dirname(file_out_off):
+        os.makedirs(os.path.dirname(file_out_off), exist_ok=True)
+    ply.write_ply(file_out_off, query_pts_ms, vertex_colors=col)
+
+
+def _write_coff_points(file_path, vertices, colors):
+    """mesh_io.write_off(file, vertices, [], colors_vertex=colors) of the reference (source/base/mesh_io.py:75-140): COFF"""
+    if len(vertices) == 0:
+        return
+    if os.path.dirname(file_path):
+        os.makedirs(os.path.dirname(file_path), exist_ok=True)
+    with open(file_path, 'w') as fp:
+        fp.write('COFF\n')
+        fp.write(str(len(vertices)) + ' 0 0\n')
+        for v, c in zip(vertices, colors):
+            fp.write(str(v[0]) + ' ' + str(v[1]) + ' ' + str(v[2]) + ' ' + ''.join(str(x) + ' ' for x in c) + '\n')
+
+
+def implicit_surface_to_mesh(query_dist_ms, query_pts_ms, volume_out_file, mc_out_file, grid_res, sigma,
+                             certainty_threshold=26):
+    """reference :181-230 with the volume, the iso-surface and the inversion fix on the device"""
+    _check_process()
+    import torch
+    from points2surf_amd import engine, ply
+    query_dist_ms = np.asarray(query_dist_ms)
+    if query_dist_ms.max() == 0.0 and query_dist_ms.min() == 0.0:
+        print('WARNING: implicit surface for {} contains only zeros'.format(volume_out_file))
+        return
+    start = time.time()
+    volume, _ = engine.sdf_volume(np.asarray(query_pts_ms), query_dist_ms, grid_res, sigma, certainty_threshold, clamp=True)
+    torch.cuda.synchronize()
+    print('Sign propagation took: {}'.format(time.time() - start))
+
+    # green = inside; red = outside (the reference's debug output of the samples, :203-209)
+    norm = query_dist_ms / np.max(np.abs(query_dist_ms))
+    col = np.zeros((norm.shape[0], 3))
+    col[norm < 0.0, 0] = np.abs(norm[norm < 0.0]) + 1.0 / 2.0
+    col[norm > 0.0, 1] = norm[norm > 0.0] + 1.0 / 2.0
+    _write_coff_points(volume_out_file, np.asarray(query_pts_ms), col)
+
+    vmin, vmax = float(volume.min().item()), float(volume.max().item())
+    if vmin < 0.0 and vmax > 0.0:
+        start = time.time()
+        v, f, _ = engine.marching_cubes(volume, model_space=True, fix_inversion=True)
+        torch.cuda.synchronize()
+        print('Marching Cubes took: {}'.format(time.time() - start))
+        if v.shape[0] == 0 and f.shape[0] == 0:
+            print('Warning: marching cubes gives no result!')
+        else:
+            if os.path.dirname(mc_out_file):
+                os.makedirs(os.path.dirname(mc_out_file), exist_ok=True)
+            ply.write_ply(mc_out_file, v.cpu().numpy(), f.cpu().numpy())
+    else:
+        print('Warning: volume for marching cubes contains no 0-level set!')
+
+
+def implicit_surface_to_mesh_file(query_dist_ms_file, query_pts_ms_file, volume_out_file, mc_out_file, grid_res, sigma,
+                                  certainty_threshold):
+    implicit_surface_to_mesh(np.load(query_dist_ms_file), np.load(query_pts_ms_file), volume_out_file, mc_out_file,
+                             grid_res, sigma, certainty_threshold)
+
+
+def _call_necessary(files_in, files_out):
+    """file_utils.call_necessary (source/base/file_utils.py:194-240): inputs exist and an output is missing or older"""
+    if any(not os.path.isfile(f) for f in files_in):
+        print('WARNING: Input file are missing: {}'.format([f for f in files_in if not os.path.isfile(f)]))
+        return False
+    if any(not os.path.isfile(f) or os.path.getsize(f) == 0 for f in files_out):
+        return True
+    return max(os.path.getmtime(f) for f in files_in) >= min(os.path.getmtime(f) for f in files_out)
+
+
 def implicit_surface_to_mesh_directory(imp_surf_dist_ms_dir, query_pts_ms_dir, vol_out_dir, mesh_out_dir,
                                        grid_res, sigma, certainty_threshold, num_processes=1):
-    """reference source/sdf.py:240-266 with the per-shape calls made serially in THIS process: the volume stage
-    runs on the GPU, and a HIP context cannot be used from the forked ``multiprocessing.Pool`` workers the reference
-    starts for ``num_processes > 1`` (full_eval.py passes ``--workers``).  ``num_processes`` is accepted and ignored:
-    one shape's propagation takes milliseconds on the device (149 s on a CPU core at 256^3)."""
-    from source.base import file_utils
+    """reference :240-266 with the per-shape calls made serially in THIS process (``num_processes`` is accepted and
+    ignored: one shape's propagation + iso-surface takes milliseconds on the device, 149 s on a CPU core at 256^3)"""
     os.makedirs(vol_out_dir, exist_ok=True)
     os.makedirs(mesh_out_dir, exist_ok=True)
-    dist_files = [f for f in os.listdir(imp_surf_dist_ms_dir)
-                  if os.path.isfile(os.path.join(imp_surf_dist_ms_dir, f)) and f[-8:] == '.xyz.npy']
+    dist_files = sorted(f for f in os.listdir(imp_surf_dist_ms_dir)
+                        if os.path.isfile(os.path.join(imp_surf_dist_ms_dir, f)) and f[-8:] == '.xyz.npy')
     for f in dist_files:
         f_dist, f_query = os.path.join(imp_surf_dist_ms_dir, f), os.path.join(query_pts_ms_dir, f)
         f_vol, f_mesh = os.path.join(vol_out_dir, f[:-8] + '.off'), os.path.join(mesh_out_dir, f[:-8] + '.ply')
-        if file_utils.call_necessary([f_dist, f_query], [f_vol, f_mesh]):
-            _ref.implicit_surface_to_mesh_file(f_dist, f_query, f_vol, f_mesh, grid_res, sigma, certainty_threshold)
+        if _call_necessary([f_dist, f_query], [f_vol, f_mesh]):
+            implicit_surface_to_mesh_file(f_dist, f_query, f_vol, f_mesh, grid_res, sigma, certainty_threshold)
 
 
-# the reference's implicit_surface_to_mesh resolves both names in ITS module globals
-_ref.add_samples_to_volume = add_samples_to_volume
-_ref.propagate_sign = propagate_sign
+if _ref is not None:
+    # code of the reference module that resolves these names in ITS globals gets the device versions too
+    _ref.add_samples_to_volume = add_samples_to_volume
+    _ref.propagate_sign = propagate_sign
+    _ref.visualize_query_points = visualize_query_points

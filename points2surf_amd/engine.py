@@ -354,3 +354,29 @@ def sdf_volume(query_pts_ms, query_dist_ms, grid_resolution, sigma, certainty_th
         _lib.check(lib.p2s_sdf_volume(_ptr(q), _ptr(d), d.shape[0], res, int(sigma), ctypes.c_float(certainty_threshold),
                                       int(bool(clamp)), dev.index, _ptr(vol), ctypes.byref(iters), _stream_ptr(dev)))
     return vol, int(iters.value)
+
+
+def marching_cubes(vol, model_space=True, fix_inversion=True):
+    """iso-surface of a [res]^3 float32 device volume at level 0 (what reference source/sdf.py:211-225
+    obtains from scikit-image + trimesh).  Returns (verts [V,3] float32, faces [F,3] int32, inverted) device tensors;
+    empty tensors when the volume holds no 0-level set."""
+    if not torch.cuda.is_available():
+        raise RuntimeError('points2surf_amd needs a ROCm GPU (gfx950); no CPU fallback exists')
+    lib = _lib.load()
+    dev = vol.device
+    vol = _f32c(vol, dev)
+    res = int(vol.shape[0])
+    if vol.shape != (res, res, res):
+        raise ValueError('bad volume shape %s' % (tuple(vol.shape),))
+    nv, nf, inv = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+    with torch.cuda.device(dev):
+        _lib.check(lib.p2s_marching_cubes(_ptr(vol), res, None, 0, None, 0, ctypes.byref(nv), ctypes.byref(nf),
+                                          int(bool(model_space)), int(bool(fix_inversion)), ctypes.byref(inv), dev.index,
+                                          _stream_ptr(dev)), allow=(_lib.P2S_ECAPACITY,))
+        verts = torch.empty((max(nv.value, 1), 3), dtype=torch.float32, device=dev)
+        faces = torch.empty((max(nf.value, 1), 3), dtype=torch.int32, device=dev)
+        if nv.value or nf.value:
+            _lib.check(lib.p2s_marching_cubes(_ptr(vol), res, _ptr(verts), nv.value, _ptr(faces), nf.value,
+                                              ctypes.byref(nv), ctypes.byref(nf), int(bool(model_space)),
+                                              int(bool(fix_inversion)), ctypes.byref(inv), dev.index, _stream_ptr(dev)))
+    return verts[:nv.value], faces[:nf.value], bool(inv.value)

@@ -111,9 +111,11 @@ def test_sdf_bridge_reexports_reference_and_overrides_two_functions():
         assert ref.__file__.startswith(ref_shims.REFERENCE_ROOT)
         # re-exported reference functions (query grid helper is the reference's own object)
         assert sdf.get_voxel_centers_grid_smaller_pc is ref.get_voxel_centers_grid_smaller_pc
-        assert sdf.implicit_surface_to_mesh_file is ref.implicit_surface_to_mesh_file
-        # the directory driver is the drop-in's serial one (HIP contexts do not survive the reference's fork pool)
-        assert sdf.implicit_surface_to_mesh_directory is not ref.implicit_surface_to_mesh_directory
+        # the consumer stage full_eval.py calls is the drop-in's own (device volume + iso-surface, serial driver: HIP
+        # contexts do not survive the reference's fork pool)
+        for name in ('implicit_surface_to_mesh', 'implicit_surface_to_mesh_file', 'implicit_surface_to_mesh_directory'):
+            assert getattr(sdf, name) is not getattr(ref, name, None) and getattr(sdf, name).__module__ == 'source.sdf'
+        assert ref.visualize_query_points is sdf.visualize_query_points and sdf.visualize_query_points.__module__ == 'source.sdf'
         # the two overridden names are patched into the reference module too
         assert ref.propagate_sign is sdf.propagate_sign and ref.add_samples_to_volume is sdf.add_samples_to_volume
         v = sdf.add_samples_to_volume(np.zeros((8, 8, 8)), np.zeros((1, 3), np.float32), np.ones(1, np.float32))

@@ -91,7 +91,16 @@ def test_full_eval_call_sequence_matches_reference(model, dropin_eval, tmp_path)
         opt.reconstruction = True
         ev.points_to_surf_eval(opt)
         res_dir_rec = os.path.join(opt.outdir, 'rec')
+        # full_eval.py:51-64: the consumer stage, with --workers 7 (the reference would fork a process pool here)
+        import source.sdf as sdf
+        sdf.implicit_surface_to_mesh_directory(
+            os.path.join(res_dir_rec, 'dist_ms'), os.path.join(res_dir_rec, 'query_pts_ms'),
+            os.path.join(res_dir_rec, 'vol'), os.path.join(res_dir_rec, 'mesh'),
+            opt.query_grid_resolution, opt.sigma, opt.certainty_threshold, opt.workers)
 
+    from points2surf_amd import ply
+    from oracle import mc_oracle
+    from oracle import p2s_oracle
     with open(os.path.join(FIX, 'abc3.txt')) as f:
         names = [x.strip() for x in f if x.strip()]
     csv_rows = {l.split(',')[0].strip()[:8]: l.split(',') for l in meta['rme_comp_res_csv'].strip().split('\n')[1:]}
@@ -119,6 +128,19 @@ def test_full_eval_call_sequence_matches_reference(model, dropin_eval, tmp_path)
         for sub in ('eval', 'query_pts_ms'):
             assert os.path.isfile(os.path.join(res_dir_rec, sub, n + '.xyz.npy'))
         assert os.path.isfile(os.path.join(res_dir_rec, 'query_pts_ms_vis', n + '.ply'))
+        # rec/mesh/<shape>.ply + rec/vol/<shape>.off: the mesh equals the CPU restatement of the consumer stage run on
+        # the REFERENCE's SDF (reference add_samples/propagate semantics + the iso-surface oracle); watertight
+        assert os.path.isfile(os.path.join(res_dir_rec, 'vol', n + '.off'))
+        mv, mf = ply.read_ply(os.path.join(res_dir_rec, 'mesh', n + '.ply'))
+        q = np.load(os.path.join(res_dir_rec, 'query_pts_ms', n + '.xyz.npy'))
+        vol_ref = p2s_oracle.sdf_volume(q, ref, 32, 5, 13.0)
+        ov, of, _ = mc_oracle.marching_cubes(vol_ref.astype(np.float32))
+        print('%s shape %d mesh: %d vertices, %d faces (oracle on the reference SDF: %d, %d)'
+              % (model, i, mv.shape[0], mf.shape[0], ov.shape[0], of.shape[0]))
+        assert (mv.shape[0], mf.shape[0]) == (ov.shape[0], of.shape[0])          # identical counts
+        assert np.array_equal(mf, of) and np.abs(mv - ov).max() < 1e-4
+        chk = mc_oracle.mesh_checks(mv, mf)
+        assert chk['closed'] and chk['oriented'], chk
 
 
 def test_random_rotations_and_transform_match_the_oracle():
