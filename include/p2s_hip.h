@@ -59,7 +59,9 @@ typedef struct {
     int32_t encoder_bf16;        /* 1: per-point encoder layers on bf16 MFMA (fp32 accumulate; first layer, STN/QSTN heads,
                                     fold and decoder stay fp32).  Not bit-comparable with the fp32 reference path:
                                     see DESIGN.md for the measured deviation.  0 (default): exact fp32             */
-    int32_t reserved[8];
+    int32_t fixed_subsample;     /* train --fixed_subsample 1 (ablation): the generator is re-seeded with 42 before every
+                                    query's draw (reference source/base/utils.py:210-211)                       */
+    int32_t reserved[7];
 } p2s_model_cfg;
 
 /* Offsets (in floats) into the weight blob.  The blob holds BatchNorm-folded fp32 weights,
@@ -178,7 +180,13 @@ int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t n_queries, int n,
  * Errors found on the device (degenerate distances) are reported by p2s_rng_check. */
 int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q_dev, int64_t n_queries, int n,
                            int32_t *ids_out_dev, float *pts_out_dev, void *stream);
-/* given-ids mode (ids produced elsewhere, e.g. fixed_subsample experiments) */
+/* fixed mode (train --fixed_subsample 1; reference source/base/utils.py:210-211): ``rng.seed(seed)`` before EVERY
+ * query's draw, seed = 42 in the reference.  q_dev = NULL: uniform draw (every query gets the same ids);
+ * q_dev [Q][3]: distance-weighted choice (same random words, per-query probabilities; needs the jump tables).
+ * Afterwards the generator is where numpy's is: seeded + the last query's consumption. */
+int p2s_subsample_fixed(p2s_rng_t r, p2s_cloud_t c, const float *q_dev, int64_t n_queries, int n, uint32_t seed,
+                        int32_t *ids_out_dev, float *pts_out_dev, void *stream);
+/* given-ids mode (ids produced elsewhere) */
 int p2s_gather_points(p2s_cloud_t c, const int32_t *ids_dev, int64_t n_ids, float *pts_out_dev,
                       void *stream);
 

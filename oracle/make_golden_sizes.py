@@ -7,6 +7,7 @@ Run in the build container only (needs /root/reference; hours of CPU for the lar
     python -m oracle.make_golden_sizes rec       p2s_max     testset 128
     python -m oracle.make_golden_sizes rec       p2s_vanilla abc3    64
     python -m oracle.make_golden_sizes rec       p2s_max     testset 256
+    python -m oracle.make_golden_sizes rec       p2s_vanilla testset 32 1        (train --fixed_subsample 1)
 
 Jobs
   fixtures  copy the DATA of datasets/abc_minimal (clouds, GT query points / distances, meshes, shape
@@ -93,7 +94,7 @@ def shapes_of(dataset):
         return [x.strip() for x in f if x.strip()]
 
 
-def run(job, model, dataset, res, batch=500):
+def run(job, model, dataset, res, batch=500, fixed=0):
     import torch
     torch.set_num_threads(int(os.environ.get('P2S_GOLDEN_THREADS', os.cpu_count())))
     ref_shims.install()
@@ -108,7 +109,9 @@ def run(job, model, dataset, res, batch=500):
         modeldir = os.path.join(tmp, 'models')
         os.makedirs(modeldir)
         torch.save(synth.to_torch_state_dict(w), os.path.join(modeldir, model + '_model.pth'))
-        torch.save(train_namespace(cfg, batch=batch), os.path.join(modeldir, model + '_params.pth'))
+        ns = train_namespace(cfg, batch=batch)
+        ns.fixed_subsample = int(fixed)          # train --fixed_subsample 1: rng.seed(42) before every draw (utils.py:210-211)
+        torch.save(ns, os.path.join(modeldir, model + '_params.pth'))
         indir_root = dataset_dir(tmp)
         outdir = os.path.join(tmp, 'out')
         args = ['--indir', indir_root, '--outdir', outdir, '--dataset', 'abc_minimal/%s.txt' % dataset,
@@ -152,7 +155,8 @@ def run(job, model, dataset, res, batch=500):
         meta['reference_queries_per_s'] = nq / meta['reference_seconds']
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    key = 'ref_%s_%s_%s_grid%d' % (job, model, dataset, res)
+    key = 'ref_%s_%s_%s_grid%d' % (job, model, dataset + ('_fixed' if fixed else ''), res)
+    meta['fixed_subsample'] = int(fixed)
     np.savez_compressed(os.path.join(GOLDEN, key + '.npz'), **out)
     update_meta(key, meta)
     print(key, {k: v for k, v in meta.items() if k != 'rme_comp_res_csv'}, flush=True)
@@ -162,4 +166,4 @@ if __name__ == '__main__':
     if sys.argv[1] == 'fixtures':
         job_fixtures()
     else:
-        run(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]))
+        run(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), fixed=int(sys.argv[5]) if len(sys.argv) > 5 else 0)

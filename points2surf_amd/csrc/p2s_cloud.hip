@@ -780,6 +780,30 @@ int p2s_gather_points(p2s_cloud_t c, const int32_t *ids_dev, int64_t n_ids, floa
 // ---- RNG -----------------------------------------------------------------------------------------
 }  // extern "C"
 
+// init_genrand(seed): numpy legacy seeding with an integer seed -> mt[624] + position 624
+void p2s_mt_seed_host(uint32_t seed, uint32_t st[625]) {
+    st[0] = seed;
+    for (int i = 1; i < 624; ++i) st[i] = 1812433253u * (st[i - 1] ^ (st[i - 1] >> 30)) + (uint32_t)i;
+    st[624] = 624;
+}
+
+int p2s_rng_reseed(p2s_rng_s *r, uint32_t seed, hipStream_t s) {
+    int rc = p2s_rng_session_close(r, s);
+    if (rc) return rc;
+    uint32_t st[625];
+    p2s_mt_seed_host(seed, st);
+    P2S_HIP_CHECK(hipMemcpyAsync(r->state, st, sizeof(st), hipMemcpyHostToDevice, s));
+    P2S_HIP_CHECK(hipStreamSynchronize(s));        // st lives on this stack frame
+    return P2S_OK;
+}
+
+namespace {
+__global__ void p2s_replicate_rows_kernel(int32_t *__restrict__ ids, int n, long long rows) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (rows - 1) * n) ids[n + i] = ids[i % n];
+}
+}  // namespace
+
 int p2s_rng_serial_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s) {
     // The recurrence is serial (one workgroup) and pure latency: co-resident MFMA-saturated encoder
     // workgroups slow it ~3x.  Requesting most of a CU's LDS keeps any 50 KB encoder workgroup off its CU
@@ -804,11 +828,8 @@ int p2s_rng_create(uint32_t seed, int device, p2s_rng_t *out) {
         return P2S_ENODEVICE;
     }
     P2S_HIP_CHECK(hipSetDevice(device));
-    // init_genrand(seed): numpy legacy seeding with an integer seed
     uint32_t st[625];
-    st[0] = seed;
-    for (int i = 1; i < 624; ++i) st[i] = 1812433253u * (st[i - 1] ^ (st[i - 1] >> 30)) + (uint32_t)i;
-    st[624] = 624;
+    p2s_mt_seed_host(seed, st);
     p2s_rng_s *r = new p2s_rng_s();
     r->device = device;
     if (hipMalloc(&r->state, sizeof(st)) != hipSuccess) {
@@ -867,6 +888,41 @@ int p2s_rng_set_state(p2s_rng_t r, const uint32_t *mt624_host, int32_t pos, void
     st[624] = (uint32_t)pos;
     P2S_HIP_CHECK(hipMemcpyAsync(r->state, st, sizeof(st), hipMemcpyHostToDevice, (hipStream_t)stream));
     P2S_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return P2S_OK;
+}
+
+int p2s_subsample_fixed(p2s_rng_t r, p2s_cloud_t c, const float *q_dev, int64_t nq, int n, uint32_t seed,
+                        int32_t *ids_out_dev, float *pts_out_dev, void *stream) {
+    if (!r || !c || nq < 0 || n < 1 || !ids_out_dev) {
+        p2s_set_error("p2s_subsample_fixed: bad argument (ids_out_dev is required)");
+        return P2S_EINVAL;
+    }
+    if (q_dev) return p2s_wc_subsample_fixed(r, c, q_dev, nq, n, seed, ids_out_dev, pts_out_dev, (hipStream_t)stream);
+    if (c->d.n < n) {
+        p2s_set_error("p2s_subsample_fixed: cloud has %d points < sub_sample_size %d (shuffle+pad path unsupported)", c->d.n, n);
+        return P2S_EINVAL;
+    }
+    if (nq == 0) return P2S_OK;
+    P2S_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    // every query draws the same n values from the freshly seeded generator: draw them once, copy the row
+    int rc = p2s_rng_reseed(r, seed, s);
+    if (rc) return rc;
+    const uint32_t rng = (uint32_t)(c->d.n - 1);
+    if (rng == 0) {
+        P2S_HIP_CHECK(hipMemsetAsync(ids_out_dev, 0, (size_t)nq * n * 4, s));
+    } else {
+        uint32_t mask = rng;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        if ((rc = p2s_rng_serial_randint(r, rng, mask, n, ids_out_dev, s))) return rc;
+        if (nq > 1) {
+            const long long tot = (long long)(nq - 1) * n;
+            hipLaunchKernelGGL(p2s_replicate_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ids_out_dev, n,
+                               (long long)nq);
+            P2S_LAUNCH_CHECK("p2s_replicate_rows_kernel");
+        }
+    }
+    if (pts_out_dev) return p2s_gather_points(c, ids_out_dev, (int64_t)nq * n, pts_out_dev, stream);
     return P2S_OK;
 }
 

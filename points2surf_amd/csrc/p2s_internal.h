@@ -134,3 +134,7 @@ int p2s_rng_session_close(p2s_rng_s *r, hipStream_t s);        // advance the ge
 int p2s_rng_session_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s);
 int p2s_rng_session_raw(p2s_rng_s *r, long long need_words, hipStream_t s);
 void p2s_wc_free_rng(p2s_rng_s *r);               // p2s_wchoice.hip workspace
+void p2s_mt_seed_host(uint32_t seed, uint32_t st[625]);                 // init_genrand
+int p2s_rng_reseed(p2s_rng_s *r, uint32_t seed, hipStream_t s);         // rng.seed(seed): closes any session
+int p2s_wc_subsample_fixed(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_t nq, int n_sel, uint32_t seed,
+                           int32_t *ids_out_dev, float *pts_out_dev, hipStream_t s);

@@ -239,8 +239,12 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         const int cur = (int)std::min<int64_t>(C, q_end - q0);
         if (ci >= nbuf && sa != s) PIPE_HIP(hipStreamWaitEvent(sa, b.freed[bi], 0));
         const int e0 = p2s_prof_mark(m, sa);
-        const int rc2 = weighted ? p2s_subsample_weighted(r, c, q_all + (size_t)q0 * 3, cur, n, b.sub_ids[bi], nullptr, sa)
-                                 : p2s_subsample_uniform(r, c, cur, n, b.sub_ids[bi], nullptr, sa);
+        int rc2;
+        if (m->cfg.fixed_subsample)      // rng.seed(42) before every draw (reference source/base/utils.py:210-211)
+            rc2 = p2s_subsample_fixed(r, c, weighted ? q_all + (size_t)q0 * 3 : nullptr, cur, n, 42u, b.sub_ids[bi], nullptr, sa);
+        else
+            rc2 = weighted ? p2s_subsample_weighted(r, c, q_all + (size_t)q0 * 3, cur, n, b.sub_ids[bi], nullptr, sa)
+                           : p2s_subsample_uniform(r, c, cur, n, b.sub_ids[bi], nullptr, sa);
         if (rc2) return fail(rc2);
         p2s_prof_span(m, ST_SUB, e0, p2s_prof_mark(m, sa));
         if (sa != s) PIPE_HIP(hipEventRecord(b.ready[bi], sa));

@@ -581,6 +581,7 @@ struct WcArgs {
     long long *meta;          // [0] words consumed (out), [1] sticky error
     long long *stats;         // development counters (null = off): [0] fallbacks, [1] window misses
     const long long *ctl;     // serial kernel: start at query ctl[0], word ctl[1] (null = query 0, word meta[0])
+    int fixed;                // fixed_subsample: every query starts at word 0 of a freshly seeded generator
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1331,7 +1332,7 @@ __global__ __launch_bounds__(256) void wc_ids_kernel(WcArgs a) {
     for (int i = tid; i < BW; i += 256) l.bitmap[i] = 0;
     __syncthreads();
     const int q = blockIdx.x;
-    const long long base = a.base[q];
+    const long long base = a.fixed ? 0 : a.base[q];
     WcQuery qa;
     qa.Sq = a.S + (size_t)q * a.n;
     qa.Rq = a.R + (size_t)q * a.K;
@@ -1342,6 +1343,12 @@ __global__ __launch_bounds__(256) void wc_ids_kernel(WcArgs a) {
     qa.K = a.K;
     qa.nsel = a.nsel;
     const long long used = wc_full_query<true>(qa, l, wsum, wsumd, a.ids_out + (size_t)q * a.nsel);
+    if (a.fixed) {
+        // rng.seed(42) before every query: the generator ends where the LAST query of the call left it
+        if (tid == 0 && used < 0) a.meta[1] = 3;
+        if (tid == 0 && q == a.nq - 1 && used >= 0) a.meta[0] = used;
+        return;
+    }
     // cross-check against the offsets kernel: both must agree on where the next query starts
     const long long next = (q + 1 < a.nq) ? a.base[q + 1] : a.meta[0];
     if (tid == 0 && (used < 0 || base + used != next)) a.meta[1] = 4;
@@ -1470,9 +1477,22 @@ void p2s_wc_free_rng(p2s_rng_s *r) {
     if (r->wc_stot) (void)hipFree(r->wc_stot);
 }
 
+static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_t nq, int n_sel, int32_t *ids_out_dev,
+                        float *pts_out_dev, void *stream, bool fixed, uint32_t fixed_seed);
+
 extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q_dev, int64_t nq, int n_sel,
                                       int32_t *ids_out_dev, float *pts_out_dev, void *stream) {
-    if (!r || !c || !q_dev || nq < 0 || n_sel < 1 || (!ids_out_dev && pts_out_dev)) {
+    return wc_subsample(r, c, q_dev, nq, n_sel, ids_out_dev, pts_out_dev, stream, false, 0u);
+}
+
+int p2s_wc_subsample_fixed(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_t nq, int n_sel, uint32_t seed,
+                           int32_t *ids_out_dev, float *pts_out_dev, hipStream_t s) {
+    return wc_subsample(r, c, q_dev, nq, n_sel, ids_out_dev, pts_out_dev, (void *)s, true, seed);
+}
+
+static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_t nq, int n_sel, int32_t *ids_out_dev,
+                        float *pts_out_dev, void *stream, bool fixed, uint32_t fixed_seed) {
+    if (!r || !c || !q_dev || nq < 0 || n_sel < 1 || (!ids_out_dev && pts_out_dev) || (fixed && !ids_out_dev)) {
         p2s_set_error("p2s_subsample_weighted: bad argument (q_dev is required, pts_out_dev needs ids_out_dev)");
         return P2S_EINVAL;
     }
@@ -1552,7 +1572,13 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
     if (want_stats && !stats_dev) (void)hipMalloc(&stats_dev, 16 * 8);
     for (int64_t done = 0; done < nq;) {
         const int cur = (int)std::min<int64_t>(per_req, nq - done);
-        rc = p2s_rng_session_raw(r, (long long)(2.0 * n_sel * 1.15 * cur) + margin, s);
+        if (fixed) {
+            // a fresh generator per batch: every query of the batch reads the same words from its start
+            if ((rc = p2s_rng_reseed(r, fixed_seed, s))) return rc;
+            rc = p2s_rng_session_raw(r, (long long)(2.0 * n_sel * 1.5) + margin, s);
+        } else {
+            rc = p2s_rng_session_raw(r, (long long)(2.0 * n_sel * 1.15 * cur) + margin, s);
+        }
         if (rc) return rc;
         hipLaunchKernelGGL(wc_tables_kernel, dim3(cur), dim3(256), 0, s, c->d.pts, n, q_dev + (size_t)done * 3, plan, K,
                            r->wc_dist, r->wc_S, (WcRec *)r->wc_T, stot, pmax, mu, n_sel, meta);
@@ -1573,11 +1599,14 @@ extern "C" int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q
         a.meta = meta;
         a.stats = nullptr;
         a.ctl = nullptr;
+        a.fixed = fixed ? 1 : 0;
         if (want_stats) {
             (void)hipMemsetAsync(stats_dev, 0, 16 * 8, s);
             a.stats = stats_dev;
         }
-        if (serial_only) {
+        if (fixed) {
+            // no serial dependence between the queries: the ids kernel alone (it reports the last query's consumption)
+        } else if (serial_only) {
             hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(WC_NT), lds_off, s, a);
         } else {
             // speculation tables on all CUs + a light chain per block of SP_B queries; two spare pairs for blocks that

@@ -107,8 +107,6 @@ def _engine_cfg(train_opt, pred_dim):
         raise ValueError('the HIP engine expects outputs ordered imp_surf_magnitude, imp_surf_sign (got %s)' % outputs)
     if getattr(train_opt, 'patch_radius', 0.0) > 0.0:
         raise ValueError('fixed patch_radius (radius query) models are not supported by the HIP engine')
-    if int(getattr(train_opt, 'fixed_subsample', 0)):
-        raise ValueError('fixed_subsample ablation is not supported by the HIP engine')
     return dict(
         net_size=getattr(train_opt, 'net_size', 1024), points_per_patch=train_opt.points_per_patch,
         sub_sample_size=train_opt.sub_sample_size, output_dim=pred_dim,
@@ -116,6 +114,7 @@ def _engine_cfg(train_opt, pred_dim):
         sym_op=train_opt.sym_op, single_transformer=bool(train_opt.single_transformer),
         shared_transformer=bool(train_opt.shared_transformer),
         uniform_subsample=bool(getattr(train_opt, 'uniform_subsample', 0)),
+        fixed_subsample=bool(getattr(train_opt, 'fixed_subsample', 0)),
         # opt-in reduced precision (BASELINE configs[3]): per-point encoder layers on bf16 MFMA, everything else fp32
         encoder_bf16=os.environ.get('P2S_ENCODER', 'fp32') == 'bf16')
 

@@ -256,6 +256,19 @@ class Rng:
                                                       _stream_ptr(self.device)))
         return ids, pts
 
+    def subsample_fixed(self, cloud, n, n_queries=0, query_ms=None, seed=42, want_pts=True):
+        """a6 with train --fixed_subsample 1 (reference source/base/utils.py:210-211): ``rng.seed(42)`` before every
+        query's draw.  ``query_ms`` None: uniform (n_queries identical rows); else the distance-weighted choice."""
+        q = None if query_ms is None else _f32c(query_ms, self.device).reshape(-1, 3)
+        nq = int(n_queries) if q is None else int(q.shape[0])
+        ids = torch.empty((nq, n), dtype=torch.int32, device=self.device)
+        pts = torch.empty((nq, n, 3), dtype=torch.float32, device=self.device) if want_pts else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_subsample_fixed(self.handle, cloud.handle, _ptr(q), nq, int(n),
+                                                    ctypes.c_uint32(int(seed) & 0xffffffff), _ptr(ids), _ptr(pts),
+                                                    _stream_ptr(self.device)))
+        return ids, pts
+
     def skip(self, cloud, n, n_queries=0, query_ms=None):
         """advance the stream past queries without producing their ids: ``n_queries`` uniform draws of ``n`` ids, or
         the distance-weighted draws of the queries ``query_ms`` (query-range sharding, reference stream semantics)"""

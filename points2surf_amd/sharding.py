@@ -96,7 +96,7 @@ def query_range(n_queries, world, rank):
 def skip_queries(cloud, rng_dev, cfg, queries, sub_sample_size, chunk=4096):
     """advance the RNG stream past ``queries`` ([m,3] device tensor, in order) without inference"""
     m = int(queries.shape[0])
-    if m == 0:
+    if m == 0 or cfg.get('fixed_subsample'):      # fixed: every query re-seeds the generator, nothing carries over
         return
     if cfg.get('uniform_subsample'):
         rng_dev.skip(cloud, sub_sample_size, n_queries=m)

@@ -43,7 +43,7 @@ class ModelCfg(ctypes.Structure):
                 ('sub_sample_size', ctypes.c_int32), ('output_dim', ctypes.c_int32),
                 ('use_point_stn', ctypes.c_int32), ('shared_transformer', ctypes.c_int32),
                 ('weighted_subsample', ctypes.c_int32), ('encoder_bf16', ctypes.c_int32),
-                ('reserved', ctypes.c_int32 * 8)]
+                ('fixed_subsample', ctypes.c_int32), ('reserved', ctypes.c_int32 * 7)]
 
 
 def _np(v):
@@ -177,6 +177,7 @@ def build_blob(state_dict, cfg):
     mc.use_point_stn = int(use_point_stn)
     mc.shared_transformer = int(shared)
     mc.weighted_subsample = int(not bool(cfg.get('uniform_subsample', False)))
+    mc.fixed_subsample = int(bool(cfg.get('fixed_subsample', False)))
     mc.encoder_bf16 = int(bool(cfg.get('encoder_bf16', False)))
     if mc.output_dim != 2:
         raise ValueError('engine supports outputs imp_surf_magnitude + imp_surf_sign (pred_dim 2)')

@@ -39,7 +39,7 @@ def test_abi_version_and_error_string(lib):
 
 def test_struct_sizes_match_header():
     from points2surf_amd import weights, _lib
-    assert ctypes.sizeof(weights.ModelCfg) == 16 * 4
+    assert ctypes.sizeof(weights.ModelCfg) == 16 * 4 and weights.ModelCfg.fixed_subsample.offset == 8 * 4
     assert ctypes.sizeof(weights.EncoderOffsets) == 22 * 8
     assert ctypes.sizeof(weights.QstnOffsets) == 12 * 8
     assert ctypes.sizeof(weights.WeightOffsets) == (2 * 22 + 12 + 10) * 8

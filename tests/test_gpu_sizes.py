@@ -86,3 +86,45 @@ def test_three_clouds_one_stream_matches_reference(model, res):
     job = 'fulleval' if res == 32 else 'rec'
     g, meta = _golden(job, model, 'abc3', res)
     _compare(_run_dataset(model, 'abc3', res), g, meta)
+
+
+@pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
+def test_fixed_subsample_matches_reference(model):
+    """train --fixed_subsample 1 (ablation branch, reference source/base/utils.py:210-211): rng.seed(42) before every
+    query's draw -- full grid-32 shape against the unmodified reference, plus the ids against numpy"""
+    import torch
+    from points2surf_amd import engine, synth
+    from oracle import p2s_oracle as O
+    key = 'ref_rec_%s_testset_fixed_grid32' % model
+    if not os.path.isfile(os.path.join(GOLDEN, key + '.npz')):
+        pytest.skip(key + ' not generated')
+    g = np.load(os.path.join(GOLDEN, key + '.npz'))
+    w, cfg = synth.make_weights(model)
+    cfg = dict(cfg, fixed_subsample=True)
+    m = engine.Model(w, cfg)
+    pts = np.load(os.path.join(FIX, '04_pts', _names('testset')[0] + '.xyz.npy'))
+    cloud = engine.Cloud(pts)
+    rng = engine.Rng(SEED)
+    sdf, q = engine.infer_shape(m, cloud, rng, 32, 3, chunk=700)
+    torch.cuda.synchronize()
+    d = np.abs(sdf.cpu().numpy() - g['rec_0'])
+    flips = int((np.sign(sdf.cpu().numpy()) != np.sign(g['rec_0'])).sum())
+    print('%s fixed_subsample: max|dSDF| %.3g, flips %d' % (model, d.max(), flips))
+    assert d.max() < 1e-5 and flips == 0
+    # stage-wise: ids and the generator state afterwards == numpy
+    qs = q[:5]
+    r2 = engine.Rng(7)
+    if cfg.get('uniform_subsample'):
+        ids, _ = r2.subsample_fixed(cloud, 1000, n_queries=5, want_pts=False)
+        rs = np.random.RandomState(42)
+        want = np.tile(rs.randint(0, pts.shape[0], 1000), (5, 1))
+    else:
+        ids, _ = r2.subsample_fixed(cloud, 1000, query_ms=qs, want_pts=False)
+        want = []
+        for qq in qs.cpu().numpy():
+            rs = np.random.RandomState(42)
+            want.append(rs.choice(pts.shape[0], size=1000, replace=False, p=O.dist_prob(pts, qq)))
+        want = np.stack(want)
+    assert np.array_equal(ids.cpu().numpy(), want)
+    nxt = r2.subsample_uniform(cloud, 1, 64, want_pts=False)[0].cpu().numpy().reshape(-1)
+    assert np.array_equal(nxt, rs.randint(0, pts.shape[0], 64))           # generator = seed(42) + the last query's draws
