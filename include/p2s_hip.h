@@ -186,7 +186,18 @@ int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q_dev, int64
  * Afterwards the generator is where numpy's is: seeded + the last query's consumption. */
 int p2s_subsample_fixed(p2s_rng_t r, p2s_cloud_t c, const float *q_dev, int64_t n_queries, int n, uint32_t seed,
                         int32_t *ids_out_dev, float *pts_out_dev, void *stream);
-/* given-ids mode (ids produced elsewhere) */
+/* clouds with FEWER points than the sub-sample size (reference source/base/utils.py:221-226): rng.shuffle of the
+ * point array (numpy legacy shuffle: rk_interval per row) + zero padding.  The reference shuffles shape.pts IN PLACE
+ * under the kd-tree, so every query permutes the array later patches are gathered from; the cloud handle keeps that
+ * permutation.  perm_before_dev [Q][N] (may be NULL): row -> original point id BEFORE query i's shuffle (what the
+ * patch gather of query i sees); ids_out_dev [Q][n] (may be NULL): the shuffled ids, -1 = zero padding.
+ * p2s_subsample_uniform / _weighted / _fixed route here automatically for such clouds. */
+int p2s_subsample_shuffle_pad(p2s_rng_t r, p2s_cloud_t c, int64_t n_queries, int n, int32_t *perm_before_dev,
+                              int32_t *ids_out_dev, void *stream);
+/* a5 from explicit kNN ids (rows looked up through perm_before_dev, NULL = identity): radius + patch space */
+int p2s_patch_from_ids(p2s_cloud_t c, const int32_t *ids_dev, const int32_t *perm_before_dev, const float *query_dev,
+                       int64_t n_queries, int k, float *patch_ps_out_dev, float *radius_out_dev, void *stream);
+/* given-ids mode (ids produced elsewhere; id < 0 = zero point) */
 int p2s_gather_points(p2s_cloud_t c, const int32_t *ids_dev, int64_t n_ids, float *pts_out_dev,
                       void *stream);
 

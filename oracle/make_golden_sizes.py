@@ -72,6 +72,7 @@ def job_fixtures():
         os.chmod(os.path.join(FIX, f), 0o644)
     with open(os.path.join(FIX, 'abc3.txt'), 'w') as f:
         f.write('\n'.join(ABC3) + '\n')
+    np.save(os.path.join(GOLDEN, SMALL + '.xyz.npy'), small_cloud())
     print('fixtures ->', FIX)
 
 
@@ -84,10 +85,26 @@ def dataset_dir(tmp):
     shutil.copyfile(os.path.join(ABC, 'testset.txt'), os.path.join(root, 'testset.txt'))
     with open(os.path.join(root, 'abc3.txt'), 'w') as f:
         f.write('\n'.join(ABC3) + '\n')
+    # the small cloud lives in its own tree (the reference's 04_pts is read-only)
+    sroot = os.path.join(tmp, 'datasets', 'small')
+    os.makedirs(os.path.join(sroot, '04_pts'))
+    np.save(os.path.join(sroot, '04_pts', SMALL + '.xyz.npy'), small_cloud())
+    with open(os.path.join(sroot, SMALL + '.txt'), 'w') as f:
+        f.write(SMALL + '\n')
     return os.path.join(tmp, 'datasets')
 
 
+SMALL = 'small800'          # 800 points: fewer than the sub-sample size -> shuffle + pad branch (utils.py:221-226)
+
+
+def small_cloud():
+    cloud = np.load(os.path.join(ABC, '04_pts', ABC3[2] + '.xyz.npy'))
+    return np.ascontiguousarray(cloud[::43][:800], dtype=np.float32)
+
+
 def shapes_of(dataset):
+    if dataset == SMALL:
+        return [SMALL]
     if dataset == 'abc3':
         return ABC3
     with open(os.path.join(ABC, 'testset.txt')) as f:
@@ -114,7 +131,8 @@ def run(job, model, dataset, res, batch=500, fixed=0):
         torch.save(ns, os.path.join(modeldir, model + '_params.pth'))
         indir_root = dataset_dir(tmp)
         outdir = os.path.join(tmp, 'out')
-        args = ['--indir', indir_root, '--outdir', outdir, '--dataset', 'abc_minimal/%s.txt' % dataset,
+        sub = 'small' if dataset == SMALL else 'abc_minimal'
+        args = ['--indir', indir_root, '--outdir', outdir, '--dataset', '%s/%s.txt' % (sub, dataset),
                 '--modeldir', modeldir, '--models', model, '--query_grid_resolution', str(res),
                 '--epsilon', '3', '--certainty_threshold', '13', '--sigma', '5', '--gpu_idx', '-1',
                 '--workers', '0', '--batchSize', str(batch), '--cache_capacity', '5']
@@ -134,8 +152,8 @@ def run(job, model, dataset, res, batch=500, fixed=0):
             with open(os.path.join(res_root, 'eval', 'rme_comp_res.csv')) as f:
                 meta['rme_comp_res_csv'] = f.read()
         else:
-            opt.indir = os.path.join(indir_root, 'abc_minimal')
-            opt.outdir = os.path.join(outdir, model + '_model', 'abc_minimal')
+            opt.indir = os.path.join(indir_root, sub)
+            opt.outdir = os.path.join(outdir, model + '_model', sub)
             opt.dataset = dataset + '.txt'
             opt.reconstruction = True
             ref_eval.points_to_surf_eval(opt)

@@ -129,6 +129,25 @@ class LegacyMT19937:
                 self.pos += want
         return out
 
+    # -- legacy RandomState.shuffle of a 2-D array ----------------------------------------
+    def shuffle_rows(self, x):
+        """``RandomState.shuffle(x)`` for a 2-D array, in place (numpy mtrand ``shuffle``, ndim > 1 branch: for i in
+        reversed(range(1, n)): j = rk_interval(i); swap rows i, j through a bounce buffer).  rk_interval(max):
+        smallest 2^k - 1 >= max as mask, successive 32-bit words & mask until <= max.  Call site:
+        source/base/utils.py:224 (clouds with fewer points than the sub-sample size)."""
+        n = x.shape[0]
+        for i in reversed(range(1, n)):
+            mask = i
+            for sft in (1, 2, 4, 8, 16):
+                mask |= mask >> sft
+            while True:
+                v = int(self.raw(1)[0]) & mask
+                if v <= i:
+                    break
+            if v != i:
+                x[[i, v]] = x[[v, i]]
+        return x
+
     # -- legacy RandomState.rand / random_sample ---------------------------------------
     def rand(self, size):
         w = self.raw(2 * size).astype(np.uint64)
@@ -270,12 +289,23 @@ def subsample_ids(rng, pts, query, sub_sample_size, uniform, fixed=False):
     (source/data_loader.py:274-277)."""
     n = pts.shape[0]
     if n < sub_sample_size:
-        raise NotImplementedError('N < sub_sample_size (shuffle + zero padding, utils.py:221-226)')
+        raise ValueError('N < sub_sample_size: use subsample_points (the reference shuffles shape.pts in place)')
     if fixed:
         rng.seed(42)
     if uniform:
         return rng.randint(n, sub_sample_size)
     return rng.choice_noreplace(n, sub_sample_size, dist_prob(pts, query))
+
+
+def subsample_points(rng, pts, query, sub_sample_size, uniform, fixed=False):
+    """source/base/utils.py:196-227 literally: returns pts_sub_sample_ms [sub_sample_size, 3].  For a cloud with fewer
+    points than the sub-sample size the reference SHUFFLES ``pts`` IN PLACE (``pts_ms[:, :3]`` is a view, :223-224) and
+    pads with zeros -- ``pts`` is modified, exactly as shape.pts is under the reference's kd-tree."""
+    if pts.shape[0] >= sub_sample_size:
+        return pts[subsample_ids(rng, pts, query, sub_sample_size, uniform, fixed)]
+    rng.shuffle_rows(pts)
+    pad = np.zeros((sub_sample_size - pts.shape[0], 3), dtype=np.float32)
+    return np.concatenate((pts[:, :3], pad), axis=0)
 
 
 # --------------------------------------------------------------------------------------
@@ -446,12 +476,25 @@ def infer_shape(w, cfg, pts, grid_resolution, epsilon, rng, points_per_patch=300
     q0, q1 = (0, q_all.shape[0]) if query_range is None else query_range
     q = q_all[q0:q1]
     ids = knn_ids(pts, q, points_per_patch)
-    r, patch_ps = patch_radius_and_ps(pts, ids, q)
     uniform = bool(cfg.get('uniform_subsample', False))
     fixed = bool(cfg.get('fixed_subsample', False))
-    sub_ids = np.stack([subsample_ids(rng, pts, q[i], sub_sample_size, uniform, fixed)
-                        for i in range(q.shape[0])]) if q.shape[0] else np.zeros((0, sub_sample_size), np.int64)
-    sub = pts[sub_ids]
+    if pts.shape[0] < sub_sample_size:
+        # data_loader.py:322-421 query by query: the kd-tree holds a float64 COPY of the original order (cKDTree of a
+        # float32 array), the patch is gathered from shape.pts -- which every previous query's sub-sample shuffled
+        cur = pts.copy()
+        r = np.zeros(q.shape[0], np.float32)
+        patch_ps = np.zeros((q.shape[0], points_per_patch, 3), np.float32)
+        sub = np.zeros((q.shape[0], sub_sample_size, 3), np.float32)
+        for i in range(q.shape[0]):
+            ri, pi = patch_radius_and_ps(cur, ids[i:i + 1], q[i:i + 1])
+            r[i], patch_ps[i] = ri[0], pi[0]
+            sub[i] = subsample_points(rng, cur, q[i], sub_sample_size, uniform, fixed)
+        sub_ids = None
+    else:
+        r, patch_ps = patch_radius_and_ps(pts, ids, q)
+        sub_ids = np.stack([subsample_ids(rng, pts, q[i], sub_sample_size, uniform, fixed)
+                            for i in range(q.shape[0])]) if q.shape[0] else np.zeros((0, sub_sample_size), np.int64)
+        sub = pts[sub_ids]
     logits = model_forward(w, cfg, patch_ps, sub, q, chunk=chunk)
     sdf = post_process(logits, r)
     if return_all:

@@ -50,6 +50,8 @@ PROTOTYPES = {
     'p2s_subsample_uniform': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'p2s_subsample_weighted': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'p2s_subsample_fixed': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, ctypes.c_uint32, c_void_p, c_void_p, c_void_p]),
+    'p2s_subsample_shuffle_pad': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    'p2s_patch_from_ids': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'p2s_gather_points': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'p2s_infer_shape': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_void_p,
                                 c_void_p, ctypes.POINTER(c_int64), c_void_p]),

@@ -492,10 +492,107 @@ __global__ void p2s_gather_kernel(const float *__restrict__ pts, const int32_t *
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int id = ids[i];
-    id = min(max(id, 0), n_points - 1);
+    if (id < 0) {            // zero padding of the N < sub_sample_size branch (reference source/base/utils.py:225-226)
+        out[3 * i + 0] = out[3 * i + 1] = out[3 * i + 2] = 0.0f;
+        return;
+    }
+    id = min(id, n_points - 1);
     out[3 * i + 0] = pts[3 * id + 0];
     out[3 * i + 1] = pts[3 * id + 1];
     out[3 * i + 2] = pts[3 * id + 2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// a6, clouds with FEWER points than the sub-sample size (reference source/base/utils.py:221-226):
+//     pts_shuffled = pts_ms[:, :3]; rng.shuffle(pts_shuffled); pad with zeros
+// The view is shuffled IN PLACE: shape.pts itself is permuted by every query, under the kd-tree (which holds its own
+// float64 copy), so the patch of a later query gathers pts[knn ids] from the permuted array (Appendix A of
+// SURVEY.md).  Reproduced literally: `perm` (device, persistent per cloud) maps the row of shape.pts to the original
+// point; per query the state before the shuffle goes to perm_before (patch gather), the state after it is the
+// sub-sample (+ -1 padding).  numpy legacy shuffle of a 2-D array: for i = n-1 .. 1: j = rk_interval(i) (masked
+// rejection on 32-bit words); swap rows i, j.  One wave: lane 0 walks, all lanes twist.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void p2s_shuffle_pad_kernel(uint32_t *__restrict__ state, int *__restrict__ perm, int n,
+                                                             long long nq, int n_sel, int *__restrict__ perm_before,
+                                                             int *__restrict__ ids_out) {
+    __shared__ uint32_t st[2][624];
+    __shared__ int sp[1024];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 624; i += 64) st[0][i] = state[i];
+    for (int i = lane; i < n; i += 64) sp[i] = perm[i];
+    int pos = (int)state[624];
+    int cur = 0;
+    __syncthreads();
+    for (long long q = 0; q < nq; ++q) {
+        if (perm_before)
+            for (int i = lane; i < n; i += 64) perm_before[q * n + i] = sp[i];
+        int i = n - 1;
+        while (i >= 1) {                                  // uniform: i and pos are broadcast from lane 0
+            if (pos >= 624) {
+                mt_twist_wave(st[cur], st[cur ^ 1], lane);
+                cur ^= 1;
+                pos = 0;
+                __syncthreads();
+            }
+            if (lane == 0) {
+                // consume words of the current block until it is exhausted or the shuffle is done
+                while (i >= 1 && pos < 624) {
+                    uint32_t mask = (uint32_t)i;
+                    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+                    const uint32_t v = mt_temper(st[cur][pos++]) & mask;
+                    if (v <= (uint32_t)i) {
+                        if ((int)v != i) {
+                            const int t = sp[v];
+                            sp[v] = sp[i];
+                            sp[i] = t;
+                        }
+                        --i;
+                    }
+                }
+            }
+            i = __shfl(i, 0);
+            pos = __shfl(pos, 0);
+            __syncthreads();
+        }
+        if (ids_out) {
+            for (int k = lane; k < n_sel; k += 64) ids_out[q * n_sel + k] = k < n ? sp[k] : -1;
+        }
+    }
+    for (int i = lane; i < 624; i += 64) state[i] = st[cur][i];
+    for (int i = lane; i < n; i += 64) perm[i] = sp[i];
+    if (lane == 0) state[624] = (uint32_t)pos;
+}
+
+// patch from explicit kNN ids, rows looked up through the current permutation of shape.pts (NULL = identity):
+// r = max ||q - p||_2 and (p - q) / r exactly as p2s_knn_kernel computes them
+__global__ __launch_bounds__(64) void p2s_patch_from_ids_kernel(const float *__restrict__ pts, const int *__restrict__ ids,
+                                                                const int *__restrict__ perm_before, int n,
+                                                                const float *__restrict__ queries, long long nq, int k,
+                                                                float *__restrict__ patch_out, float *__restrict__ radius_out) {
+    const int lane = threadIdx.x;
+    for (long long qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+        const float qxf = queries[3 * qi + 0], qyf = queries[3 * qi + 1], qzf = queries[3 * qi + 2];
+        float smax = 0.0f;
+        for (int j = lane; j < k; j += 64) {
+            int id = ids[qi * k + j];
+            if (perm_before) id = perm_before[qi * n + id];
+            const float dx = qxf - pts[3 * id + 0], dy = qyf - pts[3 * id + 1], dz = qzf - pts[3 * id + 2];
+            smax = fmaxf(smax, (dx * dx + dy * dy) + dz * dz);
+        }
+        for (int d = 32; d > 0; d >>= 1) smax = fmaxf(smax, __shfl_xor(smax, d));
+        const float rad = sqrtf(smax);
+        if (radius_out && lane == 0) radius_out[qi] = rad;
+        if (patch_out) {
+            for (int j = lane; j < k; j += 64) {
+                int id = ids[qi * k + j];
+                if (perm_before) id = perm_before[qi * n + id];
+                float *dst = patch_out + (qi * k + j) * 3;
+                dst[0] = (pts[3 * id + 0] - qxf) / rad;
+                dst[1] = (pts[3 * id + 1] - qyf) / rad;
+                dst[2] = (pts[3 * id + 2] - qzf) / rad;
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -621,6 +718,7 @@ int p2s_cloud_destroy(p2s_cloud_t c) {
     if (c->blk_cnt) (void)hipFree(c->blk_cnt);
     if (c->totals) (void)hipFree(c->totals);
     if (c->qcache) (void)hipFree(c->qcache);
+    if (c->shuffle_perm) (void)hipFree(c->shuffle_perm);
     if (c->wc_plan) (void)hipFree(c->wc_plan);
     delete c;
     return P2S_OK;
@@ -715,6 +813,7 @@ int p2s_cloud_grid(p2s_cloud_s *c, int res, int eps, const float **q_out, long l
     const long long n = host_tot[0];
     if (n > c->qc_cap) {
         if (c->qcache) (void)hipFree(c->qcache);
+    if (c->shuffle_perm) (void)hipFree(c->shuffle_perm);
         c->qcache = nullptr;
         c->qc_cap = 0;
         if (hipMalloc(&c->qcache, (size_t)n * 12) != hipSuccess) {
@@ -891,17 +990,65 @@ int p2s_rng_set_state(p2s_rng_t r, const uint32_t *mt624_host, int32_t pos, void
     return P2S_OK;
 }
 
+int p2s_subsample_shuffle_pad(p2s_rng_t r, p2s_cloud_t c, int64_t nq, int n, int32_t *perm_before_dev, int32_t *ids_out_dev,
+                              void *stream) {
+    if (!r || !c || nq < 0 || n < 1) {
+        p2s_set_error("p2s_subsample_shuffle_pad: bad argument");
+        return P2S_EINVAL;
+    }
+    if (c->d.n >= n || c->d.n > 1024) {
+        p2s_set_error("p2s_subsample_shuffle_pad: only for clouds with fewer points (%d) than the sub-sample size (%d <= 1024)",
+                      c->d.n, n);
+        return P2S_EINVAL;
+    }
+    if (nq == 0) return P2S_OK;
+    P2S_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc = p2s_rng_session_close(r, s);
+    if (rc) return rc;
+    if (!c->shuffle_perm) {
+        std::vector<int> id((size_t)c->d.n);
+        for (int i = 0; i < c->d.n; ++i) id[i] = i;
+        if (hipMalloc(&c->shuffle_perm, (size_t)c->d.n * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            p2s_set_error("p2s_subsample_shuffle_pad: hipMalloc failed");
+            return P2S_ENOMEM;
+        }
+        P2S_HIP_CHECK(hipMemcpy(c->shuffle_perm, id.data(), id.size() * 4, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(p2s_shuffle_pad_kernel, dim3(1), dim3(64), 0, s, r->state, c->shuffle_perm, c->d.n, (long long)nq, n,
+                       perm_before_dev, ids_out_dev);
+    P2S_LAUNCH_CHECK("p2s_shuffle_pad_kernel");
+    return P2S_OK;
+}
+
+int p2s_patch_from_ids(p2s_cloud_t c, const int32_t *ids_dev, const int32_t *perm_before_dev, const float *query_dev,
+                       int64_t nq, int k, float *patch_ps_out_dev, float *radius_out_dev, void *stream) {
+    if (!c || !ids_dev || !query_dev || nq < 0 || k < 1) {
+        p2s_set_error("p2s_patch_from_ids: bad argument");
+        return P2S_EINVAL;
+    }
+    if (nq == 0) return P2S_OK;
+    P2S_HIP_CHECK(hipSetDevice(c->device));
+    const unsigned grid = (unsigned)std::min<int64_t>(nq, 256 * 64);
+    hipLaunchKernelGGL(p2s_patch_from_ids_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, c->d.pts, ids_dev,
+                       perm_before_dev, c->d.n, query_dev, (long long)nq, k, patch_ps_out_dev, radius_out_dev);
+    P2S_LAUNCH_CHECK("p2s_patch_from_ids_kernel");
+    return P2S_OK;
+}
+
 int p2s_subsample_fixed(p2s_rng_t r, p2s_cloud_t c, const float *q_dev, int64_t nq, int n, uint32_t seed,
                         int32_t *ids_out_dev, float *pts_out_dev, void *stream) {
     if (!r || !c || nq < 0 || n < 1 || !ids_out_dev) {
         p2s_set_error("p2s_subsample_fixed: bad argument (ids_out_dev is required)");
         return P2S_EINVAL;
     }
-    if (q_dev) return p2s_wc_subsample_fixed(r, c, q_dev, nq, n, seed, ids_out_dev, pts_out_dev, (hipStream_t)stream);
-    if (c->d.n < n) {
-        p2s_set_error("p2s_subsample_fixed: cloud has %d points < sub_sample_size %d (shuffle+pad path unsupported)", c->d.n, n);
-        return P2S_EINVAL;
+    if (c->d.n < n) {        // the reseed sits inside the N >= n branch of the reference: small clouds shuffle + pad
+        const int rc = p2s_subsample_shuffle_pad(r, c, nq, n, nullptr, ids_out_dev, stream);
+        if (rc || !pts_out_dev) return rc;
+        return p2s_gather_points(c, ids_out_dev, (int64_t)nq * n, pts_out_dev, stream);
     }
+    if (q_dev) return p2s_wc_subsample_fixed(r, c, q_dev, nq, n, seed, ids_out_dev, pts_out_dev, (hipStream_t)stream);
     if (nq == 0) return P2S_OK;
     P2S_HIP_CHECK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
@@ -932,10 +1079,10 @@ int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t nq, int n, int32_t
         p2s_set_error("p2s_subsample_uniform: bad argument (pts_out_dev needs ids_out_dev)");
         return P2S_EINVAL;
     }
-    if (c->d.n < n) {
-        p2s_set_error("p2s_subsample_uniform: cloud has %d points < sub_sample_size %d (shuffle+pad path unsupported)",
-                      c->d.n, n);
-        return P2S_EINVAL;
+    if (c->d.n < n) {        // reference source/base/utils.py:221-226: shuffle (in place) + zero padding
+        const int rc = p2s_subsample_shuffle_pad(r, c, nq, n, nullptr, ids_out_dev, stream);
+        if (rc || !pts_out_dev) return rc;
+        return p2s_gather_points(c, ids_out_dev, (int64_t)nq * n, pts_out_dev, stream);
     }
     if (nq == 0) return P2S_OK;
     P2S_HIP_CHECK(hipSetDevice(c->device));

@@ -15,7 +15,9 @@ struct PipeBuffers {
     hipEvent_t ready[2] = {};       // data path of the buffer finished (aux stream)
     hipEvent_t freed[2] = {};       // encoders finished reading the buffer (main stream)
     hipEvent_t grid = nullptr;
-    int cap_chunk = 0, cap_k = 0, cap_n = 0;
+    int32_t *knn_ids[2] = {};       // [C][k]   } only for clouds with fewer points than the sub-sample
+    int32_t *perm[2] = {};          // [C][N]   } (shape.pts is shuffled in place by every query)
+    int cap_chunk = 0, cap_k = 0, cap_n = 0, cap_small = 0;
 };
 
 struct p2s_model_s {
@@ -83,6 +85,7 @@ struct p2s_cloud_s {
     int *blk_cnt = nullptr;
     size_t blk_cap = 0;
     long long *totals = nullptr;   // [2] device: total count, error flag
+    int *shuffle_perm = nullptr;   // clouds with fewer points than the sub-sample: current row order of shape.pts
     // the last query grid stays on the handle: the pipeline and the callers that size their outputs share it
     float *qcache = nullptr;
     int qc_res = 0, qc_eps = 0;

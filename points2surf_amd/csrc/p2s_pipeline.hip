@@ -25,6 +25,8 @@ void p2s_pipe_free(p2s_model_s *m) {
         if (b.sub_ids[i]) (void)hipFree(b.sub_ids[i]);
         if (b.sub[i]) (void)hipFree(b.sub[i]);
         if (b.qrot[i]) (void)hipFree(b.qrot[i]);
+        if (b.knn_ids[i]) (void)hipFree(b.knn_ids[i]);
+        if (b.perm[i]) (void)hipFree(b.perm[i]);
         if (b.rot[i]) (void)hipFree(b.rot[i]);
         if (b.ready[i]) (void)hipEventDestroy(b.ready[i]);
         if (b.freed[i]) (void)hipEventDestroy(b.freed[i]);
@@ -35,9 +37,11 @@ void p2s_pipe_free(p2s_model_s *m) {
 
 namespace {
 
-int pipe_reserve(p2s_model_s *m, int C, int k, int n) {
+int pipe_reserve(p2s_model_s *m, int C, int k, int n, bool small) {
     PipeBuffers &b = m->pipe;
-    if (b.cap_chunk >= C && b.cap_k == k && b.cap_n == n) return P2S_OK;
+    if (b.cap_chunk >= C && b.cap_k == k && b.cap_n == n && (!small || b.cap_small)) return P2S_OK;
+    C = std::max(C, b.cap_chunk);
+    small = small || b.cap_small;
     P2S_HIP_CHECK(hipDeviceSynchronize());
     p2s_pipe_free(m);
     bool ok = hipEventCreateWithFlags(&b.grid, hipEventDisableTiming) == hipSuccess;
@@ -45,6 +49,8 @@ int pipe_reserve(p2s_model_s *m, int C, int k, int n) {
         ok = hipMalloc(&b.patch[i], (size_t)C * k * 12) == hipSuccess && hipMalloc(&b.radius[i], (size_t)C * 4) == hipSuccess &&
              hipMalloc(&b.sub_ids[i], (size_t)C * n * 4) == hipSuccess && hipMalloc(&b.sub[i], (size_t)C * n * 12) == hipSuccess &&
              hipMalloc(&b.qrot[i], (size_t)C * 12) == hipSuccess && hipMalloc(&b.rot[i], (size_t)C * 72) == hipSuccess &&
+             (!small || (hipMalloc(&b.knn_ids[i], (size_t)C * k * 4) == hipSuccess &&
+                         hipMalloc(&b.perm[i], (size_t)C * n * 4) == hipSuccess)) &&
              hipEventCreateWithFlags(&b.ready[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&b.freed[i], hipEventDisableTiming) == hipSuccess;
     }
@@ -57,6 +63,7 @@ int pipe_reserve(p2s_model_s *m, int C, int k, int n) {
     b.cap_chunk = C;
     b.cap_k = k;
     b.cap_n = n;
+    b.cap_small = small ? 1 : 0;
     return P2S_OK;
 }
 
@@ -202,7 +209,10 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
     const int64_t nq = q_end - q_begin;
     if (nq <= 0) return P2S_OK;
     const int C = (int)std::min<int64_t>(chunk, nq);
-    int rc = pipe_reserve(m, C, k, n);
+    // clouds with fewer points than the sub-sample: shuffle + pad, and shape.pts permuted under the kd-tree
+    // (reference source/base/utils.py:221-226; p2s_subsample_shuffle_pad)
+    const bool small = c->d.n < n;
+    int rc = pipe_reserve(m, C, k, n, small);
     if (rc) return rc;
     rc = p2s_model_reserve(m, C);
     if (rc) return rc;
@@ -240,7 +250,9 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         if (ci >= nbuf && sa != s) PIPE_HIP(hipStreamWaitEvent(sa, b.freed[bi], 0));
         const int e0 = p2s_prof_mark(m, sa);
         int rc2;
-        if (m->cfg.fixed_subsample)      // rng.seed(42) before every draw (reference source/base/utils.py:210-211)
+        if (small)
+            rc2 = p2s_subsample_shuffle_pad(r, c, cur, n, b.perm[bi], b.sub_ids[bi], sa);
+        else if (m->cfg.fixed_subsample)      // rng.seed(42) before every draw (reference source/base/utils.py:210-211)
             rc2 = p2s_subsample_fixed(r, c, weighted ? q_all + (size_t)q0 * 3 : nullptr, cur, n, 42u, b.sub_ids[bi], nullptr, sa);
         else
             rc2 = weighted ? p2s_subsample_weighted(r, c, q_all + (size_t)q0 * 3, cur, n, b.sub_ids[bi], nullptr, sa)
@@ -265,10 +277,15 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
             return fail(P2S_EHIP);
         }
         const int ek0 = p2s_prof_mark(m, s);
-        rc = p2s_knn_patch(c, qc, cur, k, nullptr, b.patch[bi], b.radius[bi], s);
+        rc = small ? p2s_knn_patch(c, qc, cur, k, b.knn_ids[bi], nullptr, nullptr, s)
+                   : p2s_knn_patch(c, qc, cur, k, nullptr, b.patch[bi], b.radius[bi], s);
         if (rc) return fail(rc);
         p2s_prof_span(m, ST_KNN, ek0, p2s_prof_mark(m, s));
         if (sa != s) PIPE_HIP(hipStreamWaitEvent(s, b.ready[bi], 0));
+        if (small) {       // the patch is gathered from the array as the queries before this one left it
+            rc = p2s_patch_from_ids(c, b.knn_ids[bi], b.perm[bi], qc, cur, k, b.patch[bi], b.radius[bi], s);
+            if (rc) return fail(rc);
+        }
         rc = p2s_gather_points(c, b.sub_ids[bi], (int64_t)cur * n, b.sub[bi], s);
         if (rc) return fail(rc);
         // the producer only writes sub_ids: free for chunk ci + nbuf as soon as the gather has read them

@@ -1501,10 +1501,10 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
         return P2S_EINVAL;
     }
     const int n = c->d.n;
-    if (n < n_sel) {
-        p2s_set_error("p2s_subsample_weighted: cloud has %d points < sub_sample_size %d (shuffle+pad path unsupported)", n,
-                      n_sel);
-        return P2S_EINVAL;
+    if (n < n_sel) {         // reference source/base/utils.py:221-226: no weighting, shuffle (in place) + zero padding
+        const int rc = p2s_subsample_shuffle_pad(r, c, nq, n_sel, nullptr, ids_out_dev, stream);
+        if (rc || !pts_out_dev) return rc;
+        return p2s_gather_points(c, ids_out_dev, nq * n_sel, pts_out_dev, stream);
     }
     if (r->levels_max == 0) {
         p2s_set_error("p2s_subsample_weighted: needs the jump-ahead tables (p2s_rng_set_jump_tables)");

@@ -59,3 +59,25 @@ def test_oracle_gt_query_pass_matches_reference_full_eval(model):
     d = np.abs(sdf - g['eval_0'][:n]).max()
     assert d < 1e-5, d
     assert np.array_equal(np.sign(sdf), np.sign(g['eval_0'][:n]))
+
+
+def test_oracle_small_cloud_shuffle_pad_matches_reference():
+    """cloud with fewer points (800) than the sub-sample size: rng.shuffle of shape.pts IN PLACE + zero padding
+    (reference source/base/utils.py:221-226); the oracle's literal restatement against the unmodified reference"""
+    from points2surf_amd import synth
+    path = os.path.join(GOLDEN, 'ref_rec_p2s_max_small800_grid16.npz')
+    if not os.path.isfile(path):
+        pytest.skip('golden not generated yet')
+    g = np.load(path)
+    w, cfg = synth.make_weights('p2s_max')
+    pts = np.load(os.path.join(GOLDEN, 'small800.xyz.npy'))
+    n = 10
+    _, sdf = O.infer_shape(w, cfg, pts, 16, 3, O.LegacyMT19937(40938661), query_range=(0, n))
+    assert np.abs(sdf - g['rec_0'][:n]).max() < 1e-5
+    # the legacy shuffle itself against numpy
+    rs, mt = np.random.RandomState(3), O.LegacyMT19937(3)
+    a = np.arange(800 * 3, dtype=np.float32).reshape(800, 3)
+    b = a.copy()
+    rs.shuffle(a)
+    mt.shuffle_rows(b)
+    assert np.array_equal(a, b) and rs.randint(0, 99, 7).tolist() == mt.randint(99, 7).tolist()
