@@ -268,6 +268,26 @@ int p2s_marching_cubes(const float *vol_dev, int grid_res, float *verts_out_dev,
  * edges36: cube edge ids (axis * 4 + u + 2 v), 3 per triangle, -1 padded */
 int p2s_mc_table_entry(int cfg, int32_t *n_tri, int32_t *edges36);
 
+/* ------------------------------------------------------------------------------------------
+ * "next" row: mesh metrics (reference source/base/evaluation.py:222-305): even surface sampling
+ * (trimesh.sample.sample_surface_even), directed Hausdorff and Chamfer distances between the sample sets.
+ * ------------------------------------------------------------------------------------------ */
+/* RandomState.random_sample(n): n float64 in [0, 1) from the stream of r (2 words each); needs the jump tables */
+int p2s_rng_random_sample(p2s_rng_t r, int64_t n, double *out_dev, void *stream);
+/* trimesh.sample.sample_surface: u_dev [3 n] float64 uniform deviates laid out as the reference draws them (n face
+ * picks, then n x 2 lengths); pts_out_dev [n][3] float32, face_out_dev [n] (may be NULL); *area_host = mesh area */
+int p2s_mesh_sample_surface(const float *verts_dev, const int32_t *faces_dev, int64_t n_faces, const double *u_dev,
+                            int64_t n_samples, float *pts_out_dev, int32_t *face_out_dev, double *area_host,
+                            int device, void *stream);
+/* trimesh.points.remove_close + the [:count] cut of sample_surface_even: of every pair of points within `radius` the
+ * one with more close neighbours is dropped (ties: the first); the survivors, in order, at most `limit` */
+int p2s_points_remove_close(const float *pts_dev, int64_t m, double radius, int64_t limit, float *pts_out_dev,
+                            int64_t *n_out, int device, void *stream);
+/* nearest-neighbour distance (float64, exact) of every query point to the cloud `target`; *max_host = directed
+ * Hausdorff distance, *sum_host = the Chamfer term; dist_out_dev [n] float64 may be NULL.  Synchronises. */
+int p2s_nn_distance_stats(p2s_cloud_t target, const float *query_dev, int64_t n, double *dist_out_dev, double *max_host,
+                          double *sum_host, void *stream);
+
 /* per-stage counters of the last p2s_encode_decode / p2s_infer_shape on this model
  * (HIP-event milliseconds on the launch stream; valid after the stream is synchronised) */
 typedef struct {
