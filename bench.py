@@ -61,8 +61,9 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='target CPU-baseline duration (0 = skip)')
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--rng-mode', choices=['dataset', 'per_shape'], default='dataset')
-    ap.add_argument('--bf16', action='store_true',
-                    help='secondary mode (BASELINE configs[3]): bf16 encoder + fp32 decoder; NOT the headline metric')
+    ap.add_argument('--bf16', nargs='?', const=1, default=0, type=int, choices=[0, 1, 2, 3],
+                    help='secondary modes (BASELINE configs[3]), NOT the headline metric: bf16 encoder + fp32 decoder '
+                         '(--bf16 or --bf16 1); split precision with 2 / 3 bf16 pieces per operand (--bf16 2 / 3)')
     ap.add_argument('--res', type=int, default=GRID_RES,
                     help='query-grid resolution; the headline metric is quoted at 256 (other values: BASELINE configs 1/4)')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
@@ -135,7 +136,7 @@ def main():
 
     w, cfg = synth.make_weights('p2s_max')
     if args.bf16:
-        cfg = dict(cfg, encoder_bf16=True)
+        cfg = dict(cfg, encoder_bf16=int(args.bf16))
     model = engine.Model(w, cfg)
     model.set_profiling(True)
     if args.points > 0:
@@ -227,11 +228,11 @@ def main():
                 except Exception:
                     continue
         out = {
-            'metric': 'SDF queries/sec/GPU (p2s_max, %d^3 grid%s)' % (args.res, ', bf16 encoder' if args.bf16 else ''),
+            'metric': 'SDF queries/sec/GPU (p2s_max, %d^3 grid%s)' % (args.res, (', bf16 encoder' if args.bf16 == 1 else ', split bf16x%d encoder' % args.bf16) if args.bf16 else ''),
             'value': value, 'unit': 'queries/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / max(args.steps, 1) * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'bf16' if args.bf16 else 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': ('bf16' if args.bf16 == 1 else 'bf16x%d' % args.bf16) if args.bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[2]: p2s_max, grid_res=%d, eps=3, kNN patch=300 / global ' % args.res +
                                    'sub=1000, fp32; %s, one shape per rank per step; seeded random-init weights '
                                    '(Famous set / pretrained weights not available offline)' % workload,
@@ -251,7 +252,7 @@ def main():
         rng_chk = engine.Rng(SEED_DATA)
         sdf_chk, _ = engine.infer_shape(model, cloud, rng_chk, args.res, EPSILON, chunk=args.chunk, want_queries=False)
         sdf_chk = sdf_chk.cpu().numpy()
-        tol = 0.25 if args.bf16 else 1e-4      # north_star: SDF within 1e-4 fp32 of the reference (bf16 mode: reported only)
+        tol = 0.25 if args.bf16 == 1 else 1e-4      # north_star: SDF within 1e-4 fp32 of the reference (plain bf16: reported only)
         if args.points == 0 and args.res == GRID_RES and os.path.isfile(GOLDEN_256):
             ref = np.load(GOLDEN_256)['rec_0']
             ok = ref.shape == sdf_chk.shape

@@ -56,9 +56,10 @@ typedef struct {
     int32_t shared_transformer;  /* one QSTN over cat(patch, sub-sample) (p2s_vanilla)         */
     int32_t weighted_subsample;  /* 0: ids = randint (train --uniform_subsample 1, p2s_max);
                                     1: distance-weighted choice without replacement (p2s_vanilla) */
-    int32_t encoder_bf16;        /* 1: per-point encoder layers on bf16 MFMA (fp32 accumulate; first layer, STN/QSTN heads,
-                                    fold and decoder stay fp32).  Not bit-comparable with the fp32 reference path:
-                                    see DESIGN.md for the measured deviation.  0 (default): exact fp32             */
+    int32_t encoder_bf16;        /* 0 (default): exact fp32.  1: per-point encoder layers on bf16 MFMA (fp32 accumulate; first
+                                    layer, STN/QSTN heads, fold and decoder stay fp32) -- outside the 1e-4 contract.
+                                    2 / 3: split precision, every operand as 2 / 3 bf16 pieces (3 / 6 bf16 MFMAs per
+                                    product, 16 / 24 mantissa bits): see DESIGN.md for the measured deviation      */
     int32_t fixed_subsample;     /* train --fixed_subsample 1 (ablation): the generator is re-seeded with 42 before every
                                     query's draw (reference source/base/utils.py:210-211)                       */
     int32_t reserved[7];

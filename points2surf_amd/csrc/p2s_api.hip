@@ -89,20 +89,30 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
             *it.dst = total;
             total += (size_t)it.K * it.N;
         }
-        if (hipMalloc(&m->blob_h, total * 2) != hipSuccess) {
+        const int ns = cfg->encoder_bf16;              // 1 plain bf16, 2 / 3 split precision (bf16 pieces per operand)
+        if (ns < 1 || ns > 3) {
+            (void)hipFree(m->blob);
+            delete m;
+            p2s_set_error("p2s_model_create: encoder_bf16 = %d (0 fp32, 1 bf16, 2 / 3 split bf16)", ns);
+            return P2S_EINVAL;
+        }
+        m->h_total = total;
+        if (hipMalloc(&m->blob_h, total * 2 * ns) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(m->blob);
             delete m;
             p2s_set_error("hipMalloc(bf16 weights) failed");
             return P2S_ENOMEM;
         }
-        for (auto &it : items) {
-            const int rc = p2s_launch_pack_bf16(m->blob + it.src, m->blob_h + *it.dst, it.K, it.N, 0, 0, 1, nullptr);
-            if (rc) {
-                p2s_model_destroy(m);
-                return rc;
+        for (int piece = 0; piece < ns; ++piece)
+            for (auto &it : items) {
+                const int rc = p2s_launch_pack_bf16(m->blob + it.src, m->blob_h + (size_t)piece * total + *it.dst, it.K, it.N, 0, 0,
+                                                    1, piece, nullptr);
+                if (rc) {
+                    p2s_model_destroy(m);
+                    return rc;
+                }
             }
-        }
         P2S_HIP_CHECK(hipDeviceSynchronize());
     }
     *out = m;
@@ -142,7 +152,7 @@ int p2s_get_counters(p2s_model_t m, p2s_counters *out) {
 static size_t ws_floats_per_query(const p2s_model_s *m) {
     size_t n = 2 * 1024 + 2 * 512 + 2 * 256 + 2 * 4096 + 2 * 4096 + 2 * 1024 + 1024 + 256 + 128;
     if (m->cfg.use_point_stn) n += 1024 + 512 + 256 + 16;
-    if (m->cfg.encoder_bf16) n += 4096;          // W1' of both encoders as bf16 fragments
+    if (m->cfg.encoder_bf16) n += 4096 * (size_t)m->cfg.encoder_bf16;   // W1' of both encoders as bf16 fragments, per piece
     return n;
 }
 
@@ -191,7 +201,7 @@ Ws carve(const p2s_model_s *m, int C) {
         w.qh2 = take((size_t)C * 256);
         w.rot = take((size_t)C * 16);
     }
-    w.w1h = m->cfg.encoder_bf16 ? reinterpret_cast<unsigned short *>(take((size_t)C * 4096)) : nullptr;
+    w.w1h = m->cfg.encoder_bf16 ? reinterpret_cast<unsigned short *>(take((size_t)C * 4096 * m->cfg.encoder_bf16)) : nullptr;
     return w;
 }
 
@@ -214,6 +224,9 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         // shared QSTN over cat(patch, sub-sample - q): reference points_to_surf_model.py:325-331, :100-131
         ChainArgs a;
         memset(&a, 0, sizeof(a));
+        a.ns = m->cfg.encoder_bf16;
+        a.piece_stride = (long long)m->h_total;
+        a.w1_piece_stride = (long long)2 * C * 4096;
         ChainBranch &b = a.br[0];
         b.ptsA = patch; b.ptsB = sub; b.center = query; b.rot = nullptr;
         b.w0a = W + o.qstn.c1; b.b0a = W + o.qstn.cb1;
@@ -243,6 +256,9 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
     // ---- pass 1: stem + STN trunk + max-pool, both encoders (global items first: longest first) ----
     ChainArgs a;
     memset(&a, 0, sizeof(a));
+    a.ns = m->cfg.encoder_bf16;
+    a.piece_stride = (long long)m->h_total;
+    a.w1_piece_stride = (long long)2 * C * 4096;
     for (int slot = 0; slot < 2; ++slot) {
         const int e = 1 - slot;   // slot 0 = feat_global (e=1), slot 1 = feat_local (e=0)
         const p2s_encoder_offsets &eo = o.enc[e];
@@ -308,7 +324,8 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
             b.w3 = reinterpret_cast<const float *>(m->blob_h + m->h_m3[e]);
         }
     }
-    if (bf16 && (rc = p2s_launch_pack_bf16(w.w1p, w.w1h, 64, 64, 4096, 4096, 2 * C, s))) return rc;
+    for (int piece = 0; bf16 && piece < m->cfg.encoder_bf16; ++piece)
+        if ((rc = p2s_launch_pack_bf16(w.w1p, w.w1h + (size_t)piece * 2 * C * 4096, 64, 64, 4096, 4096, 2 * C, piece, s))) return rc;
     if ((rc = bf16 ? p2s_launch_chain_bf16(a, s) : p2s_launch_chain(a, s))) return rc;
     const int ev3 = p2s_prof_mark(m, s);
     m->counters.launches_chain += 2;

@@ -13,6 +13,11 @@
 // conv3 (128 -> 1024) dominates: a wave keeps the A fragments of both row blocks for all 8 k-blocks in registers
 // (64 VGPRs) and streams its 8 column tiles of weights from L2 (64 KB per wave and tile).  Measured ~40 % of the bf16
 // MFMA peak; 128-point tiles (-DP2S_BF16_MT=128: half the weight stream, 2 workgroups/CU) are no faster.
+//
+// Split precision (template parameter NS = 2 or 3; cfg.encoder_bf16 = 2 / 3): every activation and weight is carried as
+// NS bf16 pieces  x = x0 + x1 (+ x2),  x_p = bf16(residual),  and a product is the sum of the piece products with
+// p + q < NS (3 MFMAs for NS = 2, 6 for NS = 3), all into the same fp32 accumulator: 16 / 24 mantissa bits per operand
+// at 1/16 of the fp32 MFMA cost per piece product.  Arithmetic model + measured deviation: DESIGN.md "bf16 modes".
 #include "p2s_common.h"
 #include <cmath>
 
@@ -58,8 +63,25 @@ __device__ __forceinline__ u32x4 lds_a(const unsigned short *buf, int H, int row
     return *reinterpret_cast<const u32x4 *>(buf + (row0 + (lane & 31)) * H + 16 * kb + 8 * (lane >> 5));
 }
 
-// acc (+ bias, ReLU) -> bf16 into buf[row0 + r][col0 + c]
-__device__ __forceinline__ void store_tile(const f32x16 &acc, unsigned short *buf, int H, int row0, int col0,
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// two fp32 values -> NS bf16 pieces each (piece p = bf16 of the residual); out[p] = packed pair (a low half, b high half)
+template <int NS>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[NS]) {
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+        out[p] = pack_bf16(a, b);
+        if (p + 1 < NS) {
+            a -= bf_hi(out[p]);
+            b -= bf_lo(out[p]);
+        }
+    }
+}
+
+// acc (+ bias, ReLU) -> bf16 pieces into buf[p][row0 + r][col0 + c]
+template <int NS>
+__device__ __forceinline__ void store_tile(const f32x16 &acc, unsigned short *buf, int H, int pstride, int row0, int col0,
                                            const float *__restrict__ bias, int lane) {
     const int c = col0 + (lane & 31);
     const float b = bias[c];
@@ -67,15 +89,22 @@ __device__ __forceinline__ void store_tile(const f32x16 &acc, unsigned short *bu
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
         const int r = (i & 3) + 8 * (i >> 2);             // rows r and r + 1
-        const unsigned u = pack_bf16(fmaxf(acc[i] + b, 0.0f), fmaxf(acc[i + 1] + b, 0.0f));
-        dst[r * H] = (unsigned short)u;
-        dst[(r + 1) * H] = (unsigned short)(u >> 16);
+        unsigned u[NS];
+        split_pair<NS>(fmaxf(acc[i] + b, 0.0f), fmaxf(acc[i + 1] + b, 0.0f), u);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+            dst[p * pstride + r * H] = (unsigned short)u[p];
+            dst[p * pstride + (r + 1) * H] = (unsigned short)(u[p] >> 16);
+        }
     }
 }
 
-__global__ __launch_bounds__(256, MT == 64 ? 4 : 2) void p2s_chain_bf16_kernel(ChainArgs args) {
-    __shared__ __attribute__((aligned(16))) unsigned short bufA[MT * HA];
-    __shared__ __attribute__((aligned(16))) unsigned short bufB[MT * HB];
+template <int NS>
+__global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_bf16_kernel(ChainArgs args) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds_bf16[];
+    constexpr int SA = MT * HA, SB = MT * HB;             // halfs per piece
+    unsigned short *bufA = lds_bf16;                      // [NS][MT][HA]
+    unsigned short *bufB = lds_bf16 + NS * SA;            // [NS][MT][HB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -91,11 +120,17 @@ __global__ __launch_bounds__(256, MT == 64 ? 4 : 2) void p2s_chain_bf16_kernel(C
     const float *__restrict__ b0a = br.b0a;
     // bf16 fragment arrays (the ChainBranch pointer fields are reused for them)
     // buffer descriptors (wave-uniform SGPRs) + scalar offsets + 16 * lane: no 64-bit VALU address math, no address VGPRs
+    // piece q of a weight array sits args.piece_stride halfs (per-item W1': args.w1_piece_stride) behind piece 0
     const unsigned short *w1p = reinterpret_cast<const unsigned short *>(br.w1) + (long long)item * br.w1_item_stride;
-    const __amdgpu_buffer_rsrc_t rs0b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(br.w0b), 0, 4096 * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(w1p), 0, 4096 * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(br.w2), 0, 8192 * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(br.w3), 0, 128 * 1024 * 2, 0x00020000);
+    const long long ps = args.piece_stride, ps1 = br.w1_item_stride ? args.w1_piece_stride : args.piece_stride;
+    __amdgpu_buffer_rsrc_t rs0b[NS], rs1[NS], rs2[NS], rs3[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        rs0b[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(reinterpret_cast<const unsigned short *>(br.w0b) + q * ps), 0, 4096 * 2, 0x00020000);
+        rs1[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(w1p + q * ps1), 0, 4096 * 2, 0x00020000);
+        rs2[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(reinterpret_cast<const unsigned short *>(br.w2) + q * ps), 0, 8192 * 2, 0x00020000);
+        rs3[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(reinterpret_cast<const unsigned short *>(br.w3) + q * ps), 0, 128 * 1024 * 2, 0x00020000);
+    }
     const int lane16 = lane * 16;
 
     float cx = 0.f, cy = 0.f, cz = 0.f;
@@ -153,7 +188,10 @@ __global__ __launch_bounds__(256, MT == 64 ? 4 : 2) void p2s_chain_bf16_kernel(C
                     v = fmaf(w0a[128 + o], x2, v);
                     sv[u] = fmaxf(v, 0.0f);
                 }
-                *reinterpret_cast<unsigned *>(dst + c) = pack_bf16(sv[0], sv[1]);
+                unsigned u[NS];
+                split_pair<NS>(sv[0], sv[1], u);
+#pragma unroll
+                for (int p = 0; p < NS; ++p) *reinterpret_cast<unsigned *>(dst + p * SA + c) = u[p];
             }
         }
         __syncthreads();          // bufA ready; every wave is past its conv3 reads of bufB (previous tile)
@@ -167,12 +205,20 @@ __global__ __launch_bounds__(256, MT == 64 ? 4 : 2) void p2s_chain_bf16_kernel(C
                 for (int r = 0; r < NB / 2; ++r) acc[r] = f32x16{};
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
-                    const u32x4 b = bufld(rs0b, lane16, (nt * 4 + kb) * 1024);
+                    u32x4 b[NS];
 #pragma unroll
-                    for (int r = 0; r < NB / 2; ++r) acc[r] = mfma_bf16(lds_a(bufA, HA, 32 * (rt + 2 * r), kb, lane), b, acc[r]);
+                    for (int q = 0; q < NS; ++q) b[q] = bufld(rs0b[q], lane16, (nt * 4 + kb) * 1024);
+#pragma unroll
+                    for (int r = 0; r < NB / 2; ++r)
+#pragma unroll
+                        for (int p = NS - 1; p >= 0; --p) {              // small terms first
+                            const u32x4 a = lds_a(bufA + p * SA, HA, 32 * (rt + 2 * r), kb, lane);
+#pragma unroll
+                            for (int q = NS - 1 - p; q >= 0; --q) acc[r] = mfma_bf16(a, b[q], acc[r]);
+                        }
                 }
 #pragma unroll
-                for (int r = 0; r < NB / 2; ++r) store_tile(acc[r], bufB, HB, 32 * (rt + 2 * r), 32 * nt, br.b0b, lane);
+                for (int r = 0; r < NB / 2; ++r) store_tile<NS>(acc[r], bufB, HB, SB, 32 * (rt + 2 * r), 32 * nt, br.b0b, lane);
             }
             __syncthreads();
             // ---- conv1 (STN pass: shared weights; main pass: this item's W1' = W1 . trans2): bufB -> bufA ----
@@ -183,12 +229,20 @@ __global__ __launch_bounds__(256, MT == 64 ? 4 : 2) void p2s_chain_bf16_kernel(C
                 for (int r = 0; r < NB / 2; ++r) acc[r] = f32x16{};
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
-                    const u32x4 b = bufld(rs1, lane16, (nt * 4 + kb) * 1024);
+                    u32x4 b[NS];
 #pragma unroll
-                    for (int r = 0; r < NB / 2; ++r) acc[r] = mfma_bf16(lds_a(bufB, HB, 32 * (rt + 2 * r), kb, lane), b, acc[r]);
+                    for (int q = 0; q < NS; ++q) b[q] = bufld(rs1[q], lane16, (nt * 4 + kb) * 1024);
+#pragma unroll
+                    for (int r = 0; r < NB / 2; ++r)
+#pragma unroll
+                        for (int p = NS - 1; p >= 0; --p) {
+                            const u32x4 a = lds_a(bufB + p * SB, HB, 32 * (rt + 2 * r), kb, lane);
+#pragma unroll
+                            for (int q = NS - 1 - p; q >= 0; --q) acc[r] = mfma_bf16(a, b[q], acc[r]);
+                        }
                 }
 #pragma unroll
-                for (int r = 0; r < NB / 2; ++r) store_tile(acc[r], bufA, HA, 32 * (rt + 2 * r), 32 * nt, br.b1, lane);
+                for (int r = 0; r < NB / 2; ++r) store_tile<NS>(acc[r], bufA, HA, SA, 32 * (rt + 2 * r), 32 * nt, br.b1, lane);
             }
             __syncthreads();
         }
@@ -199,21 +253,31 @@ __global__ __launch_bounds__(256, MT == 64 ? 4 : 2) void p2s_chain_bf16_kernel(C
             for (int r = 0; r < NB; ++r) acc[r] = f32x16{};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
-                const u32x4 b = bufld(rs2, lane16, (wave * 4 + kb) * 1024);
+                u32x4 b[NS];
 #pragma unroll
-                for (int r = 0; r < NB; ++r) acc[r] = mfma_bf16(lds_a(bufA, HA, 32 * r, kb, lane), b, acc[r]);
+                for (int q = 0; q < NS; ++q) b[q] = bufld(rs2[q], lane16, (wave * 4 + kb) * 1024);
+#pragma unroll
+                for (int r = 0; r < NB; ++r)
+#pragma unroll
+                    for (int p = NS - 1; p >= 0; --p) {
+                        const u32x4 a = lds_a(bufA + p * SA, HA, 32 * r, kb, lane);
+#pragma unroll
+                        for (int q = NS - 1 - p; q >= 0; --q) acc[r] = mfma_bf16(a, b[q], acc[r]);
+                    }
             }
 #pragma unroll
-            for (int r = 0; r < NB; ++r) store_tile(acc[r], bufB, HB, 32 * r, 32 * wave, br.b2, lane);
+            for (int r = 0; r < NB; ++r) store_tile<NS>(acc[r], bufB, HB, SB, 32 * r, 32 * wave, br.b2, lane);
         }
         __syncthreads();
         // ---- conv3 (128 -> 1024) + max over the 64 points: wave w owns column tiles [8w, 8w+8) ----
         {
-            u32x4 af[NB][8];
+            u32x4 af[NS][NB][8];
 #pragma unroll
-            for (int r = 0; r < NB; ++r)
+            for (int p = 0; p < NS; ++p)
 #pragma unroll
-                for (int kb = 0; kb < 8; ++kb) af[r][kb] = lds_a(bufB, HB, 32 * r, kb, lane);
+                for (int r = 0; r < NB; ++r)
+#pragma unroll
+                    for (int kb = 0; kb < 8; ++kb) af[p][r][kb] = lds_a(bufB + p * SB, HB, 32 * r, kb, lane);
 #pragma unroll
             for (int ct = 0; ct < 8; ++ct) {
                 const int soff = (wave * 8 + ct) * 8 * 1024;        // bytes: 8 k-blocks of 64 lanes x 16 B per column tile
@@ -222,9 +286,15 @@ __global__ __launch_bounds__(256, MT == 64 ? 4 : 2) void p2s_chain_bf16_kernel(C
                 for (int r = 0; r < NB; ++r) acc[r] = f32x16{};
 #pragma unroll
                 for (int kb = 0; kb < 8; ++kb) {
-                    const u32x4 b = bufld(rs3, lane16, soff + kb * 1024);
+                    u32x4 b[NS];
 #pragma unroll
-                    for (int r = 0; r < NB; ++r) acc[r] = mfma_bf16(af[r][kb], b, acc[r]);
+                    for (int q = 0; q < NS; ++q) b[q] = bufld(rs3[q], lane16, soff + kb * 1024);
+#pragma unroll
+                    for (int r = 0; r < NB; ++r)
+#pragma unroll
+                        for (int p = NS - 1; p >= 0; --p)
+#pragma unroll
+                            for (int q = NS - 1 - p; q >= 0; --q) acc[r] = mfma_bf16(af[p][r][kb], b[q], acc[r]);
                 }
                 float m = acc[0][0];
 #pragma unroll
@@ -255,7 +325,7 @@ __global__ __launch_bounds__(256, MT == 64 ? 4 : 2) void p2s_chain_bf16_kernel(C
 // fp32 packed B fragments ([N/32][K/8][2][32][4]: k = 8 kg + 4 kk + t, n = 32 nt + j) -> bf16 fragments
 // ([N/32][K/16][64 lanes][8]: k = 16 kb + 8 (lane >> 5) + t, n = 32 nt + (lane & 31)); one thread per output element
 __global__ void p2s_pack_bf16_kernel(const float *__restrict__ src, unsigned short *__restrict__ dst, int K, int N,
-                                     long long src_stride, long long dst_stride, int n_items) {
+                                     long long src_stride, long long dst_stride, int n_items, int piece) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per = (long long)K * N;
     if (e >= per * n_items) return;
@@ -270,7 +340,13 @@ __global__ void p2s_pack_bf16_kernel(const float *__restrict__ src, unsigned sho
     const int k = 16 * kb + 8 * (lane >> 5) + t, j = lane & 31;
     const int kg = k >> 3, kk = (k >> 2) & 1, ts = k & 3;
     const long long si = ((((long long)nt * (K / 8) + kg) * 2 + kk) * 32 + j) * 4 + ts;
-    dst[(long long)item * dst_stride + (e % per)] = f2bf(src[(long long)item * src_stride + si]);
+    float x = src[(long long)item * src_stride + si];
+    unsigned short h = f2bf(x);
+    for (int q = 0; q < piece; ++q) {                 // piece q = bf16 of the residual after the pieces before it
+        x -= __uint_as_float((unsigned)h << 16);
+        h = f2bf(x);
+    }
+    dst[(long long)item * dst_stride + (e % per)] = h;
 }
 
 }  // namespace
@@ -278,17 +354,29 @@ __global__ void p2s_pack_bf16_kernel(const float *__restrict__ src, unsigned sho
 int p2s_launch_chain_bf16(const ChainArgs &args, hipStream_t stream) {
     const int n = args.br[0].n_items + args.br[1].n_items;
     if (n <= 0) return P2S_OK;
-    hipLaunchKernelGGL(p2s_chain_bf16_kernel, dim3(n), dim3(256), 0, stream, args);
+    const int ns = args.ns < 1 ? 1 : args.ns;
+    const size_t lds = (size_t)ns * MT * (HA + HB) * 2;
+    if (ns == 1) {
+        hipLaunchKernelGGL(p2s_chain_bf16_kernel<1>, dim3(n), dim3(256), lds, stream, args);
+    } else if (ns == 2) {
+        hipLaunchKernelGGL(p2s_chain_bf16_kernel<2>, dim3(n), dim3(256), lds, stream, args);
+    } else if (ns == 3) {
+        (void)hipFuncSetAttribute((const void *)p2s_chain_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(p2s_chain_bf16_kernel<3>, dim3(n), dim3(256), lds, stream, args);
+    } else {
+        p2s_set_error("p2s_launch_chain_bf16: %d pieces unsupported", ns);
+        return P2S_EINVAL;
+    }
     P2S_LAUNCH_CHECK("p2s_chain_bf16_kernel");
     return P2S_OK;
 }
 
 int p2s_launch_pack_bf16(const float *src, unsigned short *dst, int K, int N, long long src_stride, long long dst_stride,
-                         int n_items, hipStream_t stream) {
+                         int n_items, int piece, hipStream_t stream) {
     const long long total = (long long)K * N * n_items;
     if (total <= 0) return P2S_OK;
     hipLaunchKernelGGL(p2s_pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, K, N,
-                       src_stride, dst_stride, n_items);
+                       src_stride, dst_stride, n_items, piece);
     P2S_LAUNCH_CHECK("p2s_pack_bf16_kernel");
     return P2S_OK;
 }

@@ -53,13 +53,17 @@ struct ChainBranch {
 struct ChainArgs {
     ChainBranch br[2];       // br[0] items come first in the grid
     int ablate;              // only read when built with -DP2S_DEV_ABLATE (timing variants: 1 = conv3 only, 2 = all but conv3)
+    // bf16 kernels: number of bf16 pieces per operand (1 = plain bf16, 2 / 3 = split precision) and the distance in
+    // halfs between the pieces of a weight array (shared weights / per-item W1')
+    int ns;
+    long long piece_stride, w1_piece_stride;
 };
 int p2s_launch_chain(const ChainArgs &args, hipStream_t stream);
 // bf16 variant (p2s_chain_bf16.hip): w0b / w1 / w2 / w3 point to bf16 fragment arrays, w1_item_stride counts halfs
 int p2s_launch_chain_bf16(const ChainArgs &args, hipStream_t stream);
 // fp32 packed B fragments -> bf16 fragments, n_items matrices of K x N
 int p2s_launch_pack_bf16(const float *src, unsigned short *dst, int K, int N, long long src_stride, long long dst_stride,
-                         int n_items, hipStream_t stream);
+                         int n_items, int piece, hipStream_t stream);
 
 // W1' = (BN-folded conv1) . trans2, written in packed B-fragment order.  grid.y = encoder
 struct FoldArgs {

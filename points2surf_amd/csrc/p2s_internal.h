@@ -27,7 +27,8 @@ struct p2s_model_s {
     float *blob = nullptr;
     size_t n_floats = 0;
     // bf16 encoder (cfg.encoder_bf16): bf16 B fragments of the per-point layers, converted once at creation
-    unsigned short *blob_h = nullptr;
+    unsigned short *blob_h = nullptr;      // [pieces][h_total] (cfg.encoder_bf16 = number of bf16 pieces per operand)
+    size_t h_total = 0;
     size_t h_w0b[2] = {}, h_s1[2] = {}, h_s2[2] = {}, h_s3[2] = {}, h_m2[2] = {}, h_m3[2] = {}, h_qc2 = 0, h_qc3 = 0;
     float *ws = nullptr;      // per-chunk workspace, grown on demand
     int ws_chunk = 0;

@@ -116,7 +116,7 @@ def _engine_cfg(train_opt, pred_dim):
         uniform_subsample=bool(getattr(train_opt, 'uniform_subsample', 0)),
         fixed_subsample=bool(getattr(train_opt, 'fixed_subsample', 0)),
         # opt-in reduced precision (BASELINE configs[3]): per-point encoder layers on bf16 MFMA, everything else fp32
-        encoder_bf16=os.environ.get('P2S_ENCODER', 'fp32') == 'bf16')
+        encoder_bf16={'fp32': 0, 'bf16': 1, 'bf16x2': 2, 'bf16x3': 3}[os.environ.get('P2S_ENCODER', 'fp32')])
 
 
 def _load_points(indir, shape_name):
@@ -227,8 +227,7 @@ def points_to_surf_eval(eval_opt):
     world, rank, local_rank = _sharding.dist_env()
     if world > 1 and 'MASTER_PORT' in os.environ:        # launched by torchrun (tests run "ranks" one after the other)
         _sharding.init_process_group()
-    device = torch.device('cuda', eval_opt.gpu_idx if world == 1 else local_rank)
-    torch.cuda.set_device(device)
+    device = _engine.select_device(eval_opt.gpu_idx if world == 1 else local_rank)
 
     for model_name in models:
         print('Random Seed: %d' % eval_opt.seed)
@@ -285,7 +284,7 @@ def points_to_surf_eval(eval_opt):
                     continue
                 cloud = _engine.Cloud(_load_points(eval_opt.indir, shape_name), device=device)
                 q_np = _load_query_points(eval_opt.indir, shape_name)
-                sdf = _engine.infer_queries(model, cloud, rng_dev, rng_rot, torch.from_numpy(q_np).to(device), chunk=chunk)
+                sdf = _engine.infer_queries(model, cloud, rng_dev, rng_rot, _engine.upload(q_np, device), chunk=chunk)
                 sdf_np = sdf.cpu().numpy()
                 total_q += sdf_np.shape[0]
                 pending.append(writers.submit(_save_shape, model_out_dir, shape_name, sdf_np, q_np, False))

@@ -32,6 +32,20 @@ def _f32c(t, device):
     return t.contiguous()
 
 
+def select_device(index):
+    """make ``cuda:index`` current (the drop-in's --gpu_idx / LOCAL_RANK) and return it"""
+    if not torch.cuda.is_available():
+        raise RuntimeError('points2surf_amd needs a ROCm GPU (gfx950); no CPU fallback exists')
+    dev = torch.device('cuda', int(index))
+    torch.cuda.set_device(dev)
+    return dev
+
+
+def upload(array, device):
+    """host array -> contiguous device tensor (container only)"""
+    return torch.from_numpy(np.ascontiguousarray(array)).to(device)
+
+
 class Model:
     """Engine-side model: BN-folded, MFMA-packed weights resident in HBM.
 

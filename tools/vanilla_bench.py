@@ -20,13 +20,13 @@ def main():
     ap.add_argument('--res', type=int, default=256)
     ap.add_argument('--sub-queries', type=int, default=4096)
     ap.add_argument('--skip-pipeline', action='store_true')
-    ap.add_argument('--bf16', action='store_true', help='bf16 encoder + fp32 decoder (BASELINE configs[3])')
+    ap.add_argument('--bf16', nargs='?', const=1, default=0, type=int, help='bf16 encoder + fp32 decoder (BASELINE configs[3]); 2 / 3 = split bf16')
     args = ap.parse_args()
     import torch
     from points2surf_amd import engine, synth
     w, cfg = synth.make_weights('p2s_vanilla')
     if args.bf16:
-        cfg = dict(cfg, encoder_bf16=True)
+        cfg = dict(cfg, encoder_bf16=int(args.bf16))
     model = engine.Model(w, cfg)
     model.set_profiling(True)
     pts = synth.make_cloud(args.points, seed=1000)
