@@ -211,7 +211,10 @@ def main():
         chain_ms = acc.get('ms_chain_stn', 0.0) + acc.get('ms_chain_main', 0.0)
         avg_launch_ms = chain_ms / launches
         flop_per_launch = FLOP_CHAIN_PER_QUERY * n_queries / launches
-        achieved = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+        # split precision executes 3 (two pieces) / 6 (three pieces) bf16 MFMA passes per algorithmic product: the
+        # roofline of those modes is priced in executed bf16 FLOP against the dense bf16 peak
+        passes = {0: 1, 1: 1, 2: 3, 3: 6}[int(args.bf16)]
+        achieved = passes * flop_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
         peak = 2500.0 if args.bf16 else PEAK_FP32_MFMA_TFLOPS     # dense MFMA peak of the compute dtype
         # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
         # committed under profiles/; they cannot be collected from inside this process
@@ -243,7 +246,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'p2s_chain_bf16_kernel' if args.bf16 else 'p2s_chain_kernel', 'launches': int(launches), 'avg_launch_ms': avg_launch_ms,
-                         'algorithmic_flop_per_launch': flop_per_launch,
+                         'algorithmic_flop_per_launch': flop_per_launch, 'mfma_passes_per_product': passes,
                          'hbm_algorithmic_GBps': value / world * BYTES_PER_QUERY / 1e9},
             'stage_ms_rank0': {k: acc[k] for k in sorted(acc) if k.startswith('ms_')},
         }

@@ -19,8 +19,11 @@ def main():
     ap.add_argument('--model', default='p2s_max')
     ap.add_argument('--B', type=int, default=4096)
     ap.add_argument('--iters', type=int, default=3)
+    ap.add_argument('--bf16', type=int, default=0, help='0 fp32, 1 bf16, 2 / 3 split bf16 encoder')
     args = ap.parse_args()
     w, cfg = synth.make_weights(args.model)
+    if args.bf16:
+        cfg = dict(cfg, encoder_bf16=args.bf16)
     m = engine.Model(w, cfg)
     g = torch.Generator(device='cuda').manual_seed(0)
     B = args.B
