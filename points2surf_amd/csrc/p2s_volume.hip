@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256) void vol_sweep_kernel(unsigned char *__restric
                                                         int *__restrict__ tcnt) {
     __shared__ unsigned A[VA_X * VA_Y * VA_ZS];
     __shared__ unsigned B[VA_X * VA_Y * VB_ZS];
-    __shared__ unsigned C[VA_X * VT_Y * VB_ZS];
+    unsigned *C = A;      // the zy sums overlay the staged tile (its interior bytes are kept in registers): 34.6 KB, 4 workgroups / CU
+    static_assert(VA_X * VT_Y * VB_ZS <= VA_X * VA_Y * VA_ZS, "C must fit into A");
     __shared__ int red[2][4];
     __shared__ unsigned long long s_dec[3];
     __shared__ int s_changed;
@@ -329,6 +330,13 @@ __global__ __launch_bounds__(256) void vol_sweep_kernel(unsigned char *__restric
         }
     }
     if (!active) return;
+    // this lane's interior state bytes (its 8 output dwords, thread = (y, z dword)): read now, A is recycled below
+    unsigned raw_in[VT_X];
+    {
+        const int y = tid / (VT_Z / 4), zd = tid - y * (VT_Z / 4);
+#pragma unroll
+        for (int x = 0; x < VT_X; ++x) raw_in[x] = A[((x + VT_H) * VA_Y + (y + VT_H)) * VA_ZS + zd + 1];
+    }
     // All sums are kept BIASED: sign + 1 in {0, 1, 2} per byte, so the z / zy / zyx sums are <= 10 / 50 / 250 -- plain
     // 32-bit adds and subtracts never carry between bytes (the carry-safe SWAR add costs 7 ops, this costs 1), and the
     // y and x passes slide their window (out[y] = out[y-1] + entering - leaving).  tap range: offsets [t_lo, t_hi].
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(256) void vol_sweep_kernel(unsigned char *__restric
             }
             const int gx = x0 + x;
             if (inside_yz && gx < res) {
-                const unsigned raw = A[((x + VT_H) * VA_Y + (y + VT_H)) * VA_ZS + zd + 1];
+                const unsigned raw = raw_in[x];
                 // per-byte compares on the even / odd bytes as 16-bit lanes: bit 8 of (x | 0x100) - c is x >= c
                 const unsigned ev = acc & 0x00ff00ffu, od = (acc >> 8) & 0x00ff00ffu;
                 const unsigned pe = (((ev | 0x01000100u) - c_pos) >> 8) & 0x00010001u, po = (((od | 0x01000100u) - c_pos) >> 8) & 0x00010001u;
@@ -543,19 +551,39 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
         // the number of sweeps is data dependent (the front advances ~2 voxels per sweep): batches without a host
         // round trip; launches behind the final sweep exit at once
         const int batch = getenv("P2S_VOLUME_BATCH") ? std::max(1, atoi(getenv("P2S_VOLUME_BATCH"))) : 16;
+        // The verdict of batch j is copied out behind it and looked at only after batch j + 1 has been queued: the host
+        // round trip (~70 us) is off the critical path; a finished run makes the extra batch exit at once.
+        static thread_local VolState *pinned = nullptr;
+        static thread_local hipEvent_t look[2] = {nullptr, nullptr};
+        if (!pinned) {
+            if (hipHostMalloc((void **)&pinned, 2 * sizeof(VolState), hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&look[0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&look[1], hipEventDisableTiming) != hipSuccess) {
+                pinned = nullptr;
+                p2s_set_error("p2s_sdf_volume: pinned verdict buffer: %s", hipGetErrorString(hipGetLastError()));
+                return cleanup(P2S_ENOMEM);
+            }
+        }
         VolState host_vs;
         memset(&host_vs, 0, sizeof(host_vs));
         int k = 0;
         const int k_max = 64 * grid_res + 64;            // far beyond any possible run; guards the host loop only
-        while (k < k_max) {
-            for (int j = 0; j < batch; ++j, ++k)
+        bool flag_checked = false;
+        for (int j = 0; k < k_max; ++j) {
+            for (int t = 0; t < batch; ++t, ++k)
                 hipLaunchKernelGGL(vol_sweep_kernel, tg, dim3(256), 0, s, buf0, buf1, grid_res, k, taps, certainty_threshold, vs, act, tcnt);
-            if (hipMemcpyAsync(&host_vs, vs, sizeof(VolState), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                hipStreamSynchronize(s) != hipSuccess) {
+            if (hipMemcpyAsync(&pinned[j & 1], vs, sizeof(VolState), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipEventRecord(look[j & 1], s) != hipSuccess) {
                 p2s_set_error("p2s_sdf_volume: %s", hipGetErrorString(hipGetLastError()));
                 return cleanup(P2S_EHIP);
             }
-            if (k == batch) {                                           // scatter error flag, first batch only
+            if (j == 0) continue;                        // look at batch j - 1 now that batch j is queued
+            if (hipEventSynchronize(look[(j - 1) & 1]) != hipSuccess) {
+                p2s_set_error("p2s_sdf_volume: %s", hipGetErrorString(hipGetLastError()));
+                return cleanup(P2S_EHIP);
+            }
+            if (!flag_checked) {                         // scatter error flag, once
+                flag_checked = true;
                 int flag = 0;
                 (void)hipMemcpy(&flag, counts + 2 * NSHARD, 4, hipMemcpyDeviceToHost);
                 if (flag) {
@@ -563,7 +591,21 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
                     return cleanup(P2S_EINVAL);
                 }
             }
+            host_vs = pinned[(j - 1) & 1];
             if (host_vs.done) break;
+        }
+        if (!host_vs.done) {                             // the verdict may sit in the batch queued last
+            if (hipStreamSynchronize(s) == hipSuccess) {
+                (void)hipMemcpy(&host_vs, vs, sizeof(VolState), hipMemcpyDeviceToHost);
+                if (!flag_checked) {
+                    int flag = 0;
+                    (void)hipMemcpy(&flag, counts + 2 * NSHARD, 4, hipMemcpyDeviceToHost);
+                    if (flag) {
+                        p2s_set_error("p2s_sdf_volume: query point outside the [-1,1) volume");
+                        return cleanup(P2S_EINVAL);
+                    }
+                }
+            }
         }
         if (!host_vs.done) {
             p2s_set_error("p2s_sdf_volume: sign propagation did not terminate within %d sweeps", k_max);

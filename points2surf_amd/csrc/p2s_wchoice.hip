@@ -359,6 +359,10 @@ struct WcQuery {
     const uint32_t *words;       // word o of this query's first draw at words[0]
     long long words_left;        // words available from there
     int n, K, nsel;
+    // optional: the first round's look-ups, already done by the speculation pass for the draws of its window
+    // (bin, S_bin, S_{bin-1} of draw d at pre_bin[d], pre_s[d]); null = look them up here
+    const int *pre_bin;
+    const double2 *pre_s;
 };
 
 template <bool WRITE>
@@ -383,7 +387,21 @@ __device__ __forceinline__ long long wc_full_query(const WcQuery &qa, const WcLd
             bins[j] = 0;
             sb[j] = sp[j] = 0.0;
         }
-        if (m_found == 0) {
+        if (m_found == 0 && qa.pre_bin) {
+            // first round from the speculation pass's window: three coalesced loads per draw instead of the guide
+            // record + the S values around the bin (random accesses: most of this function's time under load)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = tid * per + j;
+                if (j < per && d < m) {
+                    valid |= 1u << j;
+                    bins[j] = qa.pre_bin[d];
+                    const double2 ss = qa.pre_s[d];
+                    sb[j] = ss.x;
+                    sp[j] = ss.y;
+                }
+            }
+        } else if (m_found == 0) {
             // first round (nothing found yet, every lane has up to 4 draws): straight-line code, lanes past the last
             // draw repeat it, so that all loads of a phase are in flight together
             uint2 wpair[4];
@@ -949,6 +967,8 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a_in) {
             qa.n = a.n;
             qa.K = a.K;
             qa.nsel = a.nsel;
+            qa.pre_bin = nullptr;
+            qa.pre_s = nullptr;
             used = wc_full_query<false>(qa, l, wsum, wsumd, nullptr);
             for (int i = tid; i < 2 * WC_CELLW; i += WC_NT) ((uint32_t *)wc_lds)[i] = 0;    // cell maps overlay its arrays
             wc_lds_barrier();
@@ -1056,6 +1076,8 @@ struct WcSpec {
     long long *klo;           // [SP_B] word offset of candidate 0
     long long *ctl;           // [0] first unresolved query, [1] its word offset
     const float *mu;          // [nq] expected first-round collisions
+    int *win_bin;             // [SP_B][SP_NB] first-round bin of every draw of the window (-1: past the request)
+    double2 *win_s;           // [SP_B][SP_NB] (S_bin, S_{bin-1}) of it: what the complete algorithm needs of round 1
 };
 
 __global__ void wc_ctl_init_kernel(long long *ctl, const long long *meta) {
@@ -1106,11 +1128,22 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
                 bk = bk > a.K - 1 ? a.K - 1 : bk;
                 const WcRec rec = Rq[bk];
                 bin = wc_quick_bin(rec.c0, rec.i, rec.more, x);
-                if (bin < 0) bin = wc_finish(Sq, a.n, rec.i + 1, 0, a.n, 0.0, Stot, x).bin;
+                double2 ss;
+                if (bin < 0) {
+                    const WcLoc L = wc_finish(Sq, a.n, rec.i + 1, 0, a.n, 0.0, Stot, x);
+                    bin = L.bin;
+                    ss = make_double2(L.s, L.sprev);
+                } else {
+                    ss = make_double2(Sq[bin], bin > 0 ? Sq[bin - 1] : 0.0);
+                }
+                sp.win_s[(size_t)i * SP_NB + e] = ss;
             }
         }
         xs[e] = x;
-        if (e < nb) bins[e] = bin;
+        if (e < nb) {
+            bins[e] = bin;
+            sp.win_bin[(size_t)i * SP_NB + e] = bin;
+        }
     }
     __syncthreads();
     // ---- draws that share their bin with another draw of the window: hash bin -> count
@@ -1251,6 +1284,8 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp) {
     for (int i = tid; i < lim; i += 256) s_klo[i] = sp.klo[i];
     long long s = sp.ctl[1];
     int i = 0;
+    long long t_fb = 0, n_fb = 0;
+    const long long t_start = a.stats ? wall_clock64() : 0;
     __syncthreads();
     for (;;) {
         if (tid == 0) {
@@ -1288,6 +1323,7 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp) {
             return;
         }
         if (ev != 1) break;
+        const long long t0 = a.stats ? wall_clock64() : 0;
         WcQuery qa;
         qa.Sq = a.S + (size_t)(qb + i) * a.n;
         qa.Rq = a.R + (size_t)(qb + i) * a.K;
@@ -1297,6 +1333,11 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp) {
         qa.n = a.n;
         qa.K = a.K;
         qa.nsel = a.nsel;
+        {
+            const long long d = (s - s_klo[i]) >> 1;          // inside the window (checked by the walk above)
+            qa.pre_bin = sp.win_bin + ((size_t)i * SP_NB + d);
+            qa.pre_s = sp.win_s + ((size_t)i * SP_NB + d);
+        }
         const long long used = wc_full_query<false>(qa, l, wsum, wsumd, nullptr);
         if (used < 0) {
             if (tid == 0) {
@@ -1308,9 +1349,18 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp) {
         if (tid == 0) a.base[qb + i] = s;
         s += used;
         ++i;
+        if (a.stats) {
+            t_fb += wall_clock64() - t0;
+            ++n_fb;
+        }
         __syncthreads();
     }
     if (tid == 0) {
+        if (a.stats) {
+            atomicAdd((unsigned long long *)&a.stats[12], (unsigned long long)n_fb);
+            atomicAdd((unsigned long long *)&a.stats[13], (unsigned long long)t_fb);
+            atomicAdd((unsigned long long *)&a.stats[14], (unsigned long long)(wall_clock64() - t_start));
+        }
         sp.ctl[0] = qb + i;
         sp.ctl[1] = s;
         if (qb + i >= a.nq) a.meta[0] = s;
@@ -1342,6 +1392,8 @@ __global__ __launch_bounds__(256) void wc_ids_kernel(WcArgs a) {
     qa.n = a.n;
     qa.K = a.K;
     qa.nsel = a.nsel;
+    qa.pre_bin = nullptr;
+    qa.pre_s = nullptr;
     const long long used = wc_full_query<true>(qa, l, wsum, wsumd, a.ids_out + (size_t)q * a.nsel);
     if (a.fixed) {
         // rng.seed(42) before every query: the generator ends where the LAST query of the call left it
@@ -1457,7 +1509,7 @@ int wc_reserve(p2s_rng_s *r, size_t nq, size_t n, size_t K) {
     nq = std::max(nq, r->wc_cap_q);
     if (hipMalloc(&r->wc_dist, nq * n * 4) != hipSuccess || hipMalloc(&r->wc_S, nq * n * 8) != hipSuccess ||
         hipMalloc(&r->wc_T, nq * K * sizeof(WcRec)) != hipSuccess ||
-        hipMalloc(&r->wc_stot, nq * 32 + (size_t)SP_B * SP_W + (size_t)SP_B * 8 + 64) != hipSuccess) {
+        hipMalloc(&r->wc_stot, nq * 32 + (size_t)SP_B * SP_W + (size_t)SP_B * 8 + 64 + (size_t)SP_B * SP_NB * 20 + 64) != hipSuccess) {
         (void)hipGetLastError();
         p2s_set_error("weighted sub-sample: hipMalloc of the per-query tables failed (%zu queries x %zu points)", nq, n);
         return P2S_ENOMEM;
@@ -1550,6 +1602,8 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     sp.klo = sp.ctl + 8;
     sp.rtab = (unsigned char *)(sp.klo + SP_B);
     sp.mu = mu;
+    sp.win_s = (double2 *)(((uintptr_t)(sp.rtab + (size_t)SP_B * SP_W) + 15) & ~(uintptr_t)15);
+    sp.win_bin = (int *)(sp.win_s + (size_t)SP_B * SP_NB);
     const bool serial_only = getenv("P2S_WC_SERIAL") != nullptr;            // development / A-B: the serial kernel alone
     const size_t lds_ids = wc_lds_bytes(n);
     size_t lds_off = wc_offsets_lds_bytes(n);
@@ -1629,7 +1683,7 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
             (void)hipStreamSynchronize(s);
             fprintf(stderr, "[wc stats] %d queries: %lld full-algorithm fallbacks, %lld window misses; 10-ns ticks: "
                             "A %lld issue %lld mark %lld sepcheck %lld clear+fallback %lld B %lld ring %lld; kernel %lld ticks = "
-                            "%lld shader clocks; chain passes that did work %lld\n", cur, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+                            "%lld shader clocks; chain passes that did work %lld, in-place fallbacks %lld taking %lld of %lld 10-ns ticks\n", cur, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14]);
         }
         done += cur;
     }
