@@ -15,6 +15,25 @@ void p2s_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+void *p2s_scratch(int device, size_t bytes) {
+    struct Slot { void *p = nullptr; size_t cap = 0; };
+    static thread_local Slot slots[16];
+    if (device < 0 || device >= 16) return nullptr;
+    Slot &sl = slots[device];
+    if (bytes <= sl.cap) return sl.p;
+    if (sl.p) (void)hipFree(sl.p);
+    sl.p = nullptr;
+    sl.cap = 0;
+    const size_t want = bytes + bytes / 8;
+    if (hipMalloc(&sl.p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        sl.p = nullptr;
+        return nullptr;
+    }
+    sl.cap = want;
+    return sl.p;
+}
+
 extern "C" {
 
 int p2s_abi_version(void) { return P2S_ABI_VERSION; }

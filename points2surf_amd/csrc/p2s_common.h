@@ -10,6 +10,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void p2s_set_error(const char *fmt, ...);
+// grow-only scratch buffer of the calling host thread on `device` (volume / iso-surface stages: ~0.5 ms of
+// hipMalloc + hipFree per call otherwise); valid until the thread's next request on that device; nullptr on failure.
+// Callers synchronise their stream before returning, so the buffer is idle between calls.
+void *p2s_scratch(int device, size_t bytes);
 
 #define P2S_HIP_CHECK(expr)                                                                   \
     do {                                                                                      \

@@ -520,16 +520,14 @@ extern "C" int p2s_marching_cubes(const float *vol_dev, int grid_res, float *ver
     const long long nvox = (long long)grid_res * grid_res * grid_res;
     const long long nblk = (nvox + 255) / 256;
     // scratch: vmask (1) + tcount (1) + vbase (4) + tbase (8) per point; block totals + offsets; results
-    char *scratch = nullptr;
     const size_t bytes = (size_t)nvox * 14 + (size_t)nblk * (8 + 16) + 64 * 8 + 256;
-    if (hipMalloc(&scratch, bytes) != hipSuccess) {
-        (void)hipGetLastError();
+    char *scratch = (char *)p2s_scratch(device, bytes);
+    if (!scratch) {
         p2s_set_error("p2s_marching_cubes: hipMalloc(%zu bytes) failed", bytes);
         return P2S_ENOMEM;
     }
     auto cleanup = [&](int code) {
-        (void)hipStreamSynchronize(s);
-        (void)hipFree(scratch);
+        (void)hipStreamSynchronize(s);       // the scratch buffer is idle again when we return
         return code;
     };
     long long *tbase = (long long *)scratch;

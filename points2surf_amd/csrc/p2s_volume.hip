@@ -499,18 +499,16 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
     const bool fast = (grid_res % 16 == 0) && sigma <= 5 && !getenv("P2S_VOLUME_GENERIC");
     // scratch, fast path: two state bytes per voxel (ping-pong) + the sweep state.  Generic path: sign (1) +
     // unknown_initially (1) + new sign (1) + z sums (1) + zy sums (2) bytes per voxel
-    char *scratch = nullptr;
-    unsigned long long *counts = nullptr;   // [0..64) zeros of s, [64..128) zeros of new, [128] error flag (as int)
-    if (hipMalloc(&scratch, (size_t)nvox * (fast ? 2 : 7) + sizeof(VolState) + 256 + (size_t)(nvox / 512 + 64) * 12) != hipSuccess || hipMalloc(&counts, (2 * NSHARD + 2) * 8) != hipSuccess) {
-        if (scratch) (void)hipFree(scratch);
-        p2s_set_error("p2s_sdf_volume: hipMalloc(%lld bytes) failed", nvox * (fast ? 2 : 7));
-        (void)hipGetLastError();
+    const size_t scratch_bytes = (size_t)nvox * (fast ? 2 : 7) + sizeof(VolState) + 256 + (size_t)(nvox / 512 + 64) * 12;
+    const size_t counts_at = (scratch_bytes + 63) & ~(size_t)63;
+    char *scratch = (char *)p2s_scratch(device, counts_at + (2 * NSHARD + 2) * 8);
+    if (!scratch) {
+        p2s_set_error("p2s_sdf_volume: hipMalloc(%zu bytes) failed", counts_at);
         return P2S_ENOMEM;
     }
+    unsigned long long *counts = (unsigned long long *)(scratch + counts_at);   // [0..64) zeros of s, [64..128) zeros of new, [128] error flag
     auto cleanup = [&](int code) {
-        (void)hipStreamSynchronize(s);
-        (void)hipFree(scratch);
-        (void)hipFree(counts);
+        (void)hipStreamSynchronize(s);       // the scratch buffer is idle again when we return
         return code;
     };
     const unsigned grid = (unsigned)((nvox + 255) / 256);

@@ -206,3 +206,21 @@ def test_speculative_offsets_across_blocks_match_numpy_and_serial_kernel(fixture
     got3 = r3.subsample_weighted(cloud, q, 1000, want_pts=False)[0].cpu().numpy()
     r3.check()
     assert np.array_equal(got3, got) and nq == 1300
+
+
+def test_weighted_at_the_size_cap(torch_cuda):
+    """the largest clouds the weighted sub-sample takes (LDS bitmap of the in-place algorithm): 170,000
+    points work and match numpy; 260,000 are refused with an error code, not a wrong result"""
+    from points2surf_amd import engine, _lib
+    g = np.random.default_rng(17)
+    pts = g.uniform(-0.7, 0.7, (170000, 3)).astype(np.float32)
+    q = g.uniform(-0.5, 0.5, (3, 3)).astype(np.float32)
+    cloud = engine.Cloud(pts)
+    r = engine.Rng(3)
+    got = r.subsample_weighted(cloud, torch_cuda.from_numpy(q).cuda(), 1000, want_pts=False)[0].cpu().numpy()
+    r.check()
+    ref, rs = _numpy_reference(3, pts, q, 1000)
+    assert np.array_equal(got, ref)
+    big = engine.Cloud(g.uniform(-0.7, 0.7, (260000, 3)).astype(np.float32))
+    with pytest.raises(_lib.P2SError):
+        engine.Rng(3).subsample_weighted(big, torch_cuda.from_numpy(q).cuda(), 1000, want_pts=False)

@@ -22,6 +22,15 @@ for _ in range(3):
 torch.cuda.synchronize()
 dt = (time.time() - t0) / 3
 nv = res ** 3
+v, f, inv = engine.marching_cubes(vol)
+torch.cuda.synchronize()
+t0 = time.time()
+for _ in range(3):
+    v, f, inv = engine.marching_cubes(vol)
+torch.cuda.synchronize()
+dt_mc = (time.time() - t0) / 3
+print(json.dumps({'res': res, 'marching_cubes_ms': dt_mc * 1e3, 'vertices': int(v.shape[0]), 'faces': int(f.shape[0]),
+                  'GBps_volume_read_4B_per_voxel': 4.0 * nv / dt_mc / 1e9}))
 print(json.dumps({'res': res, 'queries': int(q.shape[0]), 'sweeps': it, 'ms': dt * 1e3, 'ms_per_sweep': dt * 1e3 / max(it, 1),
                   'GBps_algorithmic_2B_per_voxel_sweep': 2.0 * nv * it / dt / 1e9,
                   'unknown_left': int((vol == 0).sum().item())}))
