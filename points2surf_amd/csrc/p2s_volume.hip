@@ -168,7 +168,10 @@ __global__ void vol_compose_kernel(float *__restrict__ vol, const signed char *_
 // of those counters, workgroup 0 records the verdict.  Sweeps are launched in batches; a finished run makes the
 // remaining launches of its batch exit at once; the host looks at the verdict once per batch.
 // ---------------------------------------------------------------------------------------------
-constexpr int VT_X = 8, VT_Y = 16, VT_Z = 64, VT_H = 2;
+#ifndef P2S_VT_Y
+#define P2S_VT_Y 16
+#endif
+constexpr int VT_X = 8, VT_Y = P2S_VT_Y, VT_Z = 64, VT_H = 2;     // VT_Y <= 16 (one thread per (y, z dword) of 256)
 constexpr int VA_X = VT_X + 2 * VT_H, VA_Y = VT_Y + 2 * VT_H;      // halo'd rows
 constexpr int VA_ZD = VT_Z / 4 + 2, VA_ZS = VA_ZD + 1;             // dwords per halo'd row (+1: odd stride, no bank conflicts)
 constexpr int VB_ZS = VT_Z / 4 + 1;
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256) void vol_sweep_kernel(unsigned char *__restric
 #pragma unroll
         for (int ax = 0; ax < VA_X; ++ax) v[ax] = C[(ax * VT_Y + y) * VB_ZS + zd];
         const int gy = y0 + y, gz = z0 + 4 * zd;
-        const bool inside_yz = gy < res && gz < res;
+        const bool inside_yz = y < VT_Y && gy < res && gz < res;
         // |a| < thr -> 0 for the integer a = acc - bias:  a >= T  <=>  acc >= bias + T ;  a <= -T  <=>  !(acc >= bias - T + 1)
         const int bias = nt * nt * nt;
         const int T = thr > 1.0f ? (int)ceilf(thr) : 1;
