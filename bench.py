@@ -103,7 +103,7 @@ def respawn(args):
     import socket
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < args.gpus and (args.backend or 'nccl') == 'nccl':
+    if have < args.gpus and (args.backend or 'nccl') == 'nccl' and not os.environ.get('P2S_BENCH_SHARE_GPU'):
         raise SystemExit('bench.py --gpus %d: %d ranks requested but %d device(s) visible -- refusing to report a '
                          '%d-GPU number from fewer GPUs' % (args.gpus, args.gpus, have, args.gpus))
     with socket.socket() as s:
@@ -128,11 +128,19 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the HIP engine has no CPU fallback')
-    if world > torch.cuda.device_count():
+    share = bool(os.environ.get('P2S_BENCH_SHARE_GPU'))      # rehearsal of the N > 1 control flow on a 1-GPU box (gloo)
+    if world > torch.cuda.device_count() and not share:
         raise SystemExit('bench.py: %d ranks, %d device(s)' % (world, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if world > 1:
-        sharding.init_process_group(args.backend)
+        if share and (args.backend or 'nccl') == 'nccl':
+            raise SystemExit('P2S_BENCH_SHARE_GPU needs --backend gloo (RCCL refuses two ranks on one device)')
+        if share:        # init by hand: sharding.init_process_group binds LOCAL_RANK to its own device
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        else:
+            sharding.init_process_group(args.backend)
+    cdev = sharding.collective_device(torch.device('cuda', torch.cuda.current_device()))
 
     w, cfg = synth.make_weights('p2s_max')
     if args.bf16:
@@ -194,10 +202,10 @@ def main():
     dt = time.time() - t0
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        nq = torch.tensor([n_queries], dtype=torch.int64, device='cuda')
+        nq = torch.tensor([n_queries], dtype=torch.int64, device=cdev)
         dist.all_reduce(nq, op=dist.ReduceOp.SUM)
         total_queries = int(nq.item())
         if rank == 0 and gathered != total_queries:
@@ -233,13 +241,14 @@ def main():
         out = {
             'metric': 'SDF queries/sec/GPU (p2s_max, %d^3 grid%s)' % (args.res, (', bf16 encoder' if args.bf16 == 1 else ', split bf16x%d encoder' % args.bf16) if args.bf16 else ''),
             'value': value, 'unit': 'queries/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': world if not share else 1, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / max(args.steps, 1) * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': ('bf16' if args.bf16 == 1 else 'bf16x%d' % args.bf16) if args.bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[2]: p2s_max, grid_res=%d, eps=3, kNN patch=300 / global ' % args.res +
                                    'sub=1000, fp32; %s, one shape per rank per step; seeded random-init weights '
                                    '(Famous set / pretrained weights not available offline)' % workload,
-                       'queries_per_shape_rank0': int(sdf.shape[0]), 'parallelism': 'shape-sharded x%d' % world,
+                       'queries_per_shape_rank0': int(sdf.shape[0]),
+                       'parallelism': 'shape-sharded x%d' % world + (' (REHEARSAL: all ranks share one GPU, gloo)' if share else ''),
                        'rng_mode': args.rng_mode,
                        'shapes_per_hour': world * args.steps / dt * 3600.0,
                        'queries_per_s_per_gpu': value / world},

@@ -64,6 +64,16 @@ def init_process_group(backend=None):
     return world, rank, local_rank
 
 
+def collective_device(device):
+    """where tensors of a collective live: the GPU with RCCL (backend nccl), host memory with gloo (CPU tests, and the
+    2-ranks-on-one-GPU rehearsal of bench.py)"""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() != 'nccl':
+        return torch.device('cpu')
+    return device
+
+
 def gather_variable(t, dst=0):
     """Gather 1-D tensors of different lengths to ``dst``.  Returns the list (by rank) on ``dst``,
     None elsewhere.  One all_gather of the sizes + one padded gather (the path's only collective)."""
@@ -72,6 +82,7 @@ def gather_variable(t, dst=0):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [t]
     world, rank = dist.get_world_size(), dist.get_rank()
+    t = t.to(collective_device(t.device))
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)

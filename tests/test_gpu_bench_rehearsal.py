@@ -1,0 +1,30 @@
+"""GPU: rehearsal of bench.py's N > 1 control flow on a one-GPU box -- two ranks share the GPU, collectives over gloo
+(``P2S_BENCH_SHARE_GPU=1 --backend gloo``; RCCL refuses two ranks on one device).  Exercises everything the driver's
+multi-GPU run executes except the RCCL transport itself: self-spawn through torch.distributed.run, process-group
+set-up, one shape per rank per step with the other rank's draws skipped (exact dataset stream) or per-shape seeds,
+sharding.gather_variable, the max-over-ranks timing and the single JSON line of rank 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('mode', ['dataset', 'per_shape'])
+def test_two_ranks_on_one_gpu(mode):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['P2S_BENCH_SHARE_GPU'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2',
+                        '--warmup', '1', '--res', '32', '--rng-mode', mode], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    lines = [l for l in r.stdout.split('\n') if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-1500:]                      # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d['config']['rng_mode'] == mode and 'REHEARSAL' in d['config']['parallelism'] and d['n_gpus'] == 1
+    assert d['config']['queries_per_shape_rank0'] == 2976 and d['value'] > 0 and d['steps'] == 2
+    assert d['roofline']['launches'] > 0 and 'cpu_baseline' not in d
