@@ -144,3 +144,23 @@ def test_unmodified_full_eval_py_runs_through_the_dropin(tmp_path, monkeypatch):
     from points2surf_amd import ply
     v, f = ply.read_ply(os.path.join(root, 'rec', 'mesh', shape + '.ply'))
     assert v.shape[0] > 100 and f.shape[0] > 200
+
+
+def test_launcher_resolves_the_dropin_for_the_reference_cli():
+    """``python full_eval.py`` would import the reference's own ``source`` (script directory first on sys.path); the
+    launcher runs the same unmodified file with the drop-in in front: its argument parser answers ``--help``"""
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=REPO)
+    r = subprocess.run([sys.executable, '-m', 'points2surf_amd.dropin.run', os.path.join(REFERENCE, 'full_eval.py'), '--help'],
+                       cwd=REFERENCE, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'the engine has no CPU path' in r.stdout and '--query_grid_resolution' in r.stdout
+    # and without a GPU the real run stops at the engine's own check, not at a missing trimesh / skimage import
+    r = subprocess.run([sys.executable, '-m', 'points2surf_amd.dropin.run', os.path.join(REFERENCE, 'full_eval.py'),
+                        '--indir', os.path.join(REPO, 'tests', 'golden'), '--dataset', 'abc_minimal/testset.txt',
+                        '--modeldir', '/nonexistent', '--models', 'p2s_max', '--query_grid_resolution', '32', '--epsilon', '3'],
+                       cwd=REFERENCE, env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and ('ROCm GPU' in r.stderr or 'No such file' in r.stderr), r.stderr[-1500:]
+        assert 'trimesh' not in r.stderr and 'skimage' not in r.stderr
