@@ -55,7 +55,17 @@ def _report_lines(rows, keys):
     return lines
 
 
+def _rank0_only():
+    """under torchrun every rank executes the driver script; reports are written once, by rank 0 (the others wait)"""
+    from points2surf_amd import sharding
+    world, rank, _ = sharding.dist_env()
+    return world, rank
+
+
 def eval_predictions(pred_path, gt_path, report_file=None, unsigned=False):
+    world, rank = _rank0_only()
+    if rank != 0:
+        return
     files = [f for f in os.listdir(pred_path) if os.path.isfile(os.path.join(pred_path, f)) and f[-4:] == '.npy']
     results = []
     for f in files:
@@ -85,7 +95,21 @@ def eval_predictions(pred_path, gt_path, report_file=None, unsigned=False):
 
 def mesh_comparison(new_meshes_dir_abs, ref_meshes_dir_abs, num_processes, report_name, samples_per_model=10000,
                     dataset_file_abs=None):
-    from points2surf_amd import metrics
+    from points2surf_amd import metrics, sharding
+    world, rank = _rank0_only()
+    if rank != 0:
+        sharding.barrier()
+        return None
+    try:
+        return _mesh_comparison_rank0(metrics, new_meshes_dir_abs, ref_meshes_dir_abs, num_processes, report_name,
+                                      samples_per_model, dataset_file_abs)
+    finally:
+        if world > 1:
+            sharding.barrier()
+
+
+def _mesh_comparison_rank0(metrics, new_meshes_dir_abs, ref_meshes_dir_abs, num_processes, report_name, samples_per_model,
+                           dataset_file_abs):
     return metrics.mesh_comparison(new_meshes_dir_abs, ref_meshes_dir_abs, num_processes, report_name,
                                    samples_per_model=samples_per_model, dataset_file_abs=dataset_file_abs,
                                    seed=int(os.environ.get('P2S_METRIC_SEED', '0')))

@@ -134,20 +134,18 @@ def implicit_surface_to_mesh(query_dist_ms, query_pts_ms, volume_out_file, mc_ou
     col[norm > 0.0, 1] = norm[norm > 0.0] + 1.0 / 2.0
     _write_coff_points(volume_out_file, np.asarray(query_pts_ms), col)
 
-    vmin, vmax = float(volume.min().item()), float(volume.max().item())
-    if vmin < 0.0 and vmax > 0.0:
-        start = time.time()
-        v, f, _ = engine.marching_cubes(volume, model_space=True, fix_inversion=True)
-        torch.cuda.synchronize()
-        print('Marching Cubes took: {}'.format(time.time() - start))
-        if v.shape[0] == 0 and f.shape[0] == 0:
-            print('Warning: marching cubes gives no result!')
-        else:
-            if os.path.dirname(mc_out_file):
-                os.makedirs(os.path.dirname(mc_out_file), exist_ok=True)
-            ply.write_ply(mc_out_file, v.cpu().numpy(), f.cpu().numpy())
-    else:
+    # reference :211-229: mesh only if the volume holds both signs; an iso-surface without a 0-level set is empty, so
+    # the extraction itself answers that (no separate min / max pass over the volume)
+    start = time.time()
+    v, f, _ = engine.marching_cubes(volume, model_space=True, fix_inversion=True)
+    torch.cuda.synchronize()
+    print('Marching Cubes took: {}'.format(time.time() - start))
+    if v.shape[0] == 0 and f.shape[0] == 0:
         print('Warning: volume for marching cubes contains no 0-level set!')
+    else:
+        if os.path.dirname(mc_out_file):
+            os.makedirs(os.path.dirname(mc_out_file), exist_ok=True)
+        ply.write_ply(mc_out_file, v.cpu().numpy(), f.cpu().numpy())
 
 
 def implicit_surface_to_mesh_file(query_dist_ms_file, query_pts_ms_file, volume_out_file, mc_out_file, grid_res, sigma,
@@ -174,11 +172,17 @@ def implicit_surface_to_mesh_directory(imp_surf_dist_ms_dir, query_pts_ms_dir, v
     os.makedirs(mesh_out_dir, exist_ok=True)
     dist_files = sorted(f for f in os.listdir(imp_surf_dist_ms_dir)
                         if os.path.isfile(os.path.join(imp_surf_dist_ms_dir, f)) and f[-8:] == '.xyz.npy')
-    for f in dist_files:
+    # under torchrun every rank executes the driver script: the shapes are dealt round-robin (same sorted list on
+    # every rank), nobody writes a file another rank writes
+    from points2surf_amd import sharding
+    world, rank, _ = sharding.dist_env()
+    for f in dist_files[rank::world] if world > 1 else dist_files:
         f_dist, f_query = os.path.join(imp_surf_dist_ms_dir, f), os.path.join(query_pts_ms_dir, f)
         f_vol, f_mesh = os.path.join(vol_out_dir, f[:-8] + '.off'), os.path.join(mesh_out_dir, f[:-8] + '.ply')
         if _call_necessary([f_dist, f_query], [f_vol, f_mesh]):
             implicit_surface_to_mesh_file(f_dist, f_query, f_vol, f_mesh, grid_res, sigma, certainty_threshold)
+    if world > 1:
+        sharding.barrier()               # the metrics stage that follows reads every rank's meshes
 
 
 if _ref is not None:
