@@ -15,7 +15,7 @@
 // Kernels (one thread per grid point, z fastest = coalesced):
 //   mc_classify   per point: which of its three owned edges (+x, +y, +z) cross the level -> vertex count; per cell: the
 //                 configuration index -> triangle count; per-block totals
-//   mc_scan       exclusive scan of the block totals (one workgroup)
+//   mc_scan       exclusive scan of the block totals (two levels: 1024-block chunks in parallel, then the chunk totals)
 //   mc_emit       ordered emission: vertices (linear interpolation in float64, optional model-space transform), the
 //                 per-point vertex base index, then the faces (edge -> owning point -> vertex index)
 //   mc_volume     signed volume (divergence theorem) for the inversion fix; mc_flip swaps two indices per face
@@ -278,15 +278,48 @@ __global__ __launch_bounds__(256) void mc_classify_kernel(const float *__restric
         blk[blockIdx.x] = make_int2(red[0].x + red[1].x + red[2].x + red[3].x, red[0].y + red[1].y + red[2].y + red[3].y);
 }
 
-// exclusive scan of the block totals (one workgroup, chunks of 1024); totals[0] = vertices, totals[1] = faces
-__global__ __launch_bounds__(1024) void mc_scan_kernel(const int2 *__restrict__ blk, long long nblk, longlong2 *__restrict__ off,
-                                                       long long *__restrict__ totals) {
+// exclusive scan of the block totals, two levels: every workgroup scans one chunk of 1024 block totals (local offsets +
+// the chunk total), one workgroup then scans the chunk totals (<= 512 at 512^3) and adds the chunk bases in place;
+// totals[0] = vertices, totals[1] = faces
+__global__ __launch_bounds__(1024) void mc_scan_local_kernel(const int2 *__restrict__ blk, long long nblk, longlong2 *__restrict__ off,
+                                                             longlong2 *__restrict__ chunk_tot) {
+    __shared__ long long wsx[16], wsy[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long b = (long long)blockIdx.x * 1024 + tid;
+    const int2 c = b < nblk ? blk[b] : make_int2(0, 0);
+    long long vx = c.x, vy = c.y;
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long ux = __shfl_up(vx, d), uy = __shfl_up(vy, d);
+        if (lane >= d) {
+            vx += ux;
+            vy += uy;
+        }
+    }
+    if (lane == 63) {
+        wsx[wave] = vx;
+        wsy[wave] = vy;
+    }
+    __syncthreads();
+    long long bx = 0, by = 0, tx = 0, ty = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) {
+            bx += wsx[w];
+            by += wsy[w];
+        }
+        tx += wsx[w];
+        ty += wsy[w];
+    }
+    if (b < nblk) off[b] = make_longlong2(bx + vx - c.x, by + vy - c.y);
+    if (tid == 0) chunk_tot[blockIdx.x] = make_longlong2(tx, ty);
+}
+
+__global__ __launch_bounds__(1024) void mc_scan_chunks_kernel(longlong2 *__restrict__ chunk_tot, int nchunk, long long *__restrict__ totals) {
     __shared__ long long wsx[16], wsy[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     long long cx = 0, cy = 0;
-    for (long long b0 = 0; b0 < nblk; b0 += 1024) {
-        const long long b = b0 + tid;
-        const int2 c = b < nblk ? blk[b] : make_int2(0, 0);
+    for (int b0 = 0; b0 < nchunk; b0 += 1024) {
+        const int b = b0 + tid;
+        const longlong2 c = b < nchunk ? chunk_tot[b] : make_longlong2(0, 0);
         long long vx = c.x, vy = c.y;
         for (int d = 1; d < 64; d <<= 1) {
             const long long ux = __shfl_up(vx, d), uy = __shfl_up(vy, d);
@@ -309,7 +342,7 @@ __global__ __launch_bounds__(1024) void mc_scan_kernel(const int2 *__restrict__ 
             tx += wsx[w];
             ty += wsy[w];
         }
-        if (b < nblk) off[b] = make_longlong2(bx + vx - c.x, by + vy - c.y);
+        if (b < nchunk) chunk_tot[b] = make_longlong2(bx + vx - c.x, by + vy - c.y);     // exclusive base of the chunk
         cx += tx;
         cy += ty;
         __syncthreads();
@@ -365,6 +398,7 @@ __device__ __forceinline__ void mc_edge_point(const float *__restrict__ vol, int
 __global__ __launch_bounds__(256) void mc_vertices_kernel(const float *__restrict__ vol, int res, const McEntry *__restrict__ table,
                                                           const unsigned char *__restrict__ vmask,
                                                           const unsigned char *__restrict__ tcount, const longlong2 *__restrict__ off,
+                                                          const longlong2 *__restrict__ chunk_base,
                                                           int *__restrict__ vbase, long long *__restrict__ tbase,
                                                           float *__restrict__ verts, long long cap_v, int model_space) {
     const long long nvox = (long long)res * res * res;
@@ -373,10 +407,10 @@ __global__ __launch_bounds__(256) void mc_vertices_kernel(const float *__restric
     int pv, pt;
     mc_block_prefix(__popc(m), nt, pv, pt);
     if (i >= nvox) return;
-    const longlong2 o = off[blockIdx.x];
-    const long long v0 = o.x + pv;
+    const longlong2 o = off[blockIdx.x], cb = chunk_base[blockIdx.x >> 10];
+    const long long v0 = cb.x + o.x + pv;
     vbase[i] = (int)v0;
-    tbase[i] = o.y + pt;
+    tbase[i] = cb.y + o.y + pt;
     if (!m) return;
     const int z = (int)(i % res);
     const long long t = i / res;
@@ -520,7 +554,8 @@ extern "C" int p2s_marching_cubes(const float *vol_dev, int grid_res, float *ver
     const long long nvox = (long long)grid_res * grid_res * grid_res;
     const long long nblk = (nvox + 255) / 256;
     // scratch: vmask (1) + tcount (1) + vbase (4) + tbase (8) per point; block totals + offsets; results
-    const size_t bytes = (size_t)nvox * 14 + (size_t)nblk * (8 + 16) + 64 * 8 + 256;
+    const long long nchunk = (nblk + 1023) / 1024;
+    const size_t bytes = (size_t)nvox * 14 + (size_t)nblk * (8 + 16) + (size_t)nchunk * 16 + 64 * 8 + 256;
     char *scratch = (char *)p2s_scratch(device, bytes);
     if (!scratch) {
         p2s_set_error("p2s_marching_cubes: hipMalloc(%zu bytes) failed", bytes);
@@ -533,14 +568,16 @@ extern "C" int p2s_marching_cubes(const float *vol_dev, int grid_res, float *ver
     long long *tbase = (long long *)scratch;
     int *vbase = (int *)(tbase + nvox);
     longlong2 *off = (longlong2 *)(vbase + nvox + (nvox & 1));
-    int2 *blk = (int2 *)(off + nblk);
+    longlong2 *chunk_tot = off + nblk;
+    int2 *blk = (int2 *)(chunk_tot + nchunk);
     double *acc = (double *)(blk + nblk);              // [64] volume shards, then [2] totals as long long
     long long *totals = (long long *)(acc + 64);
     unsigned char *vmask = (unsigned char *)(totals + 2);
     unsigned char *tcount = vmask + nvox;
     if (hipMemsetAsync(acc, 0, 66 * 8, s) != hipSuccess) return cleanup(P2S_EHIP);
     hipLaunchKernelGGL(mc_classify_kernel, dim3((unsigned)nblk), dim3(256), 0, s, vol_dev, grid_res, table, vmask, tcount, blk);
-    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, blk, nblk, off, totals);
+    hipLaunchKernelGGL(mc_scan_local_kernel, dim3((unsigned)nchunk), dim3(1024), 0, s, blk, nblk, off, chunk_tot);
+    hipLaunchKernelGGL(mc_scan_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_tot, (int)nchunk, totals);
     long long host_tot[2] = {0, 0};
     if (hipMemcpyAsync(host_tot, totals, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
         p2s_set_error("p2s_marching_cubes: %s", hipGetErrorString(hipGetLastError()));
@@ -559,7 +596,7 @@ extern "C" int p2s_marching_cubes(const float *vol_dev, int grid_res, float *ver
                       (long long)cap_faces, host_tot[0], host_tot[1]);
         return cleanup(P2S_ECAPACITY);
     }
-    hipLaunchKernelGGL(mc_vertices_kernel, dim3((unsigned)nblk), dim3(256), 0, s, vol_dev, grid_res, table, vmask, tcount, off, vbase, tbase,
+    hipLaunchKernelGGL(mc_vertices_kernel, dim3((unsigned)nblk), dim3(256), 0, s, vol_dev, grid_res, table, vmask, tcount, off, chunk_tot, vbase, tbase,
                        verts_out_dev, (long long)cap_verts, model_space);
     hipLaunchKernelGGL(mc_faces_kernel, dim3((unsigned)nblk), dim3(256), 0, s, vol_dev, grid_res, table, vmask, tcount, vbase, tbase,
                        faces_out_dev, (long long)cap_faces);

@@ -396,14 +396,20 @@ def marching_cubes(vol, model_space=True, fix_inversion=True):
     if vol.shape != (res, res, res):
         raise ValueError('bad volume shape %s' % (tuple(vol.shape),))
     nv, nf, inv = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+    # one call with room for a rough surface (16 res^2 vertices, 32 res^2 faces; a smooth one has ~0.6 / 1.2 res^2);
+    # the exact sizes come back either way, a second call only if that was not enough
+    cap_v, cap_f = 16 * res * res, 32 * res * res
     with torch.cuda.device(dev):
-        _lib.check(lib.p2s_marching_cubes(_ptr(vol), res, None, 0, None, 0, ctypes.byref(nv), ctypes.byref(nf),
-                                          int(bool(model_space)), int(bool(fix_inversion)), ctypes.byref(inv), dev.index,
-                                          _stream_ptr(dev)), allow=(_lib.P2S_ECAPACITY,))
-        verts = torch.empty((max(nv.value, 1), 3), dtype=torch.float32, device=dev)
-        faces = torch.empty((max(nf.value, 1), 3), dtype=torch.int32, device=dev)
-        if nv.value or nf.value:
-            _lib.check(lib.p2s_marching_cubes(_ptr(vol), res, _ptr(verts), nv.value, _ptr(faces), nf.value,
-                                              ctypes.byref(nv), ctypes.byref(nf), int(bool(model_space)),
-                                              int(bool(fix_inversion)), ctypes.byref(inv), dev.index, _stream_ptr(dev)))
+        for _ in range(2):
+            verts = torch.empty((cap_v, 3), dtype=torch.float32, device=dev)
+            faces = torch.empty((cap_f, 3), dtype=torch.int32, device=dev)
+            rc = lib.p2s_marching_cubes(_ptr(vol), res, _ptr(verts), cap_v, _ptr(faces), cap_f, ctypes.byref(nv),
+                                        ctypes.byref(nf), int(bool(model_space)), int(bool(fix_inversion)), ctypes.byref(inv),
+                                        dev.index, _stream_ptr(dev))
+            if rc != _lib.P2S_ECAPACITY:
+                _lib.check(rc)
+                break
+            cap_v, cap_f = max(int(nv.value), 1), max(int(nf.value), 1)
+        else:
+            _lib.check(rc)
     return verts[:nv.value], faces[:nf.value], bool(inv.value)
