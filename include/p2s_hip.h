@@ -52,8 +52,10 @@ typedef struct {
     int32_t points_per_patch;    /* 300  (train --points_per_patch)                            */
     int32_t sub_sample_size;     /* 1000 (train --sub_sample_size)                             */
     int32_t output_dim;          /* 2: [|d| logit, sign logit]                                 */
-    int32_t use_point_stn;       /* QSTN present (p2s_vanilla)                                 */
-    int32_t shared_transformer;  /* one QSTN over cat(patch, sub-sample) (p2s_vanilla)         */
+    int32_t use_point_stn;       /* QSTN present (p2s_vanilla and most ablation models)        */
+    int32_t shared_transformer;  /* 1: one QSTN over cat(patch, sub-sample) (p2s_vanilla);
+                                    0: the QSTN of feat_global, over the sub-sample only; its
+                                       rotation also turns the patch (p2s_uniform, *_kNN ...)  */
     int32_t weighted_subsample;  /* 0: ids = randint (train --uniform_subsample 1, p2s_max);
                                     1: distance-weighted choice without replacement (p2s_vanilla) */
     int32_t encoder_bf16;        /* 0 (default): exact fp32.  1: per-point encoder layers on bf16 MFMA (fp32 accumulate; first
@@ -94,7 +96,8 @@ typedef struct {
 
 typedef struct {
     p2s_encoder_offsets enc[2];
-    p2s_qstn_offsets    qstn;    /* valid iff cfg.use_point_stn                                */
+    p2s_qstn_offsets    qstn;    /* valid iff cfg.use_point_stn: point_stn.* (shared) or
+                                    feat_global.stn1.* (not shared)                            */
     uint64_t d1l, db1l;          /* fc1_local+bn1_local   packed 1024x512                      */
     uint64_t d1g, db1g;          /* fc1_global+bn1_global packed 1024x512                      */
     uint64_t d2, db2;            /* fc2+bn2 packed 1024x256                                    */

@@ -83,6 +83,12 @@ class TorchPort:
             r = self._qstn(torch.cat((patch, shape), dim=2), 'point_stn')
             shape = torch.bmm(r, shape)
             patch = torch.bmm(r, patch)
+        elif self.cfg.get('use_point_stn'):
+            # the QSTN of feat_global sees the sub-sample only; the patch is turned like it
+            # (reference source/points_to_surf_model.py:177-185, :337-339)
+            r = self._qstn(shape, 'feat_global.stn1')
+            shape = torch.bmm(r, shape)
+            patch = torch.bmm(r, patch)
         g = self._fc_bn(self._feat(shape.contiguous(), 'feat_global'), 'fc1_global', 'bn1_global')
         l = self._fc_bn(self._feat(patch.contiguous(), 'feat_local'), 'fc1_local', 'bn1_local')
         f = torch.cat((l, g), dim=1)

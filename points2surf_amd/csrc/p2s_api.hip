@@ -58,10 +58,6 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
         p2s_set_error("p2s_model_create: unsupported cfg (net_size=%d output_dim=%d)", cfg->net_size, cfg->output_dim);
         return P2S_EINVAL;
     }
-    if (cfg->use_point_stn && !cfg->shared_transformer) {
-        p2s_set_error("p2s_model_create: per-branch QSTN (use_point_stn without shared_transformer) unsupported");
-        return P2S_EINVAL;
-    }
     if (p2s_device_count() <= device || device < 0) {
         p2s_set_error("p2s_model_create: no HIP device %d", device);
         return P2S_ENODEVICE;
@@ -240,7 +236,9 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
 
     const float *rot = nullptr;
     if (m->cfg.use_point_stn) {
-        // shared QSTN over cat(patch, sub-sample - q): reference points_to_surf_model.py:325-331, :100-131
+        // shared QSTN over cat(patch, sub-sample - q): reference points_to_surf_model.py:325-331, :100-131; without
+        // shared_transformer the QSTN belongs to feat_global and sees the sub-sample alone (:283-284, :177-185), its
+        // rotation is applied to the sub-sample and to the patch (:337-339) -- the same kernels, other points
         ChainArgs a;
         memset(&a, 0, sizeof(a));
         a.ns = m->cfg.encoder_bf16;
@@ -248,11 +246,17 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         a.w1_piece_stride = (long long)2 * C * 4096;
         ChainBranch &b = a.br[0];
         b.ptsA = patch; b.ptsB = sub; b.center = query; b.rot = nullptr;
+        const bool qstn_shared = m->cfg.shared_transformer != 0;
         b.w0a = W + o.qstn.c1; b.b0a = W + o.qstn.cb1;
         b.w0b = b.b0b = nullptr; b.w1 = W; b.b1 = nullptr; b.w1_item_stride = 0;
         b.w2 = W + o.qstn.c2; b.b2 = W + o.qstn.cb2;
         b.w3 = W + o.qstn.c3; b.b3 = W + o.qstn.cb3;
         b.out = w.qg; b.P = PL + PG; b.P1 = PL; b.n_items = C; b.relu_out = 1; b.short_chain = 1;
+        if (!qstn_shared) {
+            b.ptsA = nullptr;
+            b.P = PG;
+            b.P1 = 0;
+        }
         if (bf16) {
             b.w2 = reinterpret_cast<const float *>(m->blob_h + m->h_qc2);
             b.w3 = reinterpret_cast<const float *>(m->blob_h + m->h_qc3);

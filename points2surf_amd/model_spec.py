@@ -19,6 +19,13 @@ MODEL_DEFAULTS = dict(
 NAMED_MODELS = {
     'p2s_max': dict(use_point_stn=False, shared_transformation=False, uniform_subsample=True),
     'p2s_vanilla': dict(use_point_stn=True, shared_transformation=True, uniform_subsample=False),
+    # ablation models of the paper (experiments/train_p2s_{uniform,no_qstn,small_kNN,large_kNN}.sh): the QSTN lives in
+    # feat_global (sees the sub-sample only), its rotation is applied to the sub-sample and to the patch
+    # (source/points_to_surf_model.py:283-284, :337-339)
+    'p2s_uniform': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=True),
+    'p2s_no_qstn': dict(use_point_stn=False, shared_transformation=False, uniform_subsample=False),
+    'p2s_small_kNN': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, points_per_patch=75),
+    'p2s_large_kNN': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, points_per_patch=1200),
 }
 
 

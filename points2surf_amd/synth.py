@@ -15,7 +15,9 @@ import numpy as np
 from .model_spec import state_shapes, NAMED_MODELS
 
 
-_FC4_BIAS_SHIFT = {'p2s_max': (6.289174, 2.416443), 'p2s_vanilla': (2.6854432, 4.523528)}
+_FC4_BIAS_SHIFT = {'p2s_max': (6.289174, 2.416443), 'p2s_vanilla': (2.6854432, 4.523528),
+                   'p2s_uniform': (4.6575, 2.458), 'p2s_no_qstn': (2.3863, 1.8502), 'p2s_small_kNN': (4.2235, 2.2435),
+                   'p2s_large_kNN': (4.9557, 2.6857)}
 
 
 def make_weights(model='p2s_max', seed=1234, net_size_max=1024, output_dim=2):
@@ -67,7 +69,8 @@ def make_weights(model='p2s_max', seed=1234, net_size_max=1024, output_dim=2):
         shared_transformer=bool(cfg.get('shared_transformation', False)),
         use_feat_stn=True, single_transformer=False,
         uniform_subsample=bool(cfg.get('uniform_subsample', False)), fixed_subsample=False,
-        net_size=net_size_max, points_per_patch=300, sub_sample_size=1000, output_dim=output_dim)
+        net_size=net_size_max, points_per_patch=int(cfg.get('points_per_patch', 300)), sub_sample_size=1000,
+        output_dim=output_dim)
     return w, cfg_out
 
 

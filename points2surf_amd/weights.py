@@ -133,8 +133,6 @@ def build_blob(state_dict, cfg):
         raise ValueError('use_feat_stn=0 ablation is not on the accelerated path')
     if bool(cfg.get('single_transformer', False)):
         raise ValueError('single_transformer ablation is not on the accelerated path')
-    if use_point_stn and not shared:
-        raise ValueError('per-branch QSTN ablation is not on the accelerated path')
     if cfg.get('sym_op', 'max') != 'max':
         raise ValueError("Unsupported symmetric operation: %s" % cfg.get('sym_op'))
 
@@ -156,7 +154,9 @@ def build_blob(state_dict, cfg):
         o.m3, o.mb3 = _add_gemm(blob, w, pre + '.conv3', pre + '.bn3')
     if use_point_stn:
         q = offs.qstn
-        s = 'point_stn'
+        # shared: one QSTN over cat(patch, sub-sample) (model.point_stn); otherwise the QSTN of feat_global, which
+        # sees the sub-sample only (reference source/points_to_surf_model.py:267-269, :283-284)
+        s = 'point_stn' if shared else 'feat_global.stn1'
         q.c1, q.cb1 = _add_plain(blob, w, s + '.conv1', s + '.bn1')
         q.c2, q.cb2 = _add_gemm(blob, w, s + '.conv2', s + '.bn2')
         q.c3, q.cb3 = _add_gemm(blob, w, s + '.conv3', s + '.bn3')

@@ -168,3 +168,28 @@ def test_small_cloud_shuffle_and_pad_matches_reference(model):
     mt, pos = r2.get_state()
     st = rs.get_state()
     assert np.array_equal(mt, st[1]) and pos == st[2]
+
+
+@pytest.mark.parametrize('model', ['p2s_uniform', 'p2s_no_qstn', 'p2s_small_kNN', 'p2s_large_kNN'])
+def test_ablation_models_match_reference(model):
+    """the paper's ablation models whose branches the engine implements (reference experiments/train_p2s_*.sh): QSTN
+    inside feat_global (sees the sub-sample only; its rotation also turns the patch -- source/points_to_surf_model.py
+    :283-284, :337-339), no QSTN with the weighted sub-sample, 75- and 1200-point patches.  Whole grid-32 shape against
+    the unmodified reference."""
+    import torch
+    from points2surf_amd import engine, synth
+    key = 'ref_rec_%s_testset_grid32' % model
+    if not os.path.isfile(os.path.join(GOLDEN, key + '.npz')):
+        pytest.skip(key + ' not generated')
+    g = np.load(os.path.join(GOLDEN, key + '.npz'))
+    w, cfg = synth.make_weights(model)
+    m = engine.Model(w, cfg)
+    assert m.points_per_patch == cfg['points_per_patch']
+    cloud = engine.Cloud(np.load(os.path.join(FIX, '04_pts', _names('testset')[0] + '.xyz.npy')))
+    sdf, _ = engine.infer_shape(m, cloud, engine.Rng(SEED), 32, 3, chunk=1000)
+    torch.cuda.synchronize()
+    sdf = sdf.cpu().numpy()
+    d = np.abs(sdf - g['rec_0'])
+    flips = int((np.sign(sdf) != np.sign(g['rec_0'])).sum())
+    print('%s: max|dSDF| %.3g, flips %d / %d, positive fraction %.2f' % (model, d.max(), flips, sdf.size, (sdf > 0).mean()))
+    assert d.max() < 1e-4 and flips == 0 and 0.02 < (sdf > 0).mean() < 0.98

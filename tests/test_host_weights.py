@@ -86,12 +86,27 @@ def test_engine_algebra_matches_oracle(model, fixture_cloud):
 
 def test_unsupported_configs_raise():
     w, cfg = synth.make_weights('p2s_max')
-    for bad in (dict(single_transformer=True), dict(use_feat_stn=False), dict(sym_op='sum'),
-                dict(use_point_stn=True, shared_transformer=False), dict(net_size=512)):
+    for bad in (dict(single_transformer=True), dict(use_feat_stn=False), dict(sym_op='sum'), dict(net_size=512)):
         c = dict(cfg)
         c.update(bad)
         with pytest.raises(ValueError):
             weights.build_blob(w, c)
+
+
+def test_qstn_weights_come_from_the_right_module():
+    """shared transformer: model.point_stn; otherwise the QSTN of feat_global (reference points_to_surf_model.py
+    :267-269, :283-284) -- the ablation models p2s_uniform / p2s_*_kNN; patch sizes other than 300 reach the cfg"""
+    for name, key in (('p2s_vanilla', 'point_stn.fc3.bias'), ('p2s_uniform', 'feat_global.stn1.fc3.bias')):
+        w, cfg = synth.make_weights(name)
+        assert key in w and ('point_stn.fc3.bias' in w) == (name == 'p2s_vanilla')
+        blob, offs, mc = weights.build_blob(w, cfg)
+        assert mc.use_point_stn == 1 and mc.shared_transformer == int(name == 'p2s_vanilla')
+        b3 = blob[offs.qstn.fb3:offs.qstn.fb3 + 4]
+        assert np.allclose(b3, np.asarray(w[key], dtype=np.float32) + np.array([1, 0, 0, 0], np.float32))
+    for name, k in (('p2s_small_kNN', 75), ('p2s_large_kNN', 1200), ('p2s_no_qstn', 300)):
+        w, cfg = synth.make_weights(name)
+        _, _, mc = weights.build_blob(w, cfg)
+        assert mc.points_per_patch == k and mc.weighted_subsample == 1
 
 
 def test_model_cfg_carries_the_sub_sample_mode():
