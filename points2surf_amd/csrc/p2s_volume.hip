@@ -223,82 +223,139 @@ __global__ void vol_state_init_kernel(const float *__restrict__ vol, long long n
     }
 }
 
-// sweep k: buf[k & 1] -> buf[(k + 1) & 1]
-__global__ __launch_bounds__(256) void vol_sweep_kernel(unsigned char *__restrict__ buf0, unsigned char *__restrict__ buf1,
-                                                        int res, int k, unsigned taps, float thr,
-                                                        VolState *__restrict__ vs, unsigned char *__restrict__ act,
-                                                        int *__restrict__ tcnt) {
+// geometry of one tile (workgroup-uniform)
+struct VolTile {
+    int tile, tx_i, ty_i, tz_i, x0, y0, z0;
+};
+__device__ __forceinline__ VolTile vol_tile(int tile, int tz_n, int ty_n) {
+    VolTile t;
+    t.tile = tile;
+    t.tz_i = tile % tz_n;
+    t.ty_i = (tile / tz_n) % ty_n;
+    t.tx_i = tile / (tz_n * ty_n);
+    t.z0 = t.tz_i * VT_Z;
+    t.y0 = t.ty_i * VT_Y;
+    t.x0 = t.tx_i * VT_X;
+    return t;
+}
+// staging map: thread = (row r0 of HALF a halo'd x plane, z dword d = tid % 18), 180 of the 256 threads; iteration
+// `it` moves half h = it & 1 of plane ax = it >> 1.  The x term of the address is workgroup-uniform (scalar offset of
+// the buffer load), the y / z term takes two registers per thread, the LDS address is base + a compile-time constant,
+// the face replication is fixed per thread: ONE vector instruction per element on the global side, three on the LDS
+// side.  (The map idx = tid + 256 it cost 27: two constant divisions per element, twice -- a quarter of the kernel.)
+static_assert(VA_Y % 2 == 0, "half planes");
+constexpr int VS_ROWS = VA_Y / 2, VS_THREADS = VS_ROWS * VA_ZD, VS_PER = 2 * VA_X;
+static_assert(VS_THREADS <= 256, "staging map");
+
+// the halo'd tile (raw state bytes) into registers; x, y clamped, z clamped to the first / last dword of the row (the
+// face bytes are replicated when the registers go to LDS).  All loads of a thread are issued back to back, through a
+// buffer descriptor (32-bit offsets: 64-bit pointers for the loads in flight would cost two VGPRs each).
+__device__ __forceinline__ void vol_tile_load(unsigned (&w)[VS_PER], __amdgpu_buffer_rsrc_t rsrc, const VolTile &t, int res, int tid) {
+    const int r0 = tid / VA_ZD, d = tid - r0 * VA_ZD;
+    const int z = t.z0 - 4 + 4 * d;
+    const int zb = z < 0 ? 0 : (z >= res ? res - 4 : z);
+    int voff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) voff[h] = min(max(t.y0 - VT_H + r0 + h * VS_ROWS, 0), res - 1) * res + zb;
+    if (tid < VS_THREADS) {
+#pragma unroll
+        for (int it = 0; it < VS_PER; ++it) {
+            const int x = min(max(t.x0 - VT_H + (it >> 1), 0), res - 1);
+            w[it] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[it & 1], x * res * res, 0);
+        }
+    }
+}
+__device__ __forceinline__ void vol_tile_stage(const unsigned (&w)[VS_PER], unsigned *__restrict__ A, const VolTile &t, int res, int tid) {
+    const int r0 = tid / VA_ZD, d = tid - r0 * VA_ZD;
+    const int z = t.z0 - 4 + 4 * d;
+    const unsigned sel = z < 0 ? 0x00000000u : (z >= res ? 0x03030303u : 0x03020100u);   // v_perm: replicate byte 0 / byte 3 / identity
+    unsigned *a = A + r0 * VA_ZS + d;
+    if (tid < VS_THREADS) {
+#pragma unroll
+        for (int it = 0; it < VS_PER; ++it)
+            a[((it >> 1) * VA_Y + (it & 1) * VS_ROWS) * VA_ZS] = __builtin_amdgcn_perm(w[it], w[it], sel);
+    }
+}
+
+// per-byte compare constants for v_lerp_u8: byte of lerp(x, K, R) = (x + K + R) >> 1, its bit 7 is  x >= c  for the
+// biased sums x <= 250:  c = 0 -> always (K = 255, R = 1) ; 1 <= c <= 255 -> K = 255 - c, R = 1 ; c >= 256 -> never (K = R = 0)
+__device__ __forceinline__ void lerp_ge_consts(int c, unsigned &K, unsigned &R) {
+    const int kk = c <= 0 ? 255 : (c >= 256 ? 0 : 255 - c);
+    K = (unsigned)kk * 0x01010101u;
+    R = c >= 256 ? 0u : 0x01010101u;
+}
+
+// sweep k: buf[k & 1] -> buf[(k + 1) & 1]; taps = the offsets [T_LO, T_HI] of scipy's convolve (compile time: the five
+// sigmas are five kernels; with run-time taps every window step cost ten selects).  PERSISTENT workgroups: <= 4 per
+// CU (LDS), each walks the active tiles of its share; the staging loads of the NEXT tile are in flight while the
+// current one is summed (their registers are free as soon as the tile sits in LDS), and the dispatcher starts <= 1024
+// workgroups per sweep instead of one per tile.  The kernel is VALU-bound (~600 instructions per wave and tile).
+template <int T_LO, int T_HI>
+__global__ __launch_bounds__(256, 4) void vol_sweep_kernel(unsigned char *__restrict__ buf0, unsigned char *__restrict__ buf1,
+                                                           int res, int k, float thr,
+                                                           VolState *__restrict__ vs, unsigned char *__restrict__ act,
+                                                           int *__restrict__ tcnt) {
+    static_assert(T_LO >= -2 && T_HI <= 2 && T_LO <= T_HI, "taps");
+    constexpr int NT = T_HI - T_LO + 1;
     __shared__ unsigned A[VA_X * VA_Y * VA_ZS];
     __shared__ unsigned B[VA_X * VA_Y * VB_ZS];
     unsigned *C = A;      // the zy sums overlay the staged tile (its interior bytes are kept in registers): 34.6 KB, 4 workgroups / CU
     static_assert(VA_X * VT_Y * VB_ZS <= VA_X * VA_Y * VA_ZS, "C must fit into A");
     __shared__ int red[2][4];
     __shared__ unsigned long long s_dec[3];
-    __shared__ int s_changed;
+    __shared__ int s_changed[2];
+    __shared__ int s_list[256], s_n, s_done;
     const int tid = threadIdx.x;
-    // XCD-aware tile order: workgroup i runs on XCD i % 8 (own L2).  Giving every XCD one contiguous slab of tiles
-    // keeps the halo re-reads and the two 64-byte halves of every 128-byte line (adjacent z tiles) in ONE L2; the
-    // naive order fetched each line from HBM into two L2s.
-    const int wg = blockIdx.x;
+    // XCD-aware tile order: workgroup i runs on XCD i % 8 (own L2).  Every XCD owns one contiguous slab of tiles: the
+    // halo re-reads and the two 64-byte halves of every 128-byte line (adjacent z tiles) stay in ONE L2.  Inside the
+    // slab the workgroups of an XCD interleave (tile = first + m * workgroups): the front is spatially coherent, its
+    // tiles spread over all of them.
+    const int wg = blockIdx.x, xcd = wg & 7, wl = wg >> 3, wgs = gridDim.x >> 3;
     const int tz_n = (res + VT_Z - 1) / VT_Z, ty_n = (res + VT_Y - 1) / VT_Y, tx_n = (res + VT_X - 1) / VT_X;
     const int n_tiles = tz_n * ty_n * tx_n, slab = (n_tiles + 7) >> 3;
-    const int tile = (wg & 7) * slab + (wg >> 3);
-    const bool has_tile = tile < n_tiles && (wg >> 3) < slab;
-    const int tile_c = has_tile ? tile : 0;
-    const int tz_i = tile_c % tz_n, ty_i = (tile_c / tz_n) % ty_n, tx_i = tile_c / (tz_n * ty_n);
+    const int slab_end = min((xcd + 1) * slab, n_tiles);
+    const int first = xcd * slab + wl;
     const unsigned char *__restrict__ in = (k & 1) ? buf1 : buf0;
     unsigned char *__restrict__ out = (k & 1) ? buf0 : buf1;
-    const int z0 = tz_i * VT_Z, y0 = ty_i * VT_Y, x0 = tx_i * VT_X;
-    const int rowd = res >> 2;                                      // dwords per z row
-    // ---- active tiles only.  A tile whose state bytes did not change in a sweep, and whose 26 neighbours did not
-    //      either, would reproduce its previous output: it is skipped, its two buffers already agree and its zero
-    //      counts stay in the running totals.  After the first sweeps only the tiles along the advancing front
-    //      remain (the flags: sweep k reads act[k % 3], sets act[(k + 1) % 3], clears act[(k + 2) % 3]).
-    const bool active = has_tile && act[(k % 3) * n_tiles + tile] != 0;
-    if (has_tile && tid == 0) act[((k + 2) % 3) * n_tiles + tile] = 0;
-    if (tid == 0) s_changed = 0;
-    if (!active && wg != 0) return;
-    // ---- stage the halo'd tile (raw state bytes); x, y clamped, z replicated at the volume faces.  All loads of a
-    //      thread are issued before anything waits: a rolled loop would pay the memory latency 17 times, and the loop
-    //      control below (dependent loads of the counters) would add its own round trip in front of them.  If the
-    //      run turns out to be over the loads were for nothing (both buffers stay valid memory).
-    constexpr int TOT = VA_X * VA_Y * VA_ZD, PER = (TOT + 255) / 256;
-    unsigned w[PER];
-#pragma unroll
-    for (int it = 0; it < PER; ++it) {
-        const int idx = tid + 256 * it;
-        const int row = idx / VA_ZD, d = idx - row * VA_ZD;
-        const int ax = row / VA_Y, ay = row - ax * VA_Y;
-        const int x = min(max(x0 - VT_H + ax, 0), res - 1), y = min(max(y0 - VT_H + ay, 0), res - 1);
-        const int z = z0 - 4 + 4 * d;
-        const unsigned *rowp = (const unsigned *)(in + ((long long)x * res + y) * res);
-        const int zi = z < 0 ? 0 : (z >= res ? rowd - 1 : z >> 2);
-        w[it] = (active && idx < TOT) ? rowp[zi] : 0u;
-    }
-    // ---- the reference's loop control (source/sdf.py:156-176) as a function of the finished sweeps' counters
-    const int done = vs->done;
-    if (tid < 64) {                        // wave 0 sums the shards
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(in), 0, res * res * res, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, res * res * res, 0x00020000);
+    // ---- speculative: the loads of this workgroup's first tile go out before its "active" flag is known (otherwise
+    //      flag -> loads -> sums is three dependent round trips).  If the run is over or the tile is idle they were for
+    //      nothing (both buffers stay valid memory).
+    unsigned w[VS_PER];
+    VolTile cur = vol_tile(first < slab_end ? first : 0, tz_n, ty_n);
+    vol_tile_load(w, rsrc, cur, res, tid);
+    // ---- wave 0: the reference's loop control (source/sdf.py:156-176) from the finished sweeps' counters, and the list
+    //      of this workgroup's ACTIVE tiles.  A tile whose state bytes did not change in a sweep, and whose 26
+    //      neighbours did not either, would reproduce its previous output: it is skipped, its two buffers already agree
+    //      and its zero counts stay in the running totals.  After the first sweeps only the tiles along the advancing
+    //      front remain (sweep k reads act[k % 3], sets act[(k + 1) % 3], clears act[(k + 2) % 3]).
+    if (tid < 64) {
+        const int done = vs->done;
         const unsigned long long before = (k <= 1) ? wave_sum64(vs->unknown0, tid) : wave_sum64(vs->cnt[(k - 2) & 3][0], tid);
         const unsigned long long zn = k >= 1 ? wave_sum64(vs->cnt[(k - 1) & 3][1], tid) : 0ull;
         const unsigned long long zx = k >= 1 ? wave_sum64(vs->cnt[(k - 1) & 3][0], tid) : 0ull;
+        int n = 0;
+        for (int m0 = 0; first + m0 * wgs < slab_end; m0 += 64) {
+            const int tile = first + (m0 + tid) * wgs;
+            const bool mine = tile < slab_end;
+            const bool on = mine && act[(k % 3) * n_tiles + tile] != 0;
+            if (mine) act[((k + 2) % 3) * n_tiles + tile] = 0;
+            const unsigned long long mask = __ballot(on);
+            if (on) s_list[n + __popcll(mask & ((1ull << tid) - 1ull))] = tile;
+            n += __popcll(mask);
+        }
         if (tid == 0) {
             s_dec[0] = before;
             s_dec[1] = zn;
             s_dec[2] = zx;
+            s_n = n;
+            s_done = done;
+            s_changed[0] = s_changed[1] = 0;
         }
     }
-#pragma unroll
-    for (int it = 0; it < PER; ++it) {
-        const int idx = tid + 256 * it;
-        const int row = idx / VA_ZD, d = idx - row * VA_ZD;
-        const int z = z0 - 4 + 4 * d;
-        unsigned v = w[it];
-        if (z < 0) v = (v & 0xffu) * 0x01010101u;
-        else if (z >= res) v = (v >> 24) * 0x01010101u;
-        if (idx < TOT) A[row * VA_ZS + d] = v;
-    }
     __syncthreads();
-    if (done) return;
+    if (s_done) return;
     {
         bool stop = false;
         int fin = 0;
@@ -332,132 +389,131 @@ __global__ __launch_bounds__(256) void vol_sweep_kernel(unsigned char *__restric
             atomicAdd(&vs->cnt[k & 3][1][0], s_dec[1]);
         }
     }
-    if (!active) return;
-    // this lane's interior state bytes (its 8 output dwords, thread = (y, z dword)): read now, A is recycled below
-    unsigned raw_in[VT_X];
-    {
-        const int y = tid / (VT_Z / 4), zd = tid - y * (VT_Z / 4);
-#pragma unroll
-        for (int x = 0; x < VT_X; ++x) raw_in[x] = A[((x + VT_H) * VA_Y + (y + VT_H)) * VA_ZS + zd + 1];
+    const int n_act = s_n;
+    if (n_act == 0) return;
+    if (s_list[0] != cur.tile) {              // the first tile is idle: fetch the first active one
+        cur = vol_tile(s_list[0], tz_n, ty_n);
+        vol_tile_load(w, rsrc, cur, res, tid);
     }
     // All sums are kept BIASED: sign + 1 in {0, 1, 2} per byte, so the z / zy / zyx sums are <= 10 / 50 / 250 -- plain
-    // 32-bit adds and subtracts never carry between bytes (the carry-safe SWAR add costs 7 ops, this costs 1), and the
-    // y and x passes slide their window (out[y] = out[y-1] + entering - leaving).  tap range: offsets [t_lo, t_hi].
-    const int t_lo = __ffs(taps) - 1 - 2, t_hi = 31 - __clz(taps) - 2, nt = t_hi - t_lo + 1;
-    // ---- z sums: one halo'd row per thread
-    if (tid < VA_X * VA_Y) {
-        unsigned w[VA_ZD];
+    // 32-bit adds and subtracts never carry between bytes, and the y and x passes slide their window
+    // (out[y] = out[y-1] + entering - leaving).
+    // |a| < thr -> 0 for the integer a = acc - bias:  a >= T  <=>  acc >= bias + T ;  a <= -T  <=>  !(acc >= bias - T + 1)
+    constexpr int bias = NT * NT * NT;
+    const int T = thr > 1.0f ? (int)ceilf(fminf(thr, 1024.0f)) : 1;
+    unsigned k_pos, r_pos, k_neg, r_neg;
+    lerp_ge_consts(bias + T, k_pos, r_pos);
+    lerp_ge_consts(bias - T + 1, k_neg, r_neg);
+    const int ty = tid / (VT_Z / 4), tzd = tid - ty * (VT_Z / 4);         // thread = (y, z dword) of the tile
+    long long sum_da = 0, sum_db = 0;         // thread 0: deltas of this workgroup's tiles against their previous counts
+    for (int i = 0; i < n_act; ++i) {
+        const VolTile t = cur;
+        vol_tile_stage(w, A, t, res, tid);    // registers -> LDS, z faces replicated
+        __syncthreads();
+        if (tid == 0) s_changed[(i + 1) & 1] = 0;
+        if (i + 1 < n_act) {                  // next tile: loads in flight during the three passes below
+            cur = vol_tile(s_list[i + 1], tz_n, ty_n);
+            vol_tile_load(w, rsrc, cur, res, tid);
+        }
+        // this lane's interior state bytes (its 8 output dwords): read now, A is recycled below
+        unsigned raw_in[VT_X];
 #pragma unroll
-        for (int d = 0; d < VA_ZD; ++d) w[d] = ((A[tid * VA_ZS + d] & 0x03030303u) + 0x01010101u) & 0x03030303u;
+        for (int x = 0; x < VT_X; ++x) raw_in[x] = A[((x + VT_H) * VA_Y + (ty + VT_H)) * VA_ZS + tzd + 1];
+        // ---- z sums: one halo'd row per thread
+        if (tid < VA_X * VA_Y) {
+            unsigned r[VA_ZD];
 #pragma unroll
-        for (int d = 0; d < VT_Z / 4; ++d) {
-            const unsigned lo = w[d], mi = w[d + 1], hi = w[d + 2];
+            for (int d = 0; d < VA_ZD; ++d) r[d] = ((A[tid * VA_ZS + d] & 0x03030303u) + 0x01010101u) & 0x03030303u;
+#pragma unroll
+            for (int d = 0; d < VT_Z / 4; ++d) {
+                const unsigned lo = r[d], mi = r[d + 1], hi = r[d + 2];
+                unsigned acc = mi;                                                            // offset 0
+                if (T_LO <= -2) acc += __builtin_amdgcn_alignbyte(mi, lo, 2);                 // -2: bytes z-2 .. z+1
+                if (T_LO <= -1) acc += __builtin_amdgcn_alignbyte(mi, lo, 3);                 // -1
+                if (T_HI >= 1) acc += __builtin_amdgcn_alignbyte(hi, mi, 1);                  // +1
+                if (T_HI >= 2) acc += __builtin_amdgcn_alignbyte(hi, mi, 2);                  // +2
+                B[tid * VB_ZS + d] = acc;
+            }
+        }
+        __syncthreads();
+        // ---- y sums: thread = (halo'd x, z dword), sliding window over the halo'd column
+        if (tid < VA_X * (VT_Z / 4)) {
+            const int ax = tid / (VT_Z / 4), zd = tid - ax * (VT_Z / 4);
+            unsigned v[VA_Y];
+#pragma unroll
+            for (int ay = 0; ay < VA_Y; ++ay) v[ay] = B[(ax * VA_Y + ay) * VB_ZS + zd];
             unsigned acc = 0;
-            if (taps & 1u) acc += __builtin_amdgcn_alignbyte(mi, lo, 2);      // offset -2: bytes z-2 .. z+1
-            if (taps & 2u) acc += __builtin_amdgcn_alignbyte(mi, lo, 3);      // -1
-            if (taps & 4u) acc += mi;                                         //  0
-            if (taps & 8u) acc += __builtin_amdgcn_alignbyte(hi, mi, 1);      // +1
-            if (taps & 16u) acc += __builtin_amdgcn_alignbyte(hi, mi, 2);     // +2
-            B[tid * VB_ZS + d] = acc;
-        }
-    }
-    __syncthreads();
-    // ---- y sums: thread = (halo'd x, z dword), sliding window over the halo'd column
-    if (tid < VA_X * (VT_Z / 4)) {
-        const int ax = tid / (VT_Z / 4), zd = tid - ax * (VT_Z / 4);
-        unsigned v[VA_Y];
 #pragma unroll
-        for (int ay = 0; ay < VA_Y; ++ay) v[ay] = B[(ax * VA_Y + ay) * VB_ZS + zd];
-        unsigned acc = 0;
+            for (int j = T_LO + 2; j <= T_HI + 2; ++j) acc += v[j];
+            C[(ax * VT_Y) * VB_ZS + zd] = acc;
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
-            if ((taps >> j) & 1u) acc += v[j];
-        C[(ax * VT_Y) * VB_ZS + zd] = acc;
-#pragma unroll
-        for (int y = 1; y < VT_Y; ++y) {
-            // window [y + 2 + t_lo, y + 2 + t_hi]: uniform selects instead of runtime-indexed registers
-            unsigned in_v = 0, out_v = 0;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                in_v = (t_hi + 2 == j) ? v[y + j] : in_v;
-                out_v = (t_lo + 2 == j) ? v[y - 1 + j] : out_v;
+            for (int y = 1; y < VT_Y; ++y) {              // window [y + 2 + T_LO, y + 2 + T_HI]
+                acc += v[y + 2 + T_HI] - v[y + 1 + T_LO];
+                C[(ax * VT_Y + y) * VB_ZS + zd] = acc;
             }
-            acc += in_v - out_v;
-            C[(ax * VT_Y + y) * VB_ZS + zd] = acc;
         }
-    }
-    __syncthreads();
-    // ---- x sums, threshold, speculative update, counts: thread = (y, z dword)
-    int z_new = 0, z_next = 0;
-    bool changed = false;
-    {
-        const int y = tid / (VT_Z / 4), zd = tid - y * (VT_Z / 4);
-        unsigned v[VA_X];
+        __syncthreads();
+        // ---- x sums, threshold, speculative update, counts
+        int known_new = 0, known_next = 0;
+        unsigned diff = 0;
+        const int gy = t.y0 + ty, gz = t.z0 + 4 * tzd;
+        const bool inside = gy < res && gz < res;         // x: res is a multiple of 16 >= VT_X
+        {
+            unsigned v[VA_X];
 #pragma unroll
-        for (int ax = 0; ax < VA_X; ++ax) v[ax] = C[(ax * VT_Y + y) * VB_ZS + zd];
-        const int gy = y0 + y, gz = z0 + 4 * zd;
-        const bool inside_yz = y < VT_Y && gy < res && gz < res;
-        // |a| < thr -> 0 for the integer a = acc - bias:  a >= T  <=>  acc >= bias + T ;  a <= -T  <=>  !(acc >= bias - T + 1)
-        const int bias = nt * nt * nt;
-        const int T = thr > 1.0f ? (int)ceilf(thr) : 1;
-        const unsigned c_pos = (unsigned)min(bias + T, 256) * 0x00010001u;
-        const unsigned c_neg = (unsigned)max(bias - T + 1, 0) * 0x00010001u;
-        unsigned acc = 0;
+            for (int ax = 0; ax < VA_X; ++ax) v[ax] = C[(ax * VT_Y + ty) * VB_ZS + tzd];
+            unsigned acc = 0;
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
-            if ((taps >> j) & 1u) acc += v[j];
+            for (int j = T_LO + 2; j <= T_HI + 2; ++j) acc += v[j];
+            const int voff = gy * res + gz;
+            if (inside) {
 #pragma unroll
-        for (int x = 0; x < VT_X; ++x) {
-            if (x > 0) {
-                unsigned in_v = 0, out_v = 0;
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    in_v = (t_hi + 2 == j) ? v[x + j] : in_v;
-                    out_v = (t_lo + 2 == j) ? v[x - 1 + j] : out_v;
+                for (int x = 0; x < VT_X; ++x) {
+                    if (x > 0) acc += v[x + 2 + T_HI] - v[x + 1 + T_LO];
+                    const unsigned raw = raw_in[x];
+                    // bit 7 of every byte: sum >= bias + T (-> +1) ; sum < bias - T + 1 (-> -1)
+                    const unsigned P = __builtin_amdgcn_lerp(acc, k_pos, r_pos) & 0x80808080u;
+                    const unsigned N = ~__builtin_amdgcn_lerp(acc, k_neg, r_neg) & 0x80808080u;
+                    const unsigned PN = P | N;
+                    const unsigned code = (PN >> 7) | (N >> 6);                         // new sign, 2-bit two's complement
+                    const unsigned u1 = (raw >> 2) & 0x01010101u;                       // unknown initially
+                    const unsigned m3 = u1 | (u1 << 1);
+                    const unsigned o = (raw & ~m3) | (code & m3);                       // v_bfi
+                    known_new += __popc(PN);
+                    known_next += __popc((o | (o >> 1)) & 0x01010101u);
+                    diff |= o ^ raw;
+                    __builtin_amdgcn_raw_buffer_store_b32(o, rsrc_out, voff, (t.x0 + x) * res * res, 0);
                 }
-                acc += in_v - out_v;
-            }
-            const int gx = x0 + x;
-            if (inside_yz && gx < res) {
-                const unsigned raw = raw_in[x];
-                // per-byte compares on the even / odd bytes as 16-bit lanes: bit 8 of (x | 0x100) - c is x >= c
-                const unsigned ev = acc & 0x00ff00ffu, od = (acc >> 8) & 0x00ff00ffu;
-                const unsigned pe = (((ev | 0x01000100u) - c_pos) >> 8) & 0x00010001u, po = (((od | 0x01000100u) - c_pos) >> 8) & 0x00010001u;
-                const unsigned ne = (~(((ev | 0x01000100u) - c_neg) >> 8)) & 0x00010001u, no = (~(((od | 0x01000100u) - c_neg) >> 8)) & 0x00010001u;
-                const unsigned pos = pe | (po << 8), neg = ne | (no << 8);          // 0x01 per byte
-                const unsigned code = pos | (neg * 3u);                             // new sign, 2-bit two's complement
-                const unsigned um = ((raw >> 2) & 0x01010101u) * 0xffu;             // 0xff where unknown initially
-                const unsigned o = raw ^ ((raw ^ (code | 0x04040404u)) & um);
-                z_new += 4 - __popc(pos | neg);
-                z_next += 4 - __popc((o | (o >> 1)) & 0x01010101u);
-                changed |= o != raw;
-                *(unsigned *)(out + ((long long)gx * res + gy) * res + gz) = o;
             }
         }
+        int z_new = inside ? 4 * VT_X - known_new : 0, z_next = inside ? 4 * VT_X - known_next : 0;
+        for (int d = 32; d > 0; d >>= 1) {
+            z_new += __shfl_xor(z_new, d);
+            z_next += __shfl_xor(z_next, d);
+        }
+        if ((tid & 63) == 0) {
+            red[0][tid >> 6] = z_next;
+            red[1][tid >> 6] = z_new;
+        }
+        if (diff) s_changed[i & 1] = 1;
+        __syncthreads();                      // also: every read of C (= A) is done before the next tile is staged
+        if (tid == 0) {
+            // delta against this tile's counts of its previous evaluation
+            const int a = red[0][0] + red[0][1] + red[0][2] + red[0][3], b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            sum_da += (long long)a - tcnt[2 * t.tile];
+            sum_db += (long long)b - tcnt[2 * t.tile + 1];
+            tcnt[2 * t.tile] = a;
+            tcnt[2 * t.tile + 1] = b;
+        }
+        if (s_changed[i & 1] && tid < 27) {   // the state changed here: this tile and its neighbours run in the next sweep
+            const int nz = t.tz_i + tid % 3 - 1, ny = t.ty_i + (tid / 3) % 3 - 1, nx = t.tx_i + tid / 9 - 1;
+            if (nz >= 0 && nz < tz_n && ny >= 0 && ny < ty_n && nx >= 0 && nx < tx_n)
+                act[((k + 1) % 3) * n_tiles + (nx * ty_n + ny) * tz_n + nz] = 1;
+        }
     }
-    for (int d = 32; d > 0; d >>= 1) {
-        z_new += __shfl_xor(z_new, d);
-        z_next += __shfl_xor(z_next, d);
-    }
-    if ((tid & 63) == 0) {
-        red[0][tid >> 6] = z_next;
-        red[1][tid >> 6] = z_new;
-    }
-    if (changed) s_changed = 1;
-    __syncthreads();
-    if (tid == 0) {
-        // delta against this tile's counts of its previous evaluation (64-bit wrap-around = signed add)
-        const int a = red[0][0] + red[0][1] + red[0][2] + red[0][3], b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        const long long da = (long long)a - tcnt[2 * tile], db = (long long)b - tcnt[2 * tile + 1];
-        tcnt[2 * tile] = a;
-        tcnt[2 * tile + 1] = b;
-        if (da) atomicAdd(&vs->cnt[k & 3][0][wg & (NSHARD - 1)], (unsigned long long)da);
-        if (db) atomicAdd(&vs->cnt[k & 3][1][wg & (NSHARD - 1)], (unsigned long long)db);
-    }
-    if (s_changed && tid < 27) {              // the state changed here: this tile and its neighbours run in the next sweep
-        const int nz = tz_i + tid % 3 - 1, ny = ty_i + (tid / 3) % 3 - 1, nx = tx_i + tid / 9 - 1;
-        if (nz >= 0 && nz < tz_n && ny >= 0 && ny < ty_n && nx >= 0 && nx < tx_n)
-            act[((k + 1) % 3) * n_tiles + (nx * ty_n + ny) * tz_n + nz] = 1;
+    if (tid == 0) {                           // 64-bit wrap-around = signed add
+        if (sum_da) atomicAdd(&vs->cnt[k & 3][0][wg & (NSHARD - 1)], (unsigned long long)sum_da);
+        if (sum_db) atomicAdd(&vs->cnt[k & 3][1][wg & (NSHARD - 1)], (unsigned long long)sum_db);
     }
 }
 
@@ -537,10 +593,15 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
             return cleanup(P2S_EHIP);
         }
         hipLaunchKernelGGL(vol_state_init_kernel, dim3((grid + 3) / 4), dim3(256), 0, s, vol_out_dev, nvox, buf0, vs);
-        unsigned taps = 0;
-        for (int j = 0; j < sigma; ++j) taps |= 1u << (off.o[j] + 2);
         const int n_tiles = ((grid_res + VT_Z - 1) / VT_Z) * ((grid_res + VT_Y - 1) / VT_Y) * ((grid_res + VT_X - 1) / VT_X);
-        const dim3 tg((unsigned)(((n_tiles + 7) / 8) * 8));
+        // persistent workgroups: 4 fit a CU (LDS) -> 1024 fill the chip; fewer tiles than that: one workgroup per tile
+        const int wgs_max = getenv("P2S_VOLUME_WGS") ? std::max(8, atoi(getenv("P2S_VOLUME_WGS")) & ~7) : 1024;
+        const int slab_tiles = (n_tiles + 7) / 8;
+        if ((slab_tiles + wgs_max / 8 - 1) / (wgs_max / 8) > 256) {
+            p2s_set_error("p2s_sdf_volume: %d tiles exceed the per-workgroup tile list", n_tiles);
+            return cleanup(P2S_EINVAL);
+        }
+        const dim3 tg((unsigned)std::min(slab_tiles * 8, wgs_max));
         // per tile: counts of its last evaluation (2 ints) and three generations of "active" flags
         int *tcnt = (int *)(vs + 1);
         unsigned char *act = (unsigned char *)(tcnt + 2 * (size_t)n_tiles);
@@ -571,8 +632,16 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
         const int k_max = 64 * grid_res + 64;            // far beyond any possible run; guards the host loop only
         bool flag_checked = false;
         for (int j = 0; k < k_max; ++j) {
-            for (int t = 0; t < batch; ++t, ++k)
-                hipLaunchKernelGGL(vol_sweep_kernel, tg, dim3(256), 0, s, buf0, buf1, grid_res, k, taps, certainty_threshold, vs, act, tcnt);
+            for (int t = 0; t < batch; ++t, ++k) {
+                auto go = [&](auto kern) { hipLaunchKernelGGL(kern, tg, dim3(256), 0, s, buf0, buf1, grid_res, k, certainty_threshold, vs, act, tcnt); };
+                switch (sigma) {              // offsets sigma / 2 - j of scipy's convolve (origin 0)
+                case 1: go(vol_sweep_kernel<0, 0>); break;
+                case 2: go(vol_sweep_kernel<0, 1>); break;
+                case 3: go(vol_sweep_kernel<-1, 1>); break;
+                case 4: go(vol_sweep_kernel<-1, 2>); break;
+                default: go(vol_sweep_kernel<-2, 2>); break;
+                }
+            }
             if (hipMemcpyAsync(&pinned[j & 1], vs, sizeof(VolState), hipMemcpyDeviceToHost, s) != hipSuccess ||
                 hipEventRecord(look[j & 1], s) != hipSuccess) {
                 p2s_set_error("p2s_sdf_volume: %s", hipGetErrorString(hipGetLastError()));
