@@ -166,7 +166,7 @@ int p2s_get_counters(p2s_model_t m, p2s_counters *out) {
 
 static size_t ws_floats_per_query(const p2s_model_s *m) {
     size_t n = 2 * 1024 + 2 * 512 + 2 * 256 + 2 * 4096 + 2 * 4096 + 2 * 1024 + 1024 + 256 + 128;
-    if (m->cfg.use_point_stn) n += 1024 + 512 + 256 + 16;
+    if (m->cfg.use_point_stn) n += 2 * 1024 + 512 + 256 + 16;
     if (m->cfg.encoder_bf16) n += 4096 * (size_t)m->cfg.encoder_bf16;   // W1' of both encoders as bf16 fragments, per piece
     return n;
 }
@@ -192,7 +192,7 @@ int p2s_model_reserve(p2s_model_s *m, int chunk) {
 namespace {
 
 struct Ws {
-    float *g_stn, *h1, *h2, *T, *w1p, *feat, *d1, *d2, *d3, *qg, *qh1, *qh2, *rot;
+    float *g_stn, *h1, *h2, *T, *w1p, *feat, *d1, *d2, *d3, *qg, *qg2, *qh1, *qh2, *rot;
     unsigned short *w1h;
 };
 
@@ -209,9 +209,10 @@ Ws carve(const p2s_model_s *m, int C) {
     w.d1 = take((size_t)C * 1024);
     w.d2 = take((size_t)C * 256);
     w.d3 = take((size_t)C * 128);
-    w.qg = w.qh1 = w.qh2 = w.rot = nullptr;
+    w.qg = w.qg2 = w.qh1 = w.qh2 = w.rot = nullptr;
     if (m->cfg.use_point_stn) {
         w.qg = take((size_t)C * 1024);
+        w.qg2 = take((size_t)C * 1024);
         w.qh1 = take((size_t)C * 512);
         w.qh2 = take((size_t)C * 256);
         w.rot = take((size_t)C * 16);
@@ -251,25 +252,28 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         b.w0b = b.b0b = nullptr; b.w1 = W; b.b1 = nullptr; b.w1_item_stride = 0;
         b.w2 = W + o.qstn.c2; b.b2 = W + o.qstn.cb2;
         b.w3 = W + o.qstn.c3; b.b3 = W + o.qstn.cb3;
-        b.out = w.qg; b.P = PL + PG; b.P1 = PL; b.n_items = C; b.relu_out = 1; b.short_chain = 1;
-        if (!qstn_shared) {
-            b.ptsA = nullptr;
-            b.P = PG;
-            b.P1 = 0;
-        }
+        // the shared QSTN's 1300 points run as TWO workgroups per query -- sub-sample (1000) and patch (300), like the
+        // encoder passes -- and the head takes max(pool, pool): 4096 equal 1300-point workgroups filled the 768
+        // workgroup slots in 5.33 rounds (105 TFLOP/s), 8192 unequal ones pack like the encoder passes (141 TFLOP/s)
+        b.ptsA = nullptr; b.out = w.qg; b.P = PG; b.P1 = 0; b.n_items = C; b.relu_out = 1; b.short_chain = 1;
         if (bf16) {
             b.w2 = reinterpret_cast<const float *>(m->blob_h + m->h_qc2);
             b.w3 = reinterpret_cast<const float *>(m->blob_h + m->h_qc3);
         }
         a.br[1] = b;
-        a.br[1].n_items = 0;
+        if (qstn_shared) {
+            ChainBranch &p = a.br[1];
+            p.ptsA = patch; p.ptsB = nullptr; p.center = nullptr; p.P = PL; p.P1 = PL; p.out = w.qg2;
+        } else {
+            a.br[1].n_items = 0;
+        }
         if ((rc = bf16 ? p2s_launch_chain_bf16(a, s) : p2s_launch_chain(a, s))) return rc;
         GemmArgs g;
         memset(&g, 0, sizeof(g));
-        g.A = w.qg; g.lda = 1024; g.a_z = 0; g.W[0] = g.W[1] = W + o.qstn.f1; g.bias[0] = g.bias[1] = W + o.qstn.fb1;
+        g.A = w.qg; g.A2 = qstn_shared ? w.qg2 : nullptr; g.lda = 1024; g.a_z = 0; g.W[0] = g.W[1] = W + o.qstn.f1; g.bias[0] = g.bias[1] = W + o.qstn.fb1;
         g.C = w.qh1; g.ldc = 512; g.c_z = 0; g.M = C; g.N = 512; g.K = 1024; g.Z = 1; g.relu = 1;
         if ((rc = p2s_launch_gemm(g, s))) return rc;
-        g.A = w.qh1; g.lda = 512; g.W[0] = g.W[1] = W + o.qstn.f2; g.bias[0] = g.bias[1] = W + o.qstn.fb2;
+        g.A = w.qh1; g.A2 = nullptr; g.lda = 512; g.W[0] = g.W[1] = W + o.qstn.f2; g.bias[0] = g.bias[1] = W + o.qstn.fb2;
         g.C = w.qh2; g.ldc = 256; g.N = 256; g.K = 512;
         if ((rc = p2s_launch_gemm(g, s))) return rc;
         if ((rc = p2s_launch_qstn_tail(w.qh2, W + o.qstn.f3, W + o.qstn.fb3, w.rot, C, 256, s))) return rc;

@@ -84,6 +84,7 @@ int p2s_launch_fold(const FoldArgs &args, hipStream_t stream);
 // ---------------------------------------------------------------------------------------------
 struct GemmArgs {
     const float *A; long long lda; long long a_z;
+    const float *A2;              // optional: the activation is max(A, A2) element-wise (NaN-propagating) -- two partial max-pools
     const float *W[2];
     const float *bias[2];
     float *C; long long ldc; long long c_z;

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void p2s_gemm_kernel(GemmArgs g) {
     const int nt = blockIdx.y * 4 + wave;
     const int KG = g.K / 8;
     const float *__restrict__ A = g.A + (long long)z * g.a_z;
+    const float *__restrict__ A2 = g.A2 ? g.A2 + (long long)z * g.a_z : nullptr;
     const float *__restrict__ Wp = g.W[z] + (long long)nt * KG * 256 + lane * 4;
     const float *__restrict__ bias = g.bias[z];
     float *__restrict__ C = g.C + (long long)z * g.c_z;
@@ -48,7 +49,12 @@ __global__ __launch_bounds__(256) void p2s_gemm_kernel(GemmArgs g) {
             const int r = (tid >> 5) + 8 * i;
             int m = m0 + r;
             if (m >= g.M) m = g.M - 1;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(A + (long long)m * g.lda + kc + 4 * (tid & 31));
+            f32x4 v = *reinterpret_cast<const f32x4 *>(A + (long long)m * g.lda + kc + 4 * (tid & 31));
+            if (A2) {                 // max-pool over two point sets = max of their pools; NaN wins like torch's max
+                const f32x4 u = *reinterpret_cast<const f32x4 *>(A2 + (long long)m * g.lda + kc + 4 * (tid & 31));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = (u[t] > v[t] || u[t] != u[t]) ? u[t] : v[t];
+            }
             *reinterpret_cast<f32x4 *>(As + r * GS + 4 * (tid & 31)) = v;
         }
         __syncthreads();

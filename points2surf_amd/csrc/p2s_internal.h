@@ -93,7 +93,7 @@ struct p2s_cloud_s {
     long long qc_n = -1, qc_cap = 0;
     // summation plan of np.sum(float32[n]) for the weighted sub-sample (p2s_wchoice.hip), built on first use
     int *wc_plan = nullptr;        // device: leaves [L][3], ops [O][3], level offsets [levels+1]
-    int wc_leaves = 0, wc_ops_at = 0, wc_lvl_at = 0, wc_levels = 0, wc_root = 0;
+    int wc_leaves = 0, wc_ops_at = 0, wc_lvl_at = 0, wc_levels = 0, wc_root = 0, wc_nodes = 0;
 };
 
 struct p2s_rng_s {
@@ -117,7 +117,6 @@ struct p2s_rng_s {
     int *blk_cum = nullptr;        // [S][B] cumulative accepted count per block
     long long *meta = nullptr;     // [S] offsets + locate record + sticky error flag + raw-request record
     // weighted sub-sample workspace (p2s_wchoice.hip), grown on demand
-    float *wc_dist = nullptr;      // [C][n]   distances to the query, then the float32 probabilities
     double *wc_S = nullptr;        // [C][n]   exact prefix sums of the probabilities
     void *wc_T = nullptr;          // [C][K]   guide records of the cdf (32 B each)
     double *wc_stot = nullptr;     // [C]

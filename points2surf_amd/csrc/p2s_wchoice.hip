@@ -52,7 +52,7 @@ struct WcPlanDev {
     const int *leaf;       // [L][3] start, len, node
     const int *ops;        // [O][3] dst, a, b   (sorted by level)
     const int *lvl_off;    // [levels + 1] op ranges per level
-    int n_leaves, n_levels, root;
+    int n_leaves, n_levels, root, n_nodes;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -64,28 +64,68 @@ __device__ __forceinline__ float wc_clip_prob(float d, float dmax) {
     return fminf(fmaxf(pr, 0.05f), 1.0f);
 }
 
+// distances of 4 consecutive points i0 .. i0+3 to the query: np.linalg.norm(axis=1) = sqrt((dx^2 + dy^2) + dz^2).
+// The cloud (<= 1.8 MB) stays in L2 for every workgroup; three 16-byte loads per thread, coalesced.  Points past the
+// end give d = 0 (callers mask them).
+__device__ __forceinline__ void wc_dist4(const float *__restrict__ pts, int n, int i0, float qx, float qy, float qz, float (&d)[4]) {
+    float c[12];
+    if (i0 + 4 <= n) {
+        const float4 a = *(const float4 *)(pts + 3 * (size_t)i0), b = *(const float4 *)(pts + 3 * (size_t)i0 + 4),
+                     e = *(const float4 *)(pts + 3 * (size_t)i0 + 8);
+        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+        c[8] = e.x; c[9] = e.y; c[10] = e.z; c[11] = e.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = i0 + j < n;
+            c[3 * j] = in ? pts[3 * (size_t)(i0 + j)] : qx;
+            c[3 * j + 1] = in ? pts[3 * (size_t)(i0 + j) + 1] : qy;
+            c[3 * j + 2] = in ? pts[3 * (size_t)(i0 + j) + 2] : qz;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float dx = qx - c[3 * j], dy = qy - c[3 * j + 1], dz = qz - c[3 * j + 2];
+        d[j] = sqrtf((dx * dx + dy * dy) + dz * dz);
+    }
+}
+__device__ __forceinline__ float wc_dist1(const float *__restrict__ pts, int i, float qx, float qy, float qz) {
+    const float dx = qx - pts[3 * (size_t)i], dy = qy - pts[3 * (size_t)i + 1], dz = qz - pts[3 * (size_t)i + 2];
+    return sqrtf((dx * dx + dy * dy) + dz * dz);
+}
+
+// One workgroup per query.  Nothing per-point is kept between the passes: every pass re-derives distance ->
+// clipped probability -> normalised probability from the L2-resident cloud (a few dozen VALU instructions) instead of
+// round-tripping a per-query float array through HBM, and issues the loads of 4096 points (12 x 16 bytes per
+// thread) before it consumes any: the kernel was bound by the latency of ~800 dependent one-element iterations
+// per thread (6.3 ms per 4096 queries), not by its 1.6 MB of output per query.
+constexpr int WC_BATCH = 4;      // sub-tiles of 1024 points in flight per thread
 __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict__ pts, int n, const float *__restrict__ q,
-                                                        WcPlanDev plan, int K, float *__restrict__ dist_all,
+                                                        WcPlanDev plan, int K,
                                                         double *__restrict__ S_all, WcRec *__restrict__ R_all,
                                                         double *__restrict__ stot_all, float *__restrict__ pmax_all,
                                                         float *__restrict__ mu_all, int nsel, long long *__restrict__ err) {
-    __shared__ float nodes[WC_MAX_NODES];
+    extern __shared__ __attribute__((aligned(16))) float wc_tab_lds[];
+    float *pcs = wc_tab_lds;                       // [NP_BUFSIZE] clipped probabilities of one numpy buffer chunk
+    float *nodes = wc_tab_lds + NP_BUFSIZE;        // [plan.n_nodes]
     __shared__ float red_f[4];
     __shared__ double red_d[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = blockIdx.x;
-    float *dist = dist_all + (size_t)qi * n;
     double *S = S_all + (size_t)qi * n;
     WcRec *R = R_all + (size_t)qi * K;
     const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
 
-    // pass 1: d_i = ||q - p_i|| (np.linalg.norm(axis=1): ((dx^2 + dy^2) + dz^2), sqrt), max
+    // pass 1: max distance
     float mx = 0.0f;
-    for (int i = tid; i < n; i += 256) {
-        const float dx = qx - pts[3 * i], dy = qy - pts[3 * i + 1], dz = qz - pts[3 * i + 2];
-        const float d = sqrtf((dx * dx + dy * dy) + dz * dz);
-        dist[i] = d;
-        mx = fmaxf(mx, d);
+    for (int t0 = 0; t0 < n; t0 += 1024 * WC_BATCH) {
+        float d[WC_BATCH][4];
+#pragma unroll
+        for (int u = 0; u < WC_BATCH; ++u) wc_dist4(pts, n, t0 + 1024 * u + 4 * tid, qx, qy, qz, d[u]);
+#pragma unroll
+        for (int u = 0; u < WC_BATCH; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mx = fmaxf(mx, d[u][j]);        // points past the end contribute 0
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
@@ -97,30 +137,48 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
         return;
     }
 
-    // pass 2: np.sum(pc) in numpy's association.  8 lanes per leaf = the 8 strided accumulators
+    // pass 2: np.sum(pc) in numpy's association, one ufunc buffer chunk (8192 elements = 64 leaves of 128, fewer /
+    // other sizes in the last one) at a time through LDS.  8 lanes per leaf = the 8 strided accumulators.
     {
         const int g = tid >> 3, k = tid & 7;
-        for (int lf = g; lf < plan.n_leaves; lf += 32) {
-            const int st = plan.leaf[3 * lf], len = plan.leaf[3 * lf + 1], nd = plan.leaf[3 * lf + 2];
-            float res = 0.0f;
-            if (len < 8) {
-                if (k == 0)
-                    for (int i = 0; i < len; ++i) res += wc_clip_prob(dist[st + i], dmax);
-            } else {
-                const int body = len - (len & 7);
-                float r = wc_clip_prob(dist[st + k], dmax);
-                for (int i = 8; i < body; i += 8) r += wc_clip_prob(dist[st + i + k], dmax);
-                r = r + __shfl_xor(r, 1);            // (r0+r1), (r2+r3), ...
-                r = r + __shfl_xor(r, 2);            // (r0+r1)+(r2+r3), (r4+r5)+(r6+r7)
-                r = r + __shfl_xor(r, 4);
-                res = r;
-                if (k == 0)
-                    for (int i = body; i < len; ++i) res += wc_clip_prob(dist[st + i], dmax);
+        for (int c0 = 0, lf0 = 0; c0 < n; c0 += NP_BUFSIZE, lf0 += NP_BUFSIZE / PW_BLOCK) {
+#pragma unroll
+            for (int h = 0; h < NP_BUFSIZE / (1024 * WC_BATCH); ++h) {
+                float d[WC_BATCH][4];
+#pragma unroll
+                for (int u = 0; u < WC_BATCH; ++u) wc_dist4(pts, n, c0 + 1024 * (WC_BATCH * h + u) + 4 * tid, qx, qy, qz, d[u]);
+#pragma unroll
+                for (int u = 0; u < WC_BATCH; ++u) {
+                    float4 v;
+                    v.x = wc_clip_prob(d[u][0], dmax); v.y = wc_clip_prob(d[u][1], dmax);
+                    v.z = wc_clip_prob(d[u][2], dmax); v.w = wc_clip_prob(d[u][3], dmax);
+                    *(float4 *)(pcs + 1024 * (WC_BATCH * h + u) + 4 * tid) = v;          // past the end: never read
+                }
             }
-            if (k == 0) nodes[nd] = res;
+            __syncthreads();
+            const int lf1 = (c0 + NP_BUFSIZE < n) ? lf0 + NP_BUFSIZE / PW_BLOCK : plan.n_leaves;
+            for (int lf = lf0 + g; lf < lf1; lf += 32) {
+                const int st = plan.leaf[3 * lf] - c0, len = plan.leaf[3 * lf + 1], nd = plan.leaf[3 * lf + 2];
+                float res = 0.0f;
+                if (len < 8) {
+                    if (k == 0)
+                        for (int i = 0; i < len; ++i) res += pcs[st + i];
+                } else {
+                    const int body = len - (len & 7);
+                    float r = pcs[st + k];
+                    for (int i = 8; i < body; i += 8) r += pcs[st + i + k];
+                    r = r + __shfl_xor(r, 1);            // (r0+r1), (r2+r3), ...
+                    r = r + __shfl_xor(r, 2);            // (r0+r1)+(r2+r3), (r4+r5)+(r6+r7)
+                    r = r + __shfl_xor(r, 4);
+                    res = r;
+                    if (k == 0)
+                        for (int i = body; i < len; ++i) res += pcs[st + i];
+                }
+                if (k == 0) nodes[nd] = res;
+            }
+            __syncthreads();
         }
     }
-    __syncthreads();
     for (int lv = 0; lv < plan.n_levels; ++lv) {
         for (int o = plan.lvl_off[lv] + tid; o < plan.lvl_off[lv + 1]; o += 256)
             nodes[plan.ops[3 * o]] = nodes[plan.ops[3 * o + 1]] + nodes[plan.ops[3 * o + 2]];
@@ -128,16 +186,25 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
     }
     const float sum = nodes[plan.root];
 
-    // pass 3: p_i = pc_i / sum (float32, kept in place of the distance) and the total mass S_N (exact in any order)
+    // pass 3: p_i = pc_i / sum (float32) -> the total mass S_N (exact in any order), power sums, max
     double acc = 0.0, acc2 = 0.0, acc3 = 0.0;
     float pm = 0.0f;
-    for (int i = tid; i < n; i += 256) {
-        const float pi = wc_clip_prob(dist[i], dmax) / sum;
-        dist[i] = pi;
-        acc += (double)pi;
-        acc2 += (double)pi * (double)pi;              // power sums: expected collisions of the first round (below)
-        acc3 += (double)pi * (double)pi * (double)pi;
-        pm = fmaxf(pm, pi);
+    for (int t0 = 0; t0 < n; t0 += 1024 * WC_BATCH) {
+        float d[WC_BATCH][4];
+#pragma unroll
+        for (int u = 0; u < WC_BATCH; ++u) wc_dist4(pts, n, t0 + 1024 * u + 4 * tid, qx, qy, qz, d[u]);
+#pragma unroll
+        for (int u = 0; u < WC_BATCH; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (t0 + 1024 * u + 4 * tid + j < n) {
+                    const float pi = wc_clip_prob(d[u][j], dmax) / sum;
+                    acc += (double)pi;
+                    acc2 += (double)pi * (double)pi;              // power sums: expected collisions of the first round (below)
+                    acc3 += (double)pi * (double)pi * (double)pi;
+                    pm = fmaxf(pm, pi);
+                }
+            }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -173,14 +240,22 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
     }
     __syncthreads();                                  // red_d is reused by the scan below
 
-    // pass 4: prefix sums + guide records, tiles of 1024 elements (4 consecutive per lane)
+    // pass 4: prefix sums + guide records, tiles of 1024 elements (4 consecutive per lane + the first of the next
+    // lane); the distances of the next tile are in flight while this one is scanned
     const double dK = (double)K;
     double carry = 0.0;
+    float dn[5];
+    wc_dist4(pts, n, 4 * tid, qx, qy, qz, (float(&)[4])dn);
+    dn[4] = 4 * tid + 4 < n ? wc_dist1(pts, 4 * tid + 4, qx, qy, qz) : 0.0f;
     for (int t0 = 0; t0 < n; t0 += 1024) {
         const int i0 = t0 + 4 * tid;
         double p[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) p[j] = (i0 + j < n) ? (double)dist[i0 + j] : 0.0;
+        for (int j = 0; j < 5; ++j) p[j] = (i0 + j < n) ? (double)(wc_clip_prob(dn[j], dmax) / sum) : 0.0;
+        if (t0 + 1024 < n) {
+            wc_dist4(pts, n, i0 + 1024, qx, qy, qz, (float(&)[4])dn);
+            dn[4] = i0 + 1028 < n ? wc_dist1(pts, i0 + 1028, qx, qy, qz) : 0.0f;
+        }
         const double l1 = p[0], l2 = l1 + p[1], l3 = l2 + p[2], l4 = l3 + p[3];
         double v = l4;
 #pragma unroll
@@ -1064,7 +1139,10 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a_in) {
 //                    window ends the block early, the next (spec, chain) pair resumes there.
 // The ids kernel re-derives every query's consumption and flags any disagreement (meta[1] = 4).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int SP_B = 512;                            // queries per speculation block
+#ifndef P2S_SP_B
+#define P2S_SP_B 2048
+#endif
+constexpr int SP_B = P2S_SP_B;                       // queries per speculation block
 constexpr int SP_W = 1024;                           // candidate starts per query
 constexpr int SP_LOOK = 64;                          // round-2 draws decided by the distance test
 constexpr int SP_NB = SP_W + WC_MAX_SEL;             // draws whose bin is needed
@@ -1495,19 +1573,19 @@ int wc_build_plan(p2s_cloud_s *c) {
     c->wc_lvl_at = (int)lvl_at;
     c->wc_levels = n_levels;
     c->wc_root = acc;
+    c->wc_nodes = pb.nodes;
     return P2S_OK;
 }
 
 int wc_reserve(p2s_rng_s *r, size_t nq, size_t n, size_t K) {
     if (nq <= r->wc_cap_q && n <= r->wc_cap_n && K <= r->wc_cap_k) return P2S_OK;
-    if (r->wc_dist) (void)hipFree(r->wc_dist);
     if (r->wc_S) (void)hipFree(r->wc_S);
     if (r->wc_T) (void)hipFree(r->wc_T);
     if (r->wc_stot) (void)hipFree(r->wc_stot);
-    r->wc_dist = nullptr; r->wc_S = nullptr; r->wc_T = nullptr; r->wc_stot = nullptr;
+    r->wc_S = nullptr; r->wc_T = nullptr; r->wc_stot = nullptr;
     r->wc_cap_q = r->wc_cap_n = r->wc_cap_k = 0;
     nq = std::max(nq, r->wc_cap_q);
-    if (hipMalloc(&r->wc_dist, nq * n * 4) != hipSuccess || hipMalloc(&r->wc_S, nq * n * 8) != hipSuccess ||
+    if (hipMalloc(&r->wc_S, nq * n * 8) != hipSuccess ||
         hipMalloc(&r->wc_T, nq * K * sizeof(WcRec)) != hipSuccess ||
         hipMalloc(&r->wc_stot, nq * 32 + (size_t)SP_B * SP_W + (size_t)SP_B * 8 + 64 + (size_t)SP_B * SP_NB * 20 + 64) != hipSuccess) {
         (void)hipGetLastError();
@@ -1523,7 +1601,6 @@ int wc_reserve(p2s_rng_s *r, size_t nq, size_t n, size_t K) {
 }  // namespace
 
 void p2s_wc_free_rng(p2s_rng_s *r) {
-    if (r->wc_dist) (void)hipFree(r->wc_dist);
     if (r->wc_S) (void)hipFree(r->wc_S);
     if (r->wc_T) (void)hipFree(r->wc_T);
     if (r->wc_stot) (void)hipFree(r->wc_stot);
@@ -1591,6 +1668,7 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     plan.n_leaves = c->wc_leaves;
     plan.n_levels = c->wc_levels;
     plan.root = c->wc_root;
+    plan.n_nodes = c->wc_nodes;
     // per-query scalars share one allocation: [stot f64][base i64][pmax f32, cells i32][mu f32, pad], followed by the
     // speculation block: [ctl i64 x 8][klo i64 x SP_B][rtab u8 x SP_B x SP_W]
     double *stot = r->wc_stot;
@@ -1615,10 +1693,16 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
         return P2S_ECAPACITY;
     }
     if (nq >= 64) lds_off = std::max(lds_off, hog);
+    // the chain workgroup of a full block claims a CU of its own (LDS no encoder workgroup fits next to): sharing a
+    // CU with the encoders' MFMA-saturated waves it gets an instruction issued every ~200 cycles (measured: 1.4 us
+    // per query of the walk whether the table sits in global memory, LDS or registers; 80 us per fallback instead of
+    // 14.5) -- with blocks of 2048 queries the wait for a drained CU is paid twice per chunk
+    const size_t lds_chain = nq >= 64 ? std::max(lds_ids, getenv("P2S_WC_CHAIN_LDS") ? (size_t)atoi(getenv("P2S_WC_CHAIN_LDS")) : (size_t)100000) : lds_ids;
     {   // per device (a process may drive several); the call is cheap
         (void)hipFuncSetAttribute((const void *)wc_offsets_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         (void)hipFuncSetAttribute((const void *)wc_ids_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)wc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void *)wc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096 - SP_B * 8);
+        (void)hipFuncSetAttribute((const void *)wc_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NP_BUFSIZE + WC_MAX_NODES) * 4);
     }
     long long *meta = p2s_rng_raw_meta(r);
     static long long *stats_dev = nullptr;
@@ -1634,8 +1718,8 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
             rc = p2s_rng_session_raw(r, (long long)(2.0 * n_sel * 1.15 * cur) + margin, s);
         }
         if (rc) return rc;
-        hipLaunchKernelGGL(wc_tables_kernel, dim3(cur), dim3(256), 0, s, c->d.pts, n, q_dev + (size_t)done * 3, plan, K,
-                           r->wc_dist, r->wc_S, (WcRec *)r->wc_T, stot, pmax, mu, n_sel, meta);
+        hipLaunchKernelGGL(wc_tables_kernel, dim3(cur), dim3(256), (size_t)(NP_BUFSIZE + ((plan.n_nodes + 3) & ~3)) * 4, s, c->d.pts, n,
+                           q_dev + (size_t)done * 3, plan, K, r->wc_S, (WcRec *)r->wc_T, stot, pmax, mu, n_sel, meta);
         WcArgs a;
         a.S = r->wc_S;
         a.R = (const WcRec *)r->wc_T;
@@ -1669,7 +1753,7 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
             const int pairs = (cur + SP_B - 1) / SP_B + (cur > SP_B / 2 ? 2 : 0);
             for (int pr = 0; pr < pairs; ++pr) {
                 hipLaunchKernelGGL(wc_spec_kernel, dim3(std::min(cur, SP_B)), dim3(256), 0, s, a, sp);
-                hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), lds_ids, s, a, sp);
+                hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), pr < (cur + SP_B - 1) / SP_B ? lds_chain : lds_ids, s, a, sp);
             }
             a.ctl = sp.ctl;
             hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(WC_NT), wc_offsets_lds_bytes(n), s, a);

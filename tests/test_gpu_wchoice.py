@@ -181,12 +181,12 @@ def test_rng_sessions_mixed_calls_match_numpy(fixture_cloud, torch_cuda):
 
 
 def test_speculative_offsets_across_blocks_match_numpy_and_serial_kernel(fixture_cloud, torch_cuda, monkeypatch):
-    """the parallel offsets pass (wc_spec_kernel + wc_chain_kernel, blocks of 512 queries) against numpy's stream for
-    1,300 consecutive grid queries (three blocks), and against the serial kernel (P2S_WC_SERIAL) including the skip path
+    """the parallel offsets pass (wc_spec_kernel + wc_chain_kernel, blocks of 2048 queries) against numpy's stream for
+    4,300 consecutive grid queries (three blocks), and against the serial kernel (P2S_WC_SERIAL) including the skip path
     (NULL ids: stream advanced only)"""
     from points2surf_amd import engine
     cloud = engine.Cloud(fixture_cloud)
-    q = cloud.query_grid(64, 3)[2000:3300].contiguous()
+    q = cloud.query_grid(64, 3)[1000:5300].contiguous()
     nq = int(q.shape[0])
     r = engine.Rng(4242)
     got = r.subsample_weighted(cloud, q, 1000, want_pts=False)[0].cpu().numpy()
@@ -205,7 +205,7 @@ def test_speculative_offsets_across_blocks_match_numpy_and_serial_kernel(fixture
     r3 = engine.Rng(4242)
     got3 = r3.subsample_weighted(cloud, q, 1000, want_pts=False)[0].cpu().numpy()
     r3.check()
-    assert np.array_equal(got3, got) and nq == 1300
+    assert np.array_equal(got3, got) and nq == 4300
 
 
 def test_weighted_at_the_size_cap(torch_cuda):
