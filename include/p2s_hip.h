@@ -51,7 +51,8 @@ typedef struct {
     int32_t net_size;            /* 1024 (train --net_size)                                    */
     int32_t points_per_patch;    /* 300  (train --points_per_patch)                            */
     int32_t sub_sample_size;     /* 1000 (train --sub_sample_size)                             */
-    int32_t output_dim;          /* 2: [|d| logit, sign logit]                                 */
+    int32_t output_dim;          /* 2: [|d| logit, sign logit] (outputs imp_surf_magnitude, imp_surf_sign);
+                                    1: the signed-distance logit (output imp_surf, p2s_regression)  */
     int32_t use_point_stn;       /* QSTN present (p2s_vanilla and most ablation models)        */
     int32_t shared_transformer;  /* 1: one QSTN over cat(patch, sub-sample) (p2s_vanilla);
                                     0: the QSTN of feat_global, over the sub-sample only; its
@@ -64,7 +65,10 @@ typedef struct {
                                     product, 16 / 24 mantissa bits): see DESIGN.md for the measured deviation      */
     int32_t fixed_subsample;     /* train --fixed_subsample 1 (ablation): the generator is re-seeded with 42 before every
                                     query's draw (reference source/base/utils.py:210-211)                       */
-    int32_t reserved[7];
+    int32_t single_transformer;  /* train --single_transformer 1 (p2s_shared_encoder): ONE encoder over cat(patch,
+                                    sub-sample); enc[0] = enc[1] = feat_local_global.*, the QSTN is its stn1 and sees
+                                    all points, d1l / d1g = the two halves of fc1_local_global (1024 -> 1024)  */
+    int32_t reserved[6];
 } p2s_model_cfg;
 
 /* Offsets (in floats) into the weight blob.  The blob holds BatchNorm-folded fp32 weights,

@@ -40,12 +40,16 @@ NQ = 64
 
 
 def train_namespace(cfg, batch=500):
+    # experiments/train_p2s_regression.sh: ONE output ('imp_surf'); every other script: magnitude + sign
+    outputs = ['imp_surf', 'patch_pts_ids', 'p_index'] if int(cfg.get('output_dim', 2)) == 1 else \
+        ['imp_surf_magnitude', 'imp_surf_sign', 'patch_pts_ids', 'p_index']
     return argparse.Namespace(
-        outputs=['imp_surf_magnitude', 'imp_surf_sign', 'patch_pts_ids', 'p_index'],
+        outputs=outputs,
         points_per_patch=int(cfg.get('points_per_patch', 300)), patch_center='mean', sub_sample_size=1000, patch_radius=0.0,
         uniform_subsample=int(cfg['uniform_subsample']), fixed_subsample=0, net_size=1024,
         use_point_stn=int(cfg['use_point_stn']), use_feat_stn=1, sym_op='max',
-        single_transformer=0, shared_transformer=int(cfg['shared_transformer']), batchSize=batch)
+        single_transformer=int(cfg.get('single_transformer', False)), shared_transformer=int(cfg['shared_transformer']),
+        batchSize=batch)
 
 
 def sha(a):

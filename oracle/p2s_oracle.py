@@ -418,14 +418,23 @@ def model_forward(w, cfg, patch_pts_ps, pts_sub_sample_ms, query_ms, chunk=32, r
     use_point_stn = bool(cfg.get('use_point_stn', False))
     shared = bool(cfg.get('shared_transformer', False))
     use_feat_stn = bool(cfg.get('use_feat_stn', True))
-    if cfg.get('single_transformer', False):
-        raise NotImplementedError('single_transformer ablation')
+    single = bool(cfg.get('single_transformer', False))
     out = []
     feats = []
     for s in range(0, B, chunk):
         patch = np.asarray(patch_pts_ps[s:s + chunk], dtype=np.float32)
         shape = np.asarray(pts_sub_sample_ms[s:s + chunk], dtype=np.float32) \
             - np.asarray(query_ms[s:s + chunk], dtype=np.float32)[:, None, :]      # :303
+        if single:                                                                # :320-323
+            lg, _ = pointnetfeat_forward(np.concatenate([patch, shape], axis=1), w, 'feat_local_global',
+                                         use_point_stn, use_feat_stn)
+            f = _relu(_bn(_fc(lg, w, 'fc1_local_global'), w, 'bn1_local_global', 1))
+            f = _relu(_bn(_fc(f, w, 'fc2'), w, 'bn2', 1))
+            f = _relu(_bn(_fc(f, w, 'fc3'), w, 'bn3', 1))
+            out.append(_fc(f, w, 'fc4'))
+            if return_feats:
+                feats.append((lg, lg))
+            continue
         if use_point_stn and shared:                                              # :325-331
             both = np.concatenate([patch, shape], axis=1)
             trans, _ = qstn_forward(both, w, 'point_stn')
@@ -454,6 +463,10 @@ def post_process(logits, patch_radius):
     """source/points_to_surf_eval.py:184-196 + source/sdf_nn.py:11-21 + :263-273,205-207:
     sdf = tanh(l0)^2 * r * (l1 >= 0 ? +1 : -1); NaN -> 1.0."""
     logits = np.asarray(logits, dtype=np.float32)
+    if logits.shape[1] == 1:      # outputs = ['imp_surf']: sdf_nn.post_process_distance (sdf_nn.py:6-8), * radius (:176-183)
+        sdf = (np.tanh(logits[:, 0]) ** 2 * np.sign(logits[:, 0]) * np.asarray(patch_radius, dtype=np.float32)).astype(np.float32)
+        sdf[np.isnan(sdf)] = 1.0
+        return sdf
     mag = np.tanh(logits[:, 0]) ** 2 * np.asarray(patch_radius, dtype=np.float32)
     sign = np.where(logits[:, 1] >= 0, np.float32(1), np.float32(-1))
     sdf = (mag * sign).astype(np.float32)

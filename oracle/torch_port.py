@@ -79,6 +79,15 @@ class TorchPort:
     def forward(self, patch_ps, sub_ms, query):
         patch = torch.as_tensor(patch_ps).transpose(1, 2)
         shape = (torch.as_tensor(sub_ms) - torch.as_tensor(query).unsqueeze(1)).transpose(1, 2)
+        if self.cfg.get('single_transformer'):
+            # one PointNetfeat over cat(patch, sub-sample) (reference source/points_to_surf_model.py:320-323)
+            x = torch.cat((patch, shape), dim=2)
+            if self.cfg.get('use_point_stn'):
+                x = torch.bmm(self._qstn(x, 'feat_local_global.stn1'), x)
+            f = self._fc_bn(self._feat(x.contiguous(), 'feat_local_global'), 'fc1_local_global', 'bn1_local_global')
+            f = self._fc_bn(f, 'fc2', 'bn2')
+            f = self._fc_bn(f, 'fc3', 'bn3')
+            return F.linear(f, self.w['fc4.weight'], self.w['fc4.bias'])
         if self.cfg.get('use_point_stn') and self.cfg.get('shared_transformer'):
             r = self._qstn(torch.cat((patch, shape), dim=2), 'point_stn')
             shape = torch.bmm(r, shape)

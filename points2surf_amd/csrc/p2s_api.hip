@@ -54,7 +54,7 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
         p2s_set_error("p2s_model_create: null argument");
         return P2S_EINVAL;
     }
-    if (cfg->net_size != 1024 || cfg->output_dim != 2 || cfg->points_per_patch < 1 || cfg->sub_sample_size < 1) {
+    if (cfg->net_size != 1024 || (cfg->output_dim != 2 && cfg->output_dim != 1) || cfg->points_per_patch < 1 || cfg->sub_sample_size < 1) {
         p2s_set_error("p2s_model_create: unsupported cfg (net_size=%d output_dim=%d)", cfg->net_size, cfg->output_dim);
         return P2S_EINVAL;
     }
@@ -247,7 +247,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         a.w1_piece_stride = (long long)2 * C * 4096;
         ChainBranch &b = a.br[0];
         b.ptsA = patch; b.ptsB = sub; b.center = query; b.rot = nullptr;
-        const bool qstn_shared = m->cfg.shared_transformer != 0;
+        const bool qstn_shared = m->cfg.shared_transformer != 0 || m->cfg.single_transformer != 0;
         b.w0a = W + o.qstn.c1; b.b0a = W + o.qstn.cb1;
         b.w0b = b.b0b = nullptr; b.w1 = W; b.b1 = nullptr; b.w1_item_stride = 0;
         b.w2 = W + o.qstn.c2; b.b2 = W + o.qstn.cb2;
@@ -270,7 +270,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         if ((rc = bf16 ? p2s_launch_chain_bf16(a, s) : p2s_launch_chain(a, s))) return rc;
         GemmArgs g;
         memset(&g, 0, sizeof(g));
-        g.A = w.qg; g.A2 = qstn_shared ? w.qg2 : nullptr; g.lda = 1024; g.a_z = 0; g.W[0] = g.W[1] = W + o.qstn.f1; g.bias[0] = g.bias[1] = W + o.qstn.fb1;
+        g.A = w.qg; g.A2 = qstn_shared ? w.qg2 : nullptr; g.a2_z = 0; g.lda = 1024; g.a_z = 0; g.W[0] = g.W[1] = W + o.qstn.f1; g.bias[0] = g.bias[1] = W + o.qstn.fb1;
         g.C = w.qh1; g.ldc = 512; g.c_z = 0; g.M = C; g.N = 512; g.K = 1024; g.Z = 1; g.relu = 1;
         if ((rc = p2s_launch_gemm(g, s))) return rc;
         g.A = w.qh1; g.A2 = nullptr; g.lda = 512; g.W[0] = g.W[1] = W + o.qstn.f2; g.bias[0] = g.bias[1] = W + o.qstn.fb2;
@@ -314,10 +314,14 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         memset(&g, 0, sizeof(g));
         g.M = C; g.Z = 2; g.relu = 1;
         g.A = w.g_stn; g.lda = 1024; g.a_z = (long long)C * 1024;
+        if (m->cfg.single_transformer) {      // one encoder over both point sets: its pool = max of the two branches' pools
+            g.A2 = w.g_stn + (size_t)C * 1024;
+            g.a2_z = -(long long)C * 1024;
+        }
         g.W[0] = W + o.enc[0].sf1; g.W[1] = W + o.enc[1].sf1; g.bias[0] = W + o.enc[0].sfb1; g.bias[1] = W + o.enc[1].sfb1;
         g.C = w.h1; g.ldc = 512; g.c_z = (long long)C * 512; g.N = 512; g.K = 1024;
         if ((rc = p2s_launch_gemm(g, s))) return rc;
-        g.A = w.h1; g.lda = 512; g.a_z = (long long)C * 512;
+        g.A = w.h1; g.A2 = nullptr; g.lda = 512; g.a_z = (long long)C * 512;
         g.W[0] = W + o.enc[0].sf2; g.W[1] = W + o.enc[1].sf2; g.bias[0] = W + o.enc[0].sfb2; g.bias[1] = W + o.enc[1].sfb2;
         g.C = w.h2; g.ldc = 256; g.c_z = (long long)C * 256; g.N = 256; g.K = 512;
         if ((rc = p2s_launch_gemm(g, s))) return rc;
@@ -367,16 +371,20 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         g.M = C; g.relu = 1;
         // fc1_local | fc1_global -> cat (local first): reference points_to_surf_model.py:335,343,346
         g.Z = 2; g.A = w.feat; g.lda = 1024; g.a_z = (long long)C * 1024;
+        if (m->cfg.single_transformer) {      // fc1_local_global reads the ONE pooled feature; d1l / d1g are its column halves
+            g.A2 = w.feat + (size_t)C * 1024;
+            g.a2_z = -(long long)C * 1024;
+        }
         g.W[0] = W + o.d1l; g.W[1] = W + o.d1g; g.bias[0] = W + o.db1l; g.bias[1] = W + o.db1g;
         g.C = w.d1; g.ldc = 1024; g.c_z = 512; g.N = 512; g.K = 1024;
         if ((rc = p2s_launch_gemm(g, s))) return rc;
-        g.Z = 1; g.A = w.d1; g.lda = 1024; g.a_z = 0; g.W[0] = g.W[1] = W + o.d2; g.bias[0] = g.bias[1] = W + o.db2;
+        g.Z = 1; g.A = w.d1; g.A2 = nullptr; g.lda = 1024; g.a_z = 0; g.W[0] = g.W[1] = W + o.d2; g.bias[0] = g.bias[1] = W + o.db2;
         g.C = w.d2; g.ldc = 256; g.c_z = 0; g.N = 256; g.K = 1024;
         if ((rc = p2s_launch_gemm(g, s))) return rc;
         g.A = w.d2; g.lda = 256; g.W[0] = g.W[1] = W + o.d3; g.bias[0] = g.bias[1] = W + o.db3;
         g.C = w.d3; g.ldc = 128; g.N = 128; g.K = 256;
         if ((rc = p2s_launch_gemm(g, s))) return rc;
-        if ((rc = p2s_launch_decoder_tail(w.d3, W + o.d4, W + o.db4, radius, logits_out, sdf_out, C, 128, s))) return rc;
+        if ((rc = p2s_launch_decoder_tail(w.d3, W + o.d4, W + o.db4, radius, logits_out, sdf_out, C, 128, m->cfg.output_dim, s))) return rc;
     }
     const int ev4 = p2s_prof_mark(m, s);
     p2s_prof_span(m, ST_CHAIN_STN, ev0, ev1);

@@ -85,6 +85,7 @@ int p2s_launch_fold(const FoldArgs &args, hipStream_t stream);
 struct GemmArgs {
     const float *A; long long lda; long long a_z;
     const float *A2;              // optional: the activation is max(A, A2) element-wise (NaN-propagating) -- two partial max-pools
+    long long a2_z;               // stride of A2 per z (may differ from a_z: with a_z = -a2_z both z see the same pair)
     const float *W[2];
     const float *bias[2];
     float *C; long long ldc; long long c_z;
@@ -95,7 +96,7 @@ int p2s_launch_gemm(const GemmArgs &args, hipStream_t stream);
 
 // fc4 (128 -> 2) + tanh^2 * r * sign + NaN->1
 int p2s_launch_decoder_tail(const float *h3, const float *w4, const float *b4, const float *radius,
-                            float *logits_out, float *sdf_out, int B, int K, hipStream_t stream);
+                            float *logits_out, float *sdf_out, int B, int K, int output_dim, hipStream_t stream);
 // QSTN tail: fc3 (256 -> 4) + identity quaternion (in bias) -> rotation matrix [B][9]
 int p2s_launch_qstn_tail(const float *h2, const float *w3, const float *b3, float *rot_out, int B, int K,
                          hipStream_t stream);

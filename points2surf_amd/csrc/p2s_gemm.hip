@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void p2s_gemm_kernel(GemmArgs g) {
     const int nt = blockIdx.y * 4 + wave;
     const int KG = g.K / 8;
     const float *__restrict__ A = g.A + (long long)z * g.a_z;
-    const float *__restrict__ A2 = g.A2 ? g.A2 + (long long)z * g.a_z : nullptr;
+    const float *__restrict__ A2 = g.A2 ? g.A2 + (long long)z * g.a2_z : nullptr;
     const float *__restrict__ Wp = g.W[z] + (long long)nt * KG * 256 + lane * 4;
     const float *__restrict__ bias = g.bias[z];
     float *__restrict__ C = g.C + (long long)z * g.c_z;
@@ -95,10 +95,29 @@ __global__ __launch_bounds__(256) void p2s_decoder_tail_kernel(const float *__re
                                                                const float *__restrict__ b4,
                                                                const float *__restrict__ radius,
                                                                float *__restrict__ logits_out,
-                                                               float *__restrict__ sdf_out, int B, int K) {
+                                                               float *__restrict__ sdf_out, int B, int K, int od) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= B) return;
     const float *h = h3 + (long long)q * K;
+    if (od == 1) {
+        // outputs = ['imp_surf']: one logit, distance = tanh(x)^2 * sign(x) (sdf_nn.py:6-8), * patch radius
+        // (points_to_surf_eval.py:176-183); torch.sign(0) = 0, NaN stays NaN and becomes 1.0 (:205-207)
+        float l = b4[0];
+        for (int k = 0; k < K; k += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(h + k);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) l = fmaf(v[t], w4[k + t], l);
+        }
+        if (logits_out) logits_out[q] = l;
+        if (sdf_out) {
+            const float th = tanhf(l);
+            const float sg = (l > 0.0f) ? 1.0f : ((l < 0.0f) ? -1.0f : (l == 0.0f ? 0.0f : l));
+            float sdf = ((th * th) * sg) * radius[q];
+            if (sdf != sdf) sdf = 1.0f;
+            sdf_out[q] = sdf;
+        }
+        return;
+    }
     float l0 = b4[0], l1 = b4[1];
     for (int k = 0; k < K; k += 4) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(h + k);
@@ -170,10 +189,10 @@ int p2s_launch_gemm(const GemmArgs &g, hipStream_t stream) {
 }
 
 int p2s_launch_decoder_tail(const float *h3, const float *w4, const float *b4, const float *radius,
-                            float *logits_out, float *sdf_out, int B, int K, hipStream_t stream) {
+                            float *logits_out, float *sdf_out, int B, int K, int output_dim, hipStream_t stream) {
     if (B <= 0) return P2S_OK;
     hipLaunchKernelGGL(p2s_decoder_tail_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, h3, w4, b4, radius,
-                       logits_out, sdf_out, B, K);
+                       logits_out, sdf_out, B, K, output_dim);
     P2S_LAUNCH_CHECK("p2s_decoder_tail_kernel");
     return P2S_OK;
 }

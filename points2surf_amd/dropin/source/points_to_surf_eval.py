@@ -75,7 +75,7 @@ def parse_arguments(args=None):
 
 
 def get_output_dimensions(train_opt):
-    """reference :81-103: the engine implements outputs = magnitude + sign (pred_dim 2)"""
+    """reference :81-103: the engine implements outputs = magnitude + sign (pred_dim 2) and outputs = imp_surf (pred_dim 1)"""
     pred_dim = 0
     for o in train_opt.outputs:
         if o in ('imp_surf', 'imp_surf_magnitude', 'imp_surf_sign'):
@@ -98,13 +98,13 @@ def _load_train_opt(param_filename):
 
 def _engine_cfg(train_opt, pred_dim):
     outputs = list(train_opt.outputs)
-    if 'imp_surf' in outputs or 'imp_surf_magnitude' not in outputs or 'imp_surf_sign' not in outputs:
-        raise ValueError('the HIP engine supports outputs imp_surf_magnitude + imp_surf_sign (got %s)' % outputs)
     pred_cols = [o for o in outputs if o in ('imp_surf', 'imp_surf_magnitude', 'imp_surf_sign')]
-    if pred_cols != ['imp_surf_magnitude', 'imp_surf_sign']:
+    if pred_cols not in (['imp_surf_magnitude', 'imp_surf_sign'], ['imp_surf']):
         # the reference maps prediction columns by the ORDER of train_opt.outputs (output_pred_ind, :81-103); the
-        # decoder tail of the engine is column 0 = magnitude, column 1 = sign
-        raise ValueError('the HIP engine expects outputs ordered imp_surf_magnitude, imp_surf_sign (got %s)' % outputs)
+        # decoder tail of the engine is column 0 = magnitude, column 1 = sign -- or the single signed-distance logit
+        # of the regression model (experiments/train_p2s_regression.sh)
+        raise ValueError('the HIP engine supports outputs imp_surf_magnitude, imp_surf_sign (in this order) or imp_surf '
+                         '(got %s)' % outputs)
     if getattr(train_opt, 'patch_radius', 0.0) > 0.0:
         raise ValueError('fixed patch_radius (radius query) models are not supported by the HIP engine')
     return dict(

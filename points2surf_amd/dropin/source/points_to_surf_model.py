@@ -58,8 +58,6 @@ class PointsToSurfModel(nn.Module):
         if sym_op not in ('max',):
             # the reference accepts 'sum' too; the engine implements the published models ('max')
             raise ValueError('Unsupported symmetric operation: %s' % sym_op)
-        if bool(single_transformer):
-            raise ValueError('single_transformer ablation is not supported by the HIP engine')
         self.net_size_max = net_size_max
         self.num_points = num_points
         self.output_dim = output_dim
@@ -73,14 +71,19 @@ class PointsToSurfModel(nn.Module):
         self.shared_transformation = bool(shared_transformation)
         n = int(net_size_max)
 
-        if self.use_point_stn and self.shared_transformation:
-            self.point_stn = _trunk(3, n, 4)
-        self.feat_local = _encoder(n, False, use_feat_stn)
-        self.feat_global = _encoder(n, self.use_point_stn and not self.shared_transformation, use_feat_stn)
-        self.fc1_local = nn.Linear(n, n // 2)
-        self.fc1_global = nn.Linear(n, n // 2)
-        self.bn1_local = nn.BatchNorm1d(n // 2)
-        self.bn1_global = nn.BatchNorm1d(n // 2)
+        if self.single_transformer:          # reference :253-263: one encoder over cat(patch, sub-sample)
+            self.feat_local_global = _encoder(n, self.use_point_stn, use_feat_stn)
+            self.fc1_local_global = nn.Linear(n, n)
+            self.bn1_local_global = nn.BatchNorm1d(n)
+        else:
+            if self.use_point_stn and self.shared_transformation:
+                self.point_stn = _trunk(3, n, 4)
+            self.feat_local = _encoder(n, False, use_feat_stn)
+            self.feat_global = _encoder(n, self.use_point_stn and not self.shared_transformation, use_feat_stn)
+            self.fc1_local = nn.Linear(n, n // 2)
+            self.fc1_global = nn.Linear(n, n // 2)
+            self.bn1_local = nn.BatchNorm1d(n // 2)
+            self.bn1_global = nn.BatchNorm1d(n // 2)
         self.fc2 = nn.Linear(n, n // 4)
         self.fc3 = nn.Linear(n // 4, n // 8)
         self.fc4 = nn.Linear(n // 8, output_dim)

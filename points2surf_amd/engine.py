@@ -63,6 +63,7 @@ class Model:
         self._blob = np.ascontiguousarray(blob)
         self.points_per_patch = mc.points_per_patch
         self.sub_sample_size = mc.sub_sample_size
+        self.output_dim = mc.output_dim
         self.uniform_subsample = bool(cfg.get('uniform_subsample', False))
         self.handle = ctypes.c_void_p()
         _lib.check(self.lib.p2s_model_create(
@@ -81,7 +82,7 @@ class Model:
             pass
 
     def forward(self, patch_pts_ps, pts_sub_sample_ms, query_ms, radius=None, want_logits=True, want_sdf=False):
-        """a8 (+a9).  Returns (logits [B,2] or None, sdf [B] or None).  Inputs are not modified."""
+        """a8 (+a9).  Returns (logits [B, output_dim] or None, sdf [B] or None).  Inputs are not modified."""
         dev = self.device
         patch = _f32c(patch_pts_ps, dev)
         sub = _f32c(pts_sub_sample_ms, dev)
@@ -89,7 +90,7 @@ class Model:
         B = patch.shape[0]
         if patch.shape != (B, self.points_per_patch, 3) or sub.shape != (B, self.sub_sample_size, 3) or q.shape != (B, 3):
             raise ValueError('bad input shapes %s %s %s' % (tuple(patch.shape), tuple(sub.shape), tuple(q.shape)))
-        logits = torch.empty((B, 2), dtype=torch.float32, device=dev) if want_logits else None
+        logits = torch.empty((B, self.output_dim), dtype=torch.float32, device=dev) if want_logits else None
         sdf = torch.empty((B,), dtype=torch.float32, device=dev) if want_sdf else None
         rad = _f32c(radius.reshape(-1), dev) if radius is not None else None
         if want_sdf and rad is None:

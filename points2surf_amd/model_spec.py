@@ -26,6 +26,11 @@ NAMED_MODELS = {
     'p2s_no_qstn': dict(use_point_stn=False, shared_transformation=False, uniform_subsample=False),
     'p2s_small_kNN': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, points_per_patch=75),
     'p2s_large_kNN': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, points_per_patch=1200),
+    # experiments/train_p2s_regression.sh: ONE output, the signed distance itself ('imp_surf': tanh^2 * sign, sdf_nn.py:6-8)
+    'p2s_regression': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, output_dim=1),
+    # experiments/train_p2s_shared_encoder.sh (--single_transformer 1): one PointNetfeat over cat(patch, sub-sample)
+    # with its own QSTN + STN, then fc1_local_global 1024 -> 1024 (source/points_to_surf_model.py:253-263, :320-323)
+    'p2s_shared_encoder': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, single_transformer=True),
 }
 
 
@@ -86,15 +91,18 @@ def state_shapes(net_size_max=1024, output_dim=2, use_point_stn=False, use_feat_
     n = int(net_size_max)
     out = OrderedDict()
     if single_transformer:
-        raise NotImplementedError('single_transformer ablation is outside the accelerated path')
-    if use_point_stn and shared_transformation:
-        _trunk('point_stn', 3, n, 4, out)
-    _pointnetfeat('feat_local', n, False, use_feat_stn, out)
-    _pointnetfeat('feat_global', n, bool(use_point_stn and not shared_transformation), use_feat_stn, out)
-    _fc('fc1_local', n, n // 2, out)
-    _fc('fc1_global', n, n // 2, out)
-    _bn('bn1_local', n // 2, out)
-    _bn('bn1_global', n // 2, out)
+        _pointnetfeat('feat_local_global', n, bool(use_point_stn), use_feat_stn, out)
+        _fc('fc1_local_global', n, n, out)
+        _bn('bn1_local_global', n, out)
+    else:
+        if use_point_stn and shared_transformation:
+            _trunk('point_stn', 3, n, 4, out)
+        _pointnetfeat('feat_local', n, False, use_feat_stn, out)
+        _pointnetfeat('feat_global', n, bool(use_point_stn and not shared_transformation), use_feat_stn, out)
+        _fc('fc1_local', n, n // 2, out)
+        _fc('fc1_global', n, n // 2, out)
+        _bn('bn1_local', n // 2, out)
+        _bn('bn1_global', n // 2, out)
     _fc('fc2', n, n // 4, out)
     _fc('fc3', n // 4, n // 8, out)
     _fc('fc4', n // 8, output_dim, out)

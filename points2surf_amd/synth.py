@@ -17,16 +17,19 @@ from .model_spec import state_shapes, NAMED_MODELS
 
 _FC4_BIAS_SHIFT = {'p2s_max': (6.289174, 2.416443), 'p2s_vanilla': (2.6854432, 4.523528),
                    'p2s_uniform': (4.6575, 2.458), 'p2s_no_qstn': (2.3863, 1.8502), 'p2s_small_kNN': (4.2235, 2.2435),
-                   'p2s_large_kNN': (4.9557, 2.6857)}
+                   'p2s_large_kNN': (4.9557, 2.6857), 'p2s_regression': (3.7676,), 'p2s_shared_encoder': (-0.2, -3.9804)}
 
 
-def make_weights(model='p2s_max', seed=1234, net_size_max=1024, output_dim=2):
+def make_weights(model='p2s_max', seed=1234, net_size_max=1024, output_dim=None):
     """Returns ({name: float32 ndarray} without ``module.`` prefix, cfg dict)."""
     cfg = dict(NAMED_MODELS[model]) if isinstance(model, str) else dict(model)
+    if output_dim is None:
+        output_dim = int(cfg.get('output_dim', 2))
+    single = bool(cfg.get('single_transformer', False))
     shapes = state_shapes(net_size_max=net_size_max, output_dim=output_dim,
                           use_point_stn=cfg.get('use_point_stn', False),
                           shared_transformation=cfg.get('shared_transformation', False),
-                          use_feat_stn=cfg.get('use_feat_stn', True))
+                          use_feat_stn=cfg.get('use_feat_stn', True), single_transformer=single)
     rng = np.random.default_rng(seed)
     w = {}
     for name, shape in shapes.items():
@@ -62,12 +65,12 @@ def make_weights(model='p2s_max', seed=1234, net_size_max=1024, output_dim=2):
     # its spread; measured once on the abc_minimal fixture) so that tanh is not saturated and the
     # sign logit changes sign across queries
     shift = _FC4_BIAS_SHIFT.get(model if isinstance(model, str) else None)
-    if shift is not None and seed == 1234 and output_dim == 2 and net_size_max == 1024:
+    if shift is not None and seed == 1234 and output_dim == len(shift) and net_size_max == 1024:
         w['fc4.bias'] = (w['fc4.bias'] + np.asarray(shift, dtype=np.float32)).astype(np.float32)
     cfg_out = dict(
         use_point_stn=bool(cfg.get('use_point_stn', False)),
         shared_transformer=bool(cfg.get('shared_transformation', False)),
-        use_feat_stn=True, single_transformer=False,
+        use_feat_stn=True, single_transformer=single,
         uniform_subsample=bool(cfg.get('uniform_subsample', False)), fixed_subsample=False,
         net_size=net_size_max, points_per_patch=int(cfg.get('points_per_patch', 300)), sub_sample_size=1000,
         output_dim=output_dim)

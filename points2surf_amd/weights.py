@@ -43,7 +43,8 @@ class ModelCfg(ctypes.Structure):
                 ('sub_sample_size', ctypes.c_int32), ('output_dim', ctypes.c_int32),
                 ('use_point_stn', ctypes.c_int32), ('shared_transformer', ctypes.c_int32),
                 ('weighted_subsample', ctypes.c_int32), ('encoder_bf16', ctypes.c_int32),
-                ('fixed_subsample', ctypes.c_int32), ('reserved', ctypes.c_int32 * 7)]
+                ('fixed_subsample', ctypes.c_int32), ('single_transformer', ctypes.c_int32),
+                ('reserved', ctypes.c_int32 * 6)]
 
 
 def _np(v):
@@ -131,14 +132,15 @@ def build_blob(state_dict, cfg):
     shared = bool(cfg.get('shared_transformer', False))
     if not bool(cfg.get('use_feat_stn', True)):
         raise ValueError('use_feat_stn=0 ablation is not on the accelerated path')
-    if bool(cfg.get('single_transformer', False)):
-        raise ValueError('single_transformer ablation is not on the accelerated path')
+    single = bool(cfg.get('single_transformer', False))
     if cfg.get('sym_op', 'max') != 'max':
         raise ValueError("Unsupported symmetric operation: %s" % cfg.get('sym_op'))
 
     blob = _Blob()
     offs = WeightOffsets()
-    for e, pre in enumerate(('feat_local', 'feat_global')):
+    # single_transformer: ONE encoder over cat(patch, sub-sample); the engine runs it as its usual two branches
+    # (patch points / sub-sample points) with the same weights and takes the max of the two pools
+    for e, pre in enumerate(('feat_local_global', 'feat_local_global') if single else ('feat_local', 'feat_global')):
         o = offs.enc[e]
         o.w0a, o.b0a = _add_plain(blob, w, pre + '.conv0a', pre + '.bn0a')
         o.w0b, o.b0b = _add_gemm(blob, w, pre + '.conv0b', pre + '.bn0b')
@@ -156,15 +158,21 @@ def build_blob(state_dict, cfg):
         q = offs.qstn
         # shared: one QSTN over cat(patch, sub-sample) (model.point_stn); otherwise the QSTN of feat_global, which
         # sees the sub-sample only (reference source/points_to_surf_model.py:267-269, :283-284)
-        s = 'point_stn' if shared else 'feat_global.stn1'
+        s = 'feat_local_global.stn1' if single else ('point_stn' if shared else 'feat_global.stn1')
         q.c1, q.cb1 = _add_plain(blob, w, s + '.conv1', s + '.bn1')
         q.c2, q.cb2 = _add_gemm(blob, w, s + '.conv2', s + '.bn2')
         q.c3, q.cb3 = _add_gemm(blob, w, s + '.conv3', s + '.bn3')
         q.f1, q.fb1 = _add_gemm(blob, w, s + '.fc1', s + '.bn4')
         q.f2, q.fb2 = _add_gemm(blob, w, s + '.fc2', s + '.bn5')
         q.f3, q.fb3 = _add_plain(blob, w, s + '.fc3', None, extra_bias=np.array([1.0, 0, 0, 0]))
-    offs.d1l, offs.db1l = _add_gemm(blob, w, 'fc1_local', 'bn1_local')
-    offs.d1g, offs.db1g = _add_gemm(blob, w, 'fc1_global', 'bn1_global')
+    if single:
+        # fc1_local_global 1024 -> 1024 as two 512-column halves: the decoder's two fc1 GEMMs read the same feature
+        W1, b1 = fold_affine(w, 'fc1_local_global', 'bn1_local_global')
+        offs.d1l, offs.db1l = blob.add(pack_b(W1[:512].T)), blob.add(b1[:512])
+        offs.d1g, offs.db1g = blob.add(pack_b(W1[512:].T)), blob.add(b1[512:])
+    else:
+        offs.d1l, offs.db1l = _add_gemm(blob, w, 'fc1_local', 'bn1_local')
+        offs.d1g, offs.db1g = _add_gemm(blob, w, 'fc1_global', 'bn1_global')
     offs.d2, offs.db2 = _add_gemm(blob, w, 'fc2', 'bn2')
     offs.d3, offs.db3 = _add_gemm(blob, w, 'fc3', 'bn3')
     offs.d4, offs.db4 = _add_plain(blob, w, 'fc4', None)
@@ -178,7 +186,8 @@ def build_blob(state_dict, cfg):
     mc.shared_transformer = int(shared)
     mc.weighted_subsample = int(not bool(cfg.get('uniform_subsample', False)))
     mc.fixed_subsample = int(bool(cfg.get('fixed_subsample', False)))
+    mc.single_transformer = int(single)
     mc.encoder_bf16 = int(cfg.get('encoder_bf16', 0) or 0)      # 0 fp32, 1 bf16, 2 / 3 split bf16 (pieces per operand)
-    if mc.output_dim != 2:
-        raise ValueError('engine supports outputs imp_surf_magnitude + imp_surf_sign (pred_dim 2)')
+    if mc.output_dim not in (1, 2):
+        raise ValueError('engine supports outputs imp_surf (pred_dim 1) or imp_surf_magnitude + imp_surf_sign (pred_dim 2)')
     return blob.finish(), offs, mc

@@ -86,7 +86,7 @@ def test_engine_algebra_matches_oracle(model, fixture_cloud):
 
 def test_unsupported_configs_raise():
     w, cfg = synth.make_weights('p2s_max')
-    for bad in (dict(single_transformer=True), dict(use_feat_stn=False), dict(sym_op='sum'), dict(net_size=512)):
+    for bad in (dict(use_feat_stn=False), dict(sym_op='sum'), dict(net_size=512), dict(output_dim=3)):
         c = dict(cfg)
         c.update(bad)
         with pytest.raises(ValueError):
@@ -107,6 +107,25 @@ def test_qstn_weights_come_from_the_right_module():
         w, cfg = synth.make_weights(name)
         _, _, mc = weights.build_blob(w, cfg)
         assert mc.points_per_patch == k and mc.weighted_subsample == 1
+
+
+def test_regression_and_single_transformer_blobs():
+    """p2s_regression: fc4 has ONE row (output imp_surf); p2s_shared_encoder: both encoder slots hold feat_local_global,
+    the QSTN is its stn1, the decoder's two fc1 blocks are the column halves of fc1_local_global (BN folded)"""
+    w, cfg = synth.make_weights('p2s_regression')
+    blob, offs, mc = weights.build_blob(w, cfg)
+    assert mc.output_dim == 1 and mc.single_transformer == 0
+    assert np.array_equal(blob[offs.d4:offs.d4 + 128], np.asarray(w['fc4.weight'], np.float32).reshape(-1))
+    w, cfg = synth.make_weights('p2s_shared_encoder')
+    blob, offs, mc = weights.build_blob(w, cfg)
+    assert mc.single_transformer == 1 and mc.use_point_stn == 1 and mc.output_dim == 2
+    e0, e1 = offs.enc[0], offs.enc[1]
+    assert np.array_equal(blob[e0.m3:e0.m3 + 128 * 1024], blob[e1.m3:e1.m3 + 128 * 1024])
+    W1, b1 = weights.fold_affine({k: np.asarray(v) for k, v in w.items()}, 'fc1_local_global', 'bn1_local_global')
+    assert np.array_equal(weights.unpack_b(blob[offs.d1g:offs.d1g + 1024 * 512], 1024, 512), W1[512:].T.astype(np.float32))
+    assert np.array_equal(blob[offs.db1l:offs.db1l + 512], b1[:512].astype(np.float32))
+    assert np.allclose(blob[offs.qstn.fb3:offs.qstn.fb3 + 4],
+                       np.asarray(w['feat_local_global.stn1.fc3.bias'], np.float32) + np.array([1, 0, 0, 0], np.float32))
 
 
 def test_model_cfg_carries_the_sub_sample_mode():
