@@ -78,6 +78,12 @@ def test_full_grid256_matches_reference(model):
     _compare(_run_dataset(model, 'testset', 256), g, meta)
 
 
+def test_full_grid512_matches_reference():
+    """BASELINE configs[4] (512^3, overlapped data path): every one of the 757,499 queries of the 512^3 grid, p2s_max"""
+    g, meta = _golden('rec', 'p2s_max', 'testset', 512)
+    _compare(_run_dataset('p2s_max', 'testset', 512), g, meta)
+
+
 @pytest.mark.parametrize('res', [32, 64])
 @pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
 def test_three_clouds_one_stream_matches_reference(model, res):
