@@ -18,7 +18,7 @@
 //
 // Three kernels per chunk of queries:
 //   wc_tables_kernel   one workgroup per query, fully parallel: distances, max, plan-ordered sum, exact prefix sums
-//                      S[q][N] (float64), guide records R[q][K].  HBM-resident (288 GB: ~1.6 MB per query).
+//                      S[q][N] (float64), guide records R[q][K].  HBM-resident (288 GB: ~1.4 MB per query).
 //   wc_offsets_kernel  ONE workgroup walks the queries in order -- the number of random words a query consumes
 //                      depends on its collisions, so the stream position is a true serial dependence -- and computes
 //                      nothing but that: where every query's draws start.
@@ -98,7 +98,7 @@ __device__ __forceinline__ float wc_dist1(const float *__restrict__ pts, int i, 
 // clipped probability -> normalised probability from the L2-resident cloud (a few dozen VALU instructions) instead of
 // round-tripping a per-query float array through HBM, and issues the loads of 4096 points (12 x 16 bytes per
 // thread) before it consumes any: the kernel was bound by the latency of ~800 dependent one-element iterations
-// per thread (6.3 ms per 4096 queries), not by its 1.6 MB of output per query.
+// per thread (6.3 ms per 4096 queries), not by its 1.4 MB of output per query.
 constexpr int WC_BATCH = 4;      // sub-tiles of 1024 points in flight per thread
 __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict__ pts, int n, const float *__restrict__ q,
                                                         WcPlanDev plan, int K,
@@ -1646,7 +1646,7 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     if (rc) return rc;
     int K = 1024;
     while (K < n) K <<= 1;
-    // queries per batch (table memory: ~1.6 MB per query at 50k points); random words come from the raw session
+    // queries per batch (table memory: ~1.4 MB per query at 50k points); random words come from the raw session
     long long per_req = 4096;
     const long long req_env = getenv("P2S_WCHOICE_QUERIES") ? atoll(getenv("P2S_WCHOICE_QUERIES")) : 0;   // tests
     if (req_env > 0) per_req = std::min(per_req, req_env);
