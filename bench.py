@@ -48,7 +48,7 @@ GRID_RES, EPSILON = 256, 3
 SEED_DATA = 40938661
 FIXTURE_SHAPE = '00994122_57d9d4755722f9d2d7436f0a_trimesh_000'
 FIXTURE_CLOUD = os.path.join(REPO, 'tests', 'golden', 'abc_minimal', '04_pts', FIXTURE_SHAPE + '.xyz.npy')
-GOLDEN_256 = os.path.join(REPO, 'tests', 'golden', 'ref_rec_p2s_max_testset_grid256.npz')
+GOLDEN_FMT = os.path.join(REPO, 'tests', 'golden', 'ref_rec_p2s_max_testset_grid%d.npz')      # 128, 256 (default), 512
 
 
 def parse():
@@ -265,11 +265,12 @@ def main():
         sdf_chk, _ = engine.infer_shape(model, cloud, rng_chk, args.res, EPSILON, chunk=args.chunk, want_queries=False)
         sdf_chk = sdf_chk.cpu().numpy()
         tol = 0.25 if args.bf16 == 1 else 1e-4      # north_star: SDF within 1e-4 fp32 of the reference (plain bf16: reported only)
-        if args.points == 0 and args.res == GRID_RES and os.path.isfile(GOLDEN_256):
-            ref = np.load(GOLDEN_256)['rec_0']
+        golden = GOLDEN_FMT % args.res
+        if args.points == 0 and os.path.isfile(golden):
+            ref = np.load(golden)['rec_0']
             ok = ref.shape == sdf_chk.shape
             check['vs_reference_golden'] = {
-                'file': os.path.relpath(GOLDEN_256, REPO), 'queries': int(ref.shape[0]),
+                'file': os.path.relpath(golden, REPO), 'queries': int(ref.shape[0]),
                 'max_abs_dsdf': float(np.abs(ref - sdf_chk).max()) if ok else None,
                 'sign_flips': int((np.sign(ref) != np.sign(sdf_chk)).sum()) if ok else None}
             if not ok or check['vs_reference_golden']['max_abs_dsdf'] > tol or \
