@@ -244,7 +244,7 @@ def main():
             'n_gpus': world if not share else 1, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / max(args.steps, 1) * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': ('bf16' if args.bf16 == 1 else 'bf16x%d' % args.bf16) if args.bf16 else 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE.json configs[2]: p2s_max, grid_res=%d, eps=3, kNN patch=300 / global ' % args.res +
+            'config': {'workload': 'BASELINE.json configs[%d]: p2s_max, grid_res=%d, eps=3, kNN patch=300 / global ' % ({128: 1, 512: 4}.get(args.res, 2), args.res) +
                                    'sub=1000, fp32; %s, one shape per rank per step; seeded random-init weights '
                                    '(Famous set / pretrained weights not available offline)' % workload,
                        'queries_per_shape_rank0': int(sdf.shape[0]),
