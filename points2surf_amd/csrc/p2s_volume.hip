@@ -182,6 +182,8 @@ struct VolState {
     unsigned long long cnt[4][2][NSHARD];   // per sweep (mod 4): [0] zeros of the speculative next state, [1] zeros of `new`
     unsigned long long unknown0[NSHARD];    // zeros of the initial sign field
     int done, final_buf, iters, err;
+    int lcount[3][8];                        // entries of the active-tile list of generation k % 3, per XCD slab
+    unsigned long long tiles_run[NSHARD];   // tiles evaluated over the whole run (P2S_VOLUME_STATS), sharded like the counters
 };
 __device__ __forceinline__ unsigned long long wave_sum64(const unsigned long long *p, int lane) {
     unsigned long long v = p[lane];
@@ -285,6 +287,39 @@ __device__ __forceinline__ void lerp_ge_consts(int c, unsigned &K, unsigned &R) 
     R = c >= 256 ? 0u : 0x01010101u;
 }
 
+// generation 0 of the active-tile lists: every tile, in order
+__global__ void vol_list_init_kernel(int *__restrict__ tlist, VolState *__restrict__ vs, int n_tiles, int slab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_tiles) tlist[(size_t)(i / slab) * slab + i % slab] = i;
+    if (i < 8) vs->lcount[0][i] = min(max(n_tiles - i * slab, 0), slab);
+}
+
+// Tiles a workgroup activated for the next sweep -> the per-XCD lists: one atomicAdd per workgroup and slab touched
+// (an append per tile would put ~3000 atomics per sweep on 8 addresses at 512^3).  All 256 threads call it.
+constexpr int VOL_NEW_CAP = 512;
+__device__ __forceinline__ void vol_list_flush(int *s_new, int *s_new_n, int *lcount_next, int *list_next, int slab, int tid) {
+    const int n = *s_new_n;
+    __syncthreads();
+    for (int b = 0; b < n; b += 256) {
+        const int e = b + tid;
+        const int nt = e < n ? s_new[e] : -1;
+        const int x = nt >= 0 ? nt / slab : -1;
+#pragma unroll 1
+        for (int xv = 0; xv < 8; ++xv) {
+            const unsigned long long mask = __ballot(x == xv);
+            if (mask == 0) continue;                                        // wave-uniform
+            const int lane = tid & 63;
+            int base = 0;
+            if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&lcount_next[xv], __popcll(mask));
+            base = __shfl(base, __ffsll((long long)mask) - 1);
+            if (x == xv) list_next[(size_t)xv * slab + base + __popcll(mask & ((1ull << lane) - 1ull))] = nt;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) *s_new_n = 0;
+    __syncthreads();
+}
+
 // sweep k: buf[k & 1] -> buf[(k + 1) & 1]; taps = the offsets [T_LO, T_HI] of scipy's convolve (compile time: the five
 // sigmas are five kernels; with run-time taps every window step cost ten selects).  PERSISTENT workgroups: <= 4 per
 // CU (LDS), each walks the active tiles of its share; the staging loads of the NEXT tile are in flight while the
@@ -293,8 +328,8 @@ __device__ __forceinline__ void lerp_ge_consts(int c, unsigned &K, unsigned &R) 
 template <int T_LO, int T_HI>
 __global__ __launch_bounds__(256, 4) void vol_sweep_kernel(unsigned char *__restrict__ buf0, unsigned char *__restrict__ buf1,
                                                            int res, int k, float thr,
-                                                           VolState *__restrict__ vs, unsigned char *__restrict__ act,
-                                                           int *__restrict__ tcnt) {
+                                                           VolState *__restrict__ vs, int *__restrict__ act,
+                                                           int *__restrict__ tcnt, int *__restrict__ tlist) {
     static_assert(T_LO >= -2 && T_HI <= 2 && T_LO <= T_HI, "taps");
     constexpr int NT = T_HI - T_LO + 1;
     __shared__ unsigned A[VA_X * VA_Y * VA_ZS];
@@ -303,8 +338,9 @@ __global__ __launch_bounds__(256, 4) void vol_sweep_kernel(unsigned char *__rest
     static_assert(VA_X * VT_Y * VB_ZS <= VA_X * VA_Y * VA_ZS, "C must fit into A");
     __shared__ int red[2][4];
     __shared__ unsigned long long s_dec[3];
-    __shared__ int s_changed[2];
+    __shared__ unsigned s_changed[2];      // 27 bits: which of the 3x3x3 tiles around this one (itself = bit 13) see a change
     __shared__ int s_list[256], s_n, s_done;
+    __shared__ int s_new[VOL_NEW_CAP], s_new_n;      // tiles this workgroup activated for the next sweep (flushed in bulk)
     const int tid = threadIdx.x;
     // XCD-aware tile order: workgroup i runs on XCD i % 8 (own L2).  Every XCD owns one contiguous slab of tiles: the
     // halo re-reads and the two 64-byte halves of every 128-byte line (adjacent z tiles) stay in ONE L2.  Inside the
@@ -319,32 +355,27 @@ __global__ __launch_bounds__(256, 4) void vol_sweep_kernel(unsigned char *__rest
     unsigned char *__restrict__ out = (k & 1) ? buf0 : buf1;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(in), 0, res * res * res, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, res * res * res, 0x00020000);
-    // ---- speculative: the loads of this workgroup's first tile go out before its "active" flag is known (otherwise
-    //      flag -> loads -> sums is three dependent round trips).  If the run is over or the tile is idle they were for
-    //      nothing (both buffers stay valid memory).
+    // ---- wave 0: the reference's loop control (source/sdf.py:156-176) from the finished sweeps' counters, and this
+    //      workgroup's share of the ACTIVE tiles.  A tile must be re-evaluated iff a byte inside its halo'd box changed in
+    //      the previous sweep; every other tile would reproduce its output: it is skipped, its two buffers already agree
+    //      and its zero counts stay in the running totals.  The active tiles of a sweep are a COMPACT list per XCD slab
+    //      (generation k % 3: written by sweep k - 1 through the dedupe flags act[k % 3], read here, recycled by sweep
+    //      k + 1): workgroup w of the slab takes entries w, w + W, w + 2W ... -- equal shares by construction (with one
+    //      flag per tile and static shares the spatially coherent front left most workgroups idle and a few with 8 tiles).
     unsigned w[VS_PER];
-    VolTile cur = vol_tile(first < slab_end ? first : 0, tz_n, ty_n);
-    vol_tile_load(w, rsrc, cur, res, tid);
-    // ---- wave 0: the reference's loop control (source/sdf.py:156-176) from the finished sweeps' counters, and the list
-    //      of this workgroup's ACTIVE tiles.  A tile whose state bytes did not change in a sweep, and whose 26
-    //      neighbours did not either, would reproduce its previous output: it is skipped, its two buffers already agree
-    //      and its zero counts stay in the running totals.  After the first sweeps only the tiles along the advancing
-    //      front remain (sweep k reads act[k % 3], sets act[(k + 1) % 3], clears act[(k + 2) % 3]).
+    VolTile cur;
+    const int gen = k % 3, gen_next = (k + 1) % 3, gen_free = (k + 2) % 3;
+    const int *__restrict__ my_list = tlist + ((size_t)gen * 8 + xcd) * slab;
     if (tid < 64) {
         const int done = vs->done;
+        const int cnt = vs->lcount[gen][xcd];
         const unsigned long long before = (k <= 1) ? wave_sum64(vs->unknown0, tid) : wave_sum64(vs->cnt[(k - 2) & 3][0], tid);
         const unsigned long long zn = k >= 1 ? wave_sum64(vs->cnt[(k - 1) & 3][1], tid) : 0ull;
         const unsigned long long zx = k >= 1 ? wave_sum64(vs->cnt[(k - 1) & 3][0], tid) : 0ull;
-        int n = 0;
-        for (int m0 = 0; first + m0 * wgs < slab_end; m0 += 64) {
-            const int tile = first + (m0 + tid) * wgs;
-            const bool mine = tile < slab_end;
-            const bool on = mine && act[(k % 3) * n_tiles + tile] != 0;
-            if (mine) act[((k + 2) % 3) * n_tiles + tile] = 0;
-            const unsigned long long mask = __ballot(on);
-            if (on) s_list[n + __popcll(mask & ((1ull << tid) - 1ull))] = tile;
-            n += __popcll(mask);
-        }
+        const int n = wl < cnt ? (cnt - wl + wgs - 1) / wgs : 0;          // <= 256 (host check)
+        for (int m = tid; m < n; m += 64) s_list[m] = my_list[wl + m * wgs];
+        // the dedupe flags of generation k + 2 (last used by sweep k - 1's appends): this workgroup's static share
+        for (int tile = first + tid * wgs; tile < slab_end; tile += 64 * wgs) act[(size_t)gen_free * n_tiles + tile] = 0;
         if (tid == 0) {
             s_dec[0] = before;
             s_dec[1] = zn;
@@ -352,6 +383,7 @@ __global__ __launch_bounds__(256, 4) void vol_sweep_kernel(unsigned char *__rest
             s_n = n;
             s_done = done;
             s_changed[0] = s_changed[1] = 0;
+            s_new_n = 0;
         }
     }
     __syncthreads();
@@ -384,6 +416,7 @@ __global__ __launch_bounds__(256, 4) void vol_sweep_kernel(unsigned char *__rest
         }
         if (wg == 0 && tid < 2 * NSHARD)      // counters of the next sweep (nobody reads or adds to them now)
             vs->cnt[(k + 1) & 3][tid >> 6][tid & (NSHARD - 1)] = 0;
+        if (wg == 0 && tid < 8) vs->lcount[gen_free][tid] = 0;      // the list sweep k + 1 will append to
         if (wg == 0 && tid == 0 && k >= 1) {  // running totals: this sweep's = the previous sweep's + the deltas of the active tiles
             atomicAdd(&vs->cnt[k & 3][0][0], s_dec[2]);
             atomicAdd(&vs->cnt[k & 3][1][0], s_dec[1]);
@@ -391,10 +424,9 @@ __global__ __launch_bounds__(256, 4) void vol_sweep_kernel(unsigned char *__rest
     }
     const int n_act = s_n;
     if (n_act == 0) return;
-    if (s_list[0] != cur.tile) {              // the first tile is idle: fetch the first active one
-        cur = vol_tile(s_list[0], tz_n, ty_n);
-        vol_tile_load(w, rsrc, cur, res, tid);
-    }
+    if (tid == 0) atomicAdd(&vs->tiles_run[wg & (NSHARD - 1)], (unsigned long long)n_act);
+    cur = vol_tile(s_list[0], tz_n, ty_n);
+    vol_tile_load(w, rsrc, cur, res, tid);
     // All sums are kept BIASED: sign + 1 in {0, 1, 2} per byte, so the z / zy / zyx sums are <= 10 / 50 / 250 -- plain
     // 32-bit adds and subtracts never carry between bytes, and the y and x passes slide their window
     // (out[y] = out[y-1] + entering - leaving).
@@ -410,6 +442,8 @@ __global__ __launch_bounds__(256, 4) void vol_sweep_kernel(unsigned char *__rest
         const VolTile t = cur;
         vol_tile_stage(w, A, t, res, tid);    // registers -> LDS, z faces replicated
         __syncthreads();
+        if (s_new_n > VOL_NEW_CAP - 27)       // stable here (appends happen behind the barrier at the end of a tile): uniform
+            vol_list_flush(s_new, &s_new_n, vs->lcount[gen_next], tlist + (size_t)gen_next * 8 * slab, slab, tid);
         if (tid == 0) s_changed[(i + 1) & 1] = 0;
         if (i + 1 < n_act) {                  // next tile: loads in flight during the three passes below
             cur = vol_tile(s_list[i + 1], tz_n, ty_n);
@@ -455,7 +489,7 @@ __global__ __launch_bounds__(256, 4) void vol_sweep_kernel(unsigned char *__rest
         __syncthreads();
         // ---- x sums, threshold, speculative update, counts
         int known_new = 0, known_next = 0;
-        unsigned diff = 0;
+        unsigned d_all = 0, d_xlo = 0, d_xhi = 0;        // changed state bits: anywhere / within VT_H of the -x / +x face
         const int gy = t.y0 + ty, gz = t.z0 + 4 * tzd;
         const bool inside = gy < res && gz < res;         // x: res is a multiple of 16 >= VT_X
         {
@@ -481,7 +515,9 @@ __global__ __launch_bounds__(256, 4) void vol_sweep_kernel(unsigned char *__rest
                     const unsigned o = (raw & ~m3) | (code & m3);                       // v_bfi
                     known_new += __popc(PN);
                     known_next += __popc((o | (o >> 1)) & 0x01010101u);
-                    diff |= o ^ raw;
+                    d_all |= o ^ raw;
+                    if (x < VT_H) d_xlo |= o ^ raw;
+                    if (x >= VT_X - VT_H) d_xhi |= o ^ raw;
                     __builtin_amdgcn_raw_buffer_store_b32(o, rsrc_out, voff, (t.x0 + x) * res * res, 0);
                 }
             }
@@ -495,7 +531,24 @@ __global__ __launch_bounds__(256, 4) void vol_sweep_kernel(unsigned char *__rest
             red[0][tid >> 6] = z_next;
             red[1][tid >> 6] = z_new;
         }
-        if (diff) s_changed[i & 1] = 1;
+        // ---- who has to run in the next sweep.  A tile must be re-evaluated iff a byte inside its halo'd box changed:
+        //      this tile if anything changed here, the neighbour in direction (dx, dy, dz) only if something changed
+        //      within VT_H voxels of the face / edge / corner it touches (a flag per whole tile kept ~2/3 of the volume
+        //      active while the front passed: the 27-neighbourhood of an 8 x 16 x 64 tile spans 24 x 48 x 192 voxels).
+        //      Bit (dz+1) + 3 (dy+1) + 9 (dx+1).  The z band is the first / last two BYTES of the row's first / last dword.
+        {
+            const unsigned z_lo = tzd == 0 ? 0x0000ffffu : 0u, z_hi = tzd == VT_Z / 4 - 1 ? 0xffff0000u : 0u;
+            const unsigned py = (ty < VT_H ? 1u : 0u) | 8u | (ty >= VT_Y - VT_H ? 64u : 0u);      // dy = -1 / 0 / +1 at bits 0 / 3 / 6
+            unsigned m = 0;
+            if (d_all) {
+                const unsigned mz_lo = ((d_xlo & z_lo) ? 1u : 0u) | (d_xlo ? 2u : 0u) | ((d_xlo & z_hi) ? 4u : 0u);
+                const unsigned mz_al = ((d_all & z_lo) ? 1u : 0u) | 2u | ((d_all & z_hi) ? 4u : 0u);
+                const unsigned mz_hi = ((d_xhi & z_lo) ? 1u : 0u) | (d_xhi ? 2u : 0u) | ((d_xhi & z_hi) ? 4u : 0u);
+                m = (py * mz_lo) | ((py * mz_al) << 9) | ((py * mz_hi) << 18);                     // 3-bit slots: no carries
+            }
+            for (int d = 32; d > 0; d >>= 1) m |= __shfl_xor(m, d);
+            if ((tid & 63) == 0 && m) atomicOr(&s_changed[i & 1], m);
+        }
         __syncthreads();                      // also: every read of C (= A) is done before the next tile is staged
         if (tid == 0) {
             // delta against this tile's counts of its previous evaluation
@@ -505,12 +558,17 @@ __global__ __launch_bounds__(256, 4) void vol_sweep_kernel(unsigned char *__rest
             tcnt[2 * t.tile] = a;
             tcnt[2 * t.tile + 1] = b;
         }
-        if (s_changed[i & 1] && tid < 27) {   // the state changed here: this tile and its neighbours run in the next sweep
+        if (tid < 27 && ((s_changed[i & 1] >> tid) & 1u)) {
             const int nz = t.tz_i + tid % 3 - 1, ny = t.ty_i + (tid / 3) % 3 - 1, nx = t.tx_i + tid / 9 - 1;
-            if (nz >= 0 && nz < tz_n && ny >= 0 && ny < ty_n && nx >= 0 && nx < tx_n)
-                act[((k + 1) % 3) * n_tiles + (nx * ty_n + ny) * tz_n + nz] = 1;
+            if (nz >= 0 && nz < tz_n && ny >= 0 && ny < ty_n && nx >= 0 && nx < tx_n) {
+                const int nt = (nx * ty_n + ny) * tz_n + nz;
+                // first to flag it for the next sweep -> it goes onto the list (exactly once)
+                if (atomicExch(&act[(size_t)gen_next * n_tiles + nt], 1) == 0) s_new[atomicAdd(&s_new_n, 1)] = nt;
+            }
         }
     }
+    __syncthreads();
+    vol_list_flush(s_new, &s_new_n, vs->lcount[gen_next], tlist + (size_t)gen_next * 8 * slab, slab, tid);
     if (tid == 0) {                           // 64-bit wrap-around = signed add
         if (sum_da) atomicAdd(&vs->cnt[k & 3][0][wg & (NSHARD - 1)], (unsigned long long)sum_da);
         if (sum_db) atomicAdd(&vs->cnt[k & 3][1][wg & (NSHARD - 1)], (unsigned long long)sum_db);
@@ -604,12 +662,14 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
         const dim3 tg((unsigned)std::min(slab_tiles * 8, wgs_max));
         // per tile: counts of its last evaluation (2 ints) and three generations of "active" flags
         int *tcnt = (int *)(vs + 1);
-        unsigned char *act = (unsigned char *)(tcnt + 2 * (size_t)n_tiles);
-        if (hipMemsetAsync(tcnt, 0, (size_t)n_tiles * 8, s) != hipSuccess || hipMemsetAsync(act, 1, (size_t)n_tiles, s) != hipSuccess ||
-            hipMemsetAsync(act + n_tiles, 0, (size_t)n_tiles * 2, s) != hipSuccess) {
+        int *act = tcnt + 2 * (size_t)n_tiles;                    // [3][n_tiles] dedupe flags of the list appends
+        int *tlist = act + 3 * (size_t)n_tiles;                   // [3][8][slab] active tiles per generation and XCD slab
+        const int slab_n = (n_tiles + 7) / 8;
+        if (hipMemsetAsync(tcnt, 0, (size_t)n_tiles * (8 + 12), s) != hipSuccess) {
             p2s_set_error("p2s_sdf_volume: memset failed");
             return cleanup(P2S_EHIP);
         }
+        hipLaunchKernelGGL(vol_list_init_kernel, dim3((unsigned)((std::max(n_tiles, 8) + 255) / 256)), dim3(256), 0, s, tlist, vs, n_tiles, slab_n);
         // the number of sweeps is data dependent (the front advances ~2 voxels per sweep): batches without a host
         // round trip; launches behind the final sweep exit at once
         const int batch = getenv("P2S_VOLUME_BATCH") ? std::max(1, atoi(getenv("P2S_VOLUME_BATCH"))) : 16;
@@ -633,7 +693,7 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
         bool flag_checked = false;
         for (int j = 0; k < k_max; ++j) {
             for (int t = 0; t < batch; ++t, ++k) {
-                auto go = [&](auto kern) { hipLaunchKernelGGL(kern, tg, dim3(256), 0, s, buf0, buf1, grid_res, k, certainty_threshold, vs, act, tcnt); };
+                auto go = [&](auto kern) { hipLaunchKernelGGL(kern, tg, dim3(256), 0, s, buf0, buf1, grid_res, k, certainty_threshold, vs, act, tcnt, tlist); };
                 switch (sigma) {              // offsets sigma / 2 - j of scipy's convolve (origin 0)
                 case 1: go(vol_sweep_kernel<0, 0>); break;
                 case 2: go(vol_sweep_kernel<0, 1>); break;
@@ -682,6 +742,15 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
             return cleanup(P2S_EHIP);
         }
         iters = host_vs.iters;
+        if (getenv("P2S_VOLUME_STATS")) {
+            VolState fin;
+            if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(&fin, vs, sizeof(VolState), hipMemcpyDeviceToHost) == hipSuccess) {
+                unsigned long long run = 0;
+                for (int i = 0; i < NSHARD; ++i) run += fin.tiles_run[i];
+                fprintf(stderr, "[volume stats] res %d: %d sweeps, %llu tile evaluations = %.1f %% of %d tiles x sweeps\n", grid_res, iters,
+                        run, 100.0 * (double)run / ((double)n_tiles * std::max(iters, 1)), n_tiles);
+            }
+        }
         hipLaunchKernelGGL(vol_compose_state_kernel, dim3(grid), dim3(256), 0, s, vol_out_dev, buf0, buf1, vs, grid_res, clamp);
         P2S_LAUNCH_CHECK("vol_compose_state_kernel");
         if (iterations) *iterations = iters;

@@ -44,3 +44,33 @@ def test_sweep_kernel_byte_compare_and_staging_math():
     want = np.zeros_like(seen).reshape(VA_X * VA_Y, VA_ZS)
     want[:, :VA_ZD] = 1
     assert np.array_equal(seen, want.reshape(-1)) and ROWS * VA_ZD <= 256
+
+
+def test_activation_mask_of_a_changed_voxel():
+    """which of the 27 tiles around a tile must run in the next sweep when ONE voxel (x, y, z) of it changed: those whose
+    halo'd box (halo 2) contains the voxel.  Model of the kernel's bit arithmetic (py * mz products, 3-bit slots):
+    bit (dz+1) + 3 (dy+1) + 9 (dx+1)."""
+    VT_X, VT_Y, VT_Z, H = 8, 16, 64, 2
+    for x in range(VT_X):
+        for y in range(VT_Y):
+            for z in range(VT_Z):
+                tzd, byte = z // 4, z % 4
+                diff = 0xff << (8 * byte)                                    # the changed byte of this thread's dword
+                d_all = diff
+                d_xlo = diff if x < H else 0
+                d_xhi = diff if x >= VT_X - H else 0
+                z_lo = 0x0000ffff if tzd == 0 else 0
+                z_hi = 0xffff0000 if tzd == VT_Z // 4 - 1 else 0
+                py = (1 if y < H else 0) | 8 | (64 if y >= VT_Y - H else 0)
+                mz = lambda d: (1 if d & z_lo else 0) | (2 if d else 0) | (4 if d & z_hi else 0)
+                m = (py * mz(d_xlo)) | ((py * mz(d_all)) << 9) | ((py * mz(d_xhi)) << 18)
+                want = 0
+                for dx in (-1, 0, 1):
+                    for dy in (-1, 0, 1):
+                        for dz in (-1, 0, 1):
+                            okx = dx == 0 or (dx < 0 and x < H) or (dx > 0 and x >= VT_X - H)
+                            oky = dy == 0 or (dy < 0 and y < H) or (dy > 0 and y >= VT_Y - H)
+                            okz = dz == 0 or (dz < 0 and z < H) or (dz > 0 and z >= VT_Z - H)
+                            if okx and oky and okz:
+                                want |= 1 << ((dz + 1) + 3 * (dy + 1) + 9 * (dx + 1))
+                assert m == want, (x, y, z, bin(m), bin(want))
