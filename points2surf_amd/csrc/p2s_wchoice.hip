@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
     // lane); the distances of the next tile are in flight while this one is scanned
     const double dK = (double)K;
     double carry = 0.0;
+    __shared__ double red_p4[2][4];
     float dn[5];
     wc_dist4(pts, n, 4 * tid, qx, qy, qz, (float(&)[4])dn);
     dn[4] = 4 * tid + 4 < n ? wc_dist1(pts, 4 * tid + 4, qx, qy, qz) : 0.0f;
@@ -263,13 +264,14 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
             const double u = __shfl_up(v, off);
             if (lane >= off) v += u;
         }
-        if (lane == 63) red_d[wave] = v;
+        double *rd = red_p4[(t0 >> 10) & 1];          // alternating buffers: ONE barrier per tile
+        if (lane == 63) rd[wave] = v;
         __syncthreads();
         double base = carry, total = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            if (w < wave) base += red_d[w];
-            total += red_d[w];
+            if (w < wave) base += rd[w];
+            total += rd[w];
         }
         const double excl = base + (v - l4);          // S_{i0-1}
         const double sv[6] = {excl, excl + l1, excl + l2, excl + l3, excl + l4, (excl + l4) + p[4]};
@@ -299,7 +301,6 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
             }
         }
         carry += total;
-        __syncthreads();
     }
     if (tid == 0) stot_all[qi] = Stot;
 }
