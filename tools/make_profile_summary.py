@@ -72,6 +72,20 @@ if bf:
         'write_bytes_per_launch': bf['WRITE_SIZE']['avg_per_dispatch'] * 1024 if 'WRITE_SIZE' in bf else None,
         'lds_bank_conflict_cycles': bf['SQ_LDS_BANK_CONFLICT']['avg_per_dispatch'] if 'SQ_LDS_BANK_CONFLICT' in bf else None,
         'wait_inst_any_frac_of_wave_cycles': None}
+b1 = raw.get('p2s_chain_bf16_kernel<1>')
+if b1:
+    dur1 = [r[-1] for r in rows if r[1] == 'chain_bf16_kernel<1>' and r[9] == 'GRBM_GUI_ACTIVE']
+    cyc1 = b1['GRBM_GUI_ACTIVE']['avg_per_dispatch'] / 8
+    summ['chain_bf16_kernel'] = {
+        'workload': 'tools/quick_bench.py --B 4096 --iters 1 --bf16 1 (plain bf16: outside the 1e-4 contract)',
+        'queries_per_launch': 4096, 'avg_duration_ms_under_pmc': sum(dur1) / len(dur1) / 1e6,
+        'cycles_per_launch': cyc1, 'clock_GHz': cyc1 / (sum(dur1) / len(dur1)),
+        'mfma_busy_frac': b1['SQ_VALU_MFMA_BUSY_CYCLES']['avg_per_dispatch'] / (1024 * cyc1),
+        'executed_mfma_bf16_flop_per_launch': b1['SQ_INSTS_VALU_MFMA_MOPS_BF16']['avg_per_dispatch'] * 512,
+        'fetch_bytes_per_launch_corrected_x2': b1['FETCH_SIZE']['avg_per_dispatch'] * 1024 * 2,
+        'write_bytes_per_launch': b1['WRITE_SIZE']['avg_per_dispatch'] * 1024,
+        'lds_bank_conflict_cycles': b1['SQ_LDS_BANK_CONFLICT']['avg_per_dispatch']}
 json.dump(summ, open(os.path.join(out, 'pmc_summary.json'), 'w'), indent=1)
 print(json.dumps(summ['chain_kernel'], indent=1))
 print(json.dumps(summ.get('chain_bf16x3_kernel'), indent=1))
+print(json.dumps(summ.get('chain_bf16_kernel'), indent=1))
