@@ -89,6 +89,30 @@ __device__ __forceinline__ void wc_dist4(const float *__restrict__ pts, int n, i
         d[j] = sqrtf((dx * dx + dy * dy) + dz * dz);
     }
 }
+// squared distances of 4 consecutive points (pass 1: max d = sqrtf(max d^2) -- sqrtf is monotone and correctly rounded, so
+// the square root is taken once per query instead of once per point)
+__device__ __forceinline__ void wc_dist4_sq(const float *__restrict__ pts, int n, int i0, float qx, float qy, float qz, float (&d2)[4]) {
+    float c[12];
+    if (i0 + 4 <= n) {
+        const float4 a = *(const float4 *)(pts + 3 * (size_t)i0), b = *(const float4 *)(pts + 3 * (size_t)i0 + 4),
+                     e = *(const float4 *)(pts + 3 * (size_t)i0 + 8);
+        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+        c[8] = e.x; c[9] = e.y; c[10] = e.z; c[11] = e.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = i0 + j < n;
+            c[3 * j] = in ? pts[3 * (size_t)(i0 + j)] : qx;
+            c[3 * j + 1] = in ? pts[3 * (size_t)(i0 + j) + 1] : qy;
+            c[3 * j + 2] = in ? pts[3 * (size_t)(i0 + j) + 2] : qz;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float dx = qx - c[3 * j], dy = qy - c[3 * j + 1], dz = qz - c[3 * j + 2];
+        d2[j] = (dx * dx + dy * dy) + dz * dz;
+    }
+}
 __device__ __forceinline__ float wc_dist1(const float *__restrict__ pts, int i, float qx, float qy, float qz) {
     const float dx = qx - pts[3 * (size_t)i], dy = qy - pts[3 * (size_t)i + 1], dz = qz - pts[3 * (size_t)i + 2];
     return sqrtf((dx * dx + dy * dy) + dz * dz);
@@ -116,12 +140,12 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
     WcRec *R = R_all + (size_t)qi * K;
     const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
 
-    // pass 1: max distance
+    // pass 1: max distance, through the squares
     float mx = 0.0f;
     for (int t0 = 0; t0 < n; t0 += 1024 * WC_BATCH) {
         float d[WC_BATCH][4];
 #pragma unroll
-        for (int u = 0; u < WC_BATCH; ++u) wc_dist4(pts, n, t0 + 1024 * u + 4 * tid, qx, qy, qz, d[u]);
+        for (int u = 0; u < WC_BATCH; ++u) wc_dist4_sq(pts, n, t0 + 1024 * u + 4 * tid, qx, qy, qz, d[u]);
 #pragma unroll
         for (int u = 0; u < WC_BATCH; ++u)
 #pragma unroll
@@ -131,7 +155,7 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     if (lane == 0) red_f[wave] = mx;
     __syncthreads();
-    const float dmax = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    const float dmax = sqrtf(fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3])));
     if (!(dmax > 0.0f) || !(dmax < 3.0e38f)) {       // numpy would raise (NaN probabilities); flag and bail out
         if (tid == 0) err[1] = 1;
         return;
