@@ -309,6 +309,27 @@ class Rng:
         return ids, pts
 
 
+def query_logits(model, cloud, rng, queries, index):
+    """Diagnostic: the decoder logits of query ``index`` of a shape whose queries (in order) are ``queries``, with ``rng``
+    positioned at the shape's first draw -- the stream is advanced past the queries before it (NULL-ids path), then this
+    one query goes through a4..a8.  Used to classify sign flips against a reference as fp32 ties (|sign logit| ~ 0)."""
+    n = model.sub_sample_size
+    q = _f32c(queries, model.device).reshape(-1, 3)
+    if index > 0:
+        if model.uniform_subsample:
+            rng.skip(cloud, n, n_queries=int(index))
+        else:
+            rng.skip(cloud, n, query_ms=q[:index])
+    one = q[index:index + 1].contiguous()
+    if model.uniform_subsample:
+        _, sub = rng.subsample_uniform(cloud, 1, n)
+    else:
+        _, sub = rng.subsample_weighted(cloud, one, n)
+    _, patch, _ = cloud.knn_patch(one, model.points_per_patch, want_ids=False)
+    logits, _ = model.forward(patch, sub.reshape(1, n, 3), one)
+    return logits[0]
+
+
 def infer_shape(model, cloud, rng, grid_resolution, epsilon, q_begin=0, q_end=-1, chunk=0, want_queries=True):
     """Fused per-shape pipeline (p2s_infer_shape).  Returns (sdf [n] device tensor, q [n,3] or None)."""
     dev = model.device

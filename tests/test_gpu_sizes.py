@@ -51,17 +51,25 @@ def _run_dataset(model_name, dataset, res):
     return out
 
 
-def _compare(out, g, meta, tol=1e-4):
-    worst, flips, total = 0.0, 0, 0
+def _compare(out, g, meta, tol=1e-4, ties_ok=False):
+    """max |dSDF| and sign flips against the reference.  ``ties_ok``: returns the flipped (shape, query) pairs instead of
+    failing on them (the caller proves that each one is an fp32 tie); their magnitudes still have to agree"""
+    worst, total, flipped = 0.0, 0, []
     for i, (sdf, q) in enumerate(out):
         ref = g['rec_%d' % i]
         assert sdf.shape == ref.shape, (sdf.shape, ref.shape)
         assert hashlib.sha256(np.ascontiguousarray(q).tobytes()).hexdigest() == meta['shapes'][i]['query_sha256']
-        worst = max(worst, float(np.abs(sdf - ref).max()))
-        flips += int((np.sign(sdf) != np.sign(ref)).sum())
+        fl = np.nonzero(np.sign(sdf) != np.sign(ref))[0]
+        flipped += [(i, int(j)) for j in fl]
+        d = np.abs(sdf - ref)
+        d[fl] = np.abs(np.abs(sdf[fl]) - np.abs(ref[fl]))
+        worst = max(worst, float(d.max()))
         total += sdf.size
-    print('max|dSDF| %.3g, sign flips %d / %d queries' % (worst, flips, total))
-    assert worst < tol and flips == 0, (worst, flips)
+    print('max|dSDF| %.3g (magnitudes at flipped signs), sign flips %d / %d queries' % (worst, len(flipped), total))
+    assert worst < tol, worst
+    if not ties_ok:
+        assert not flipped, flipped
+    return flipped
 
 
 @pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
@@ -79,9 +87,26 @@ def test_full_grid256_matches_reference(model):
 
 
 def test_full_grid512_matches_reference():
-    """BASELINE configs[4] (512^3, overlapped data path): every one of the 757,499 queries of the 512^3 grid, p2s_max"""
+    """BASELINE configs[4] (512^3, overlapped data path): every one of the 757,499 queries of the 512^3 grid, p2s_max.
+    The sign is ``sign logit >= 0`` (sdf_nn.py:16-21): among 757k queries a few have a sign logit within fp32 noise of
+    zero (2 here, |logit| < 6e-6 with a logit accuracy of ~1.5e-5) -- the reference's own answer for them depends on
+    its batch composition and thread count (the golden run says +, the same ATen ops on the same inputs in another batch
+    say -5.0e-6: oracle/torch_port.py).  Such TIES are tolerated, if and only if the device's own sign logit is that
+    close to zero; every other query must agree in sign, and all magnitudes within 1e-4."""
+    import torch
+    from points2surf_amd import engine, synth
     g, meta = _golden('rec', 'p2s_max', 'testset', 512)
-    _compare(_run_dataset('p2s_max', 'testset', 512), g, meta)
+    out = _run_dataset('p2s_max', 'testset', 512)
+    flipped = _compare(out, g, meta, ties_ok=True)
+    assert len(flipped) <= 8, flipped                      # ~1e-5 of the queries
+    if flipped:
+        w, cfg = synth.make_weights('p2s_max')
+        model = engine.Model(w, cfg)
+        cloud = engine.Cloud(np.load(os.path.join(FIX, '04_pts', _names('testset')[0] + '.xyz.npy')))
+        for _, j in flipped:
+            lg = engine.query_logits(model, cloud, engine.Rng(SEED), torch.from_numpy(out[0][1]).cuda(), j).cpu().numpy()
+            print('query %d: logits %s, device sdf %.6g, reference %.6g' % (j, lg, out[0][0][j], g['rec_0'][j]))
+            assert abs(float(lg[1])) < 5e-5, (j, lg)
 
 
 @pytest.mark.parametrize('res', [32, 64])
