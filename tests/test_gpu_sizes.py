@@ -86,8 +86,9 @@ def test_full_grid256_matches_reference(model):
     _compare(_run_dataset(model, 'testset', 256), g, meta)
 
 
-def test_full_grid512_matches_reference():
-    """BASELINE configs[4] (512^3, overlapped data path): every one of the 757,499 queries of the 512^3 grid, p2s_max.
+@pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
+def test_full_grid512_matches_reference(model):
+    """BASELINE configs[4] (512^3, overlapped data path): every one of the 757,499 queries of the 512^3 grid.
     The sign is ``sign logit >= 0`` (sdf_nn.py:16-21): among 757k queries a few have a sign logit within fp32 noise of
     zero (2 here, |logit| < 6e-6 with a logit accuracy of ~1.5e-5) -- the reference's own answer for them depends on
     its batch composition and thread count (the golden run says +, the same ATen ops on the same inputs in another batch
@@ -95,12 +96,12 @@ def test_full_grid512_matches_reference():
     close to zero; every other query must agree in sign, and all magnitudes within 1e-4."""
     import torch
     from points2surf_amd import engine, synth
-    g, meta = _golden('rec', 'p2s_max', 'testset', 512)
-    out = _run_dataset('p2s_max', 'testset', 512)
+    g, meta = _golden('rec', model, 'testset', 512)
+    out = _run_dataset(model, 'testset', 512)
     flipped = _compare(out, g, meta, ties_ok=True)
     assert len(flipped) <= 8, flipped                      # ~1e-5 of the queries
     if flipped:
-        w, cfg = synth.make_weights('p2s_max')
+        w, cfg = synth.make_weights(model)
         model = engine.Model(w, cfg)
         cloud = engine.Cloud(np.load(os.path.join(FIX, '04_pts', _names('testset')[0] + '.xyz.npy')))
         for _, j in flipped:
