@@ -121,7 +121,7 @@ def main():
         respawn(args)
     import torch
     import torch.distributed as dist
-    from points2surf_amd import engine, synth, sharding
+    from points2surf_amd import engine, parity, synth, sharding
 
     world, rank, local_rank = sharding.dist_env()
     if args.gpus != world:
@@ -271,17 +271,16 @@ def main():
             ok = ref.shape == sdf_chk.shape
             rec = {'file': os.path.relpath(golden, REPO), 'queries': int(ref.shape[0])}
             if ok:
-                fl = np.nonzero(np.sign(ref) != np.sign(sdf_chk))[0]
-                d = np.abs(ref - sdf_chk)
-                d[fl] = np.abs(np.abs(ref[fl]) - np.abs(sdf_chk[fl]))           # flipped signs: compare the magnitudes
-                rec.update({'max_abs_dsdf': float(d.max()), 'sign_flips': int(fl.size)})
+                cmp_ = parity.compare_sdf(sdf_chk, ref)
+                fl = cmp_['flipped']
+                rec.update({'max_abs_dsdf': cmp_['max_abs_dsdf'], 'sign_flips': int(fl.size)})
                 if 0 < fl.size <= 8 and not args.bf16:
                     # sign = (sign logit >= 0): a flip is an fp32 TIE iff the device's own sign logit is within the logit
                     # accuracy of zero (the reference's answer for such a query depends on its batch composition / threads)
                     q_all = cloud.query_grid(args.res, EPSILON)
                     lg = [float(engine.query_logits(model, cloud, engine.Rng(SEED_DATA), q_all, int(j))[1]) for j in fl]
                     rec['flipped_sign_logits'] = lg
-                    rec['sign_flips_not_ties'] = int(sum(abs(x) >= 5e-5 for x in lg))
+                    rec['sign_flips_not_ties'] = parity.not_ties(lg)
                 else:
                     rec['sign_flips_not_ties'] = int(fl.size)
             check['vs_reference_golden'] = rec

@@ -10,6 +10,8 @@ import os
 import numpy as np
 import pytest
 
+from points2surf_amd import parity
+
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -59,11 +61,9 @@ def _compare(out, g, meta, tol=1e-4, ties_ok=False):
         ref = g['rec_%d' % i]
         assert sdf.shape == ref.shape, (sdf.shape, ref.shape)
         assert hashlib.sha256(np.ascontiguousarray(q).tobytes()).hexdigest() == meta['shapes'][i]['query_sha256']
-        fl = np.nonzero(np.sign(sdf) != np.sign(ref))[0]
-        flipped += [(i, int(j)) for j in fl]
-        d = np.abs(sdf - ref)
-        d[fl] = np.abs(np.abs(sdf[fl]) - np.abs(ref[fl]))
-        worst = max(worst, float(d.max()))
+        c = parity.compare_sdf(sdf, ref)
+        flipped += [(i, int(j)) for j in c['flipped']]
+        worst = max(worst, c['max_abs_dsdf'])
         total += sdf.size
     print('max|dSDF| %.3g (magnitudes at flipped signs), sign flips %d / %d queries' % (worst, len(flipped), total))
     assert worst < tol, worst
@@ -107,7 +107,7 @@ def test_full_grid512_matches_reference(model):
         for _, j in flipped:
             lg = engine.query_logits(model, cloud, engine.Rng(SEED), torch.from_numpy(out[0][1]).cuda(), j).cpu().numpy()
             print('query %d: logits %s, device sdf %.6g, reference %.6g' % (j, lg, out[0][0][j], g['rec_0'][j]))
-            assert abs(float(lg[1])) < 5e-5, (j, lg)
+            assert parity.not_ties([lg[1]]) == 0, (j, lg)
 
 
 @pytest.mark.parametrize('res', [32, 64])

@@ -1,0 +1,22 @@
+"""points2surf_amd.parity: magnitude comparison at flipped signs, tie threshold (no GPU)."""
+import numpy as np
+import pytest
+
+from points2surf_amd import parity
+
+
+def test_compare_sdf_reports_flips_and_compares_their_magnitudes():
+    ref = np.array([0.5, -0.25, 0.06695648, -0.01, 0.0], np.float32)
+    sdf = np.array([0.5 + 1e-6, -0.25, -0.06695664, -0.01 - 2e-6, 0.0], np.float32)
+    c = parity.compare_sdf(sdf, ref)
+    assert list(c['flipped']) == [2]
+    assert c['max_abs_dsdf'] < 3e-6                       # the flipped query counts with | |sdf| - |ref| |, not 0.13
+    assert parity.compare_sdf(ref, ref)['flipped'].size == 0
+    with pytest.raises(ValueError):
+        parity.compare_sdf(sdf[:3], ref)
+
+
+def test_tie_threshold():
+    assert parity.not_ties([-4.0e-6, -2.2e-6]) == 0       # the two ties of the 512^3 grid
+    assert parity.not_ties([6e-5, -1e-6, -3e-3]) == 2
+    assert parity.not_ties([]) == 0
