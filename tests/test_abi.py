@@ -73,3 +73,18 @@ def test_integration_stub_uses_only_declared_entry_points():
                                           'p2s_vanilla_uniform_subsample', 'p2s_'}   # + non-symbols (model names)
     unknown = {u for u in used if u not in declared and not u.endswith('_t')}
     assert not unknown, unknown
+
+
+def test_every_environment_switch_is_documented():
+    """each P2S_* variable the library, the Python package or bench.py reads appears in INTEGRATION.md"""
+    import glob
+    names = set()
+    files = glob.glob(os.path.join(REPO, 'points2surf_amd', 'csrc', '*')) + glob.glob(os.path.join(REPO, 'points2surf_amd', '*.py')) + \
+        glob.glob(os.path.join(REPO, 'points2surf_amd', 'dropin', '**', '*.py'), recursive=True) + [os.path.join(REPO, 'bench.py')]
+    for f in files:
+        t = open(f).read()
+        names |= set(re.findall(r'getenv\("(P2S_[A-Z0-9_]+)"\)', t))
+        names |= set(re.findall(r"environ(?:\.get)?\(?\[?'(P2S_[A-Z0-9_]+)'", t))
+    doc = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert len(names) > 20 and not missing, missing
