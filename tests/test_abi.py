@@ -88,3 +88,14 @@ def test_every_environment_switch_is_documented():
     doc = open(os.path.join(REPO, 'INTEGRATION.md')).read()
     missing = sorted(n for n in names if n not in doc)
     assert len(names) > 20 and not missing, missing
+
+
+def test_kernels_named_in_the_docs_exist():
+    """every `..._kernel` DESIGN.md / profiles/README.md name is a kernel of points2surf_amd/csrc"""
+    import glob
+    src = ''.join(open(f).read() for f in glob.glob(os.path.join(REPO, 'points2surf_amd', 'csrc', '*')))
+    for doc in ('DESIGN.md', os.path.join('profiles', 'README.md')):
+        t = open(os.path.join(REPO, doc)).read()
+        names = set(re.findall(r'`((?:p2s|wc|vol|mc|mt|rs)_[a-z0-9_]*_kernel)(?:<[^`]*>)?`', t))
+        missing = sorted(n for n in names if ('void ' + n) not in src)
+        assert len(names) >= 10 and not missing, (doc, missing)
