@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define P2S_ABI_VERSION 2
+#define P2S_ABI_VERSION 3
 
 #define P2S_OK            0
 #define P2S_EINVAL       -1   /* bad argument / unsupported configuration */
@@ -42,6 +42,10 @@ int         p2s_abi_version(void);
 const char *p2s_last_error(void);
 /* number of visible HIP devices (0 if none); never fails */
 int         p2s_device_count(void);
+/* The library caches device memory per device: the blocks of destroyed cloud handles (so that a handle per shape costs
+ * no hipMalloc / hipFree) and the scratch of the volume / iso-surface stages (~2 GB after a 512^3 call).  This gives
+ * all of it back to HIP.  Waits for a running p2s_sdf_volume / p2s_marching_cubes on `device`. */
+int         p2s_release_scratch(int device);
 
 /* ------------------------------------------------------------------------------------------
  * Model  (replaces make_regressor: PointsToSurfModel(...).cuda(); load_state_dict(); eval(),
@@ -135,9 +139,21 @@ int p2s_encode_features(p2s_model_t m, const float *patch_ps_dev, const float *s
 /* ------------------------------------------------------------------------------------------
  * Cloud  (replaces load_shape: cKDTree(pts, leaf_size=1000), reference source/data_loader.py:16-68)
  * ------------------------------------------------------------------------------------------ */
+/* The neighbour index -- uniform cell grid G^3 over the bounding box, points counting-sorted by cell (stable: original
+ * order inside a cell), 3-D summed-area table of the cell counts -- is built ON THE DEVICE, stream-ordered on `stream`:
+ * bounding box + non-finite check, one 32-byte read-back (the call's only blocking operation; non-finite coordinates
+ * are rejected with P2S_EINVAL like the reference's kd-tree build would fail), cell histogram, three scan passes,
+ * scatter, in-cell ranking.  The handle owns a copy of the points; its memory comes from a per-device block cache
+ * (see p2s_release_scratch), so creating a handle per shape allocates nothing once the cache is warm.
+ * p2s_cloud_destroy drains the streams the handle was used on before its blocks are recycled. */
 int p2s_cloud_create(const float *pts_dev, int n_points, int device, void *stream, p2s_cloud_t *out);
 int p2s_cloud_destroy(p2s_cloud_t c);
 int p2s_cloud_num_points(p2s_cloud_t c);
+/* test / diagnostic read-back of the index (host buffers, any may be NULL): *G_host = cells per axis; geom_host[4] =
+ * bounding-box minimum x, y, z and 1 / cell size; cell_start_host [G^3 + 1]; sat_host [(G + 1)^3] (inclusive prefix
+ * sums, zero borders); sorted_host [n][4] = x, y, z, original index (int32 bit pattern).  Synchronises `stream`. */
+int p2s_cloud_index_export(p2s_cloud_t c, int32_t *G_host, float *geom_host, int32_t *cell_start_host,
+                           int32_t *sat_host, float *sorted_host, void *stream);
 
 /* a1: get_voxel_centers_grid_smaller_pc (reference source/sdf.py:46-79).  Writes up to `capacity`
  * query points (C order of the voxel index) to q_out_dev [capacity][3]; *n_queries receives the

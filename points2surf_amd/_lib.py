@@ -30,6 +30,7 @@ PROTOTYPES = {
     'p2s_abi_version': (c_int, []),
     'p2s_last_error': (ctypes.c_char_p, []),
     'p2s_device_count': (c_int, []),
+    'p2s_release_scratch': (c_int, [c_int]),
     'p2s_model_create': (c_int, [ctypes.POINTER(ModelCfg), c_void_p, ctypes.c_size_t,
                                  ctypes.POINTER(WeightOffsets), c_int, ctypes.POINTER(c_void_p)]),
     'p2s_model_destroy': (c_int, [c_void_p]),
@@ -39,6 +40,8 @@ PROTOTYPES = {
     'p2s_cloud_create': (c_int, [c_void_p, c_int, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
     'p2s_cloud_destroy': (c_int, [c_void_p]),
     'p2s_cloud_num_points': (c_int, [c_void_p]),
+    'p2s_cloud_index_export': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int32), c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
     'p2s_query_grid': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
     'p2s_knn_patch': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'p2s_rng_create': (c_int, [ctypes.c_uint32, c_int, ctypes.POINTER(c_void_p)]),

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <algorithm>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -15,11 +16,27 @@ void p2s_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-void *p2s_scratch(int device, size_t bytes) {
-    struct Slot { void *p = nullptr; size_t cap = 0; };
-    static thread_local Slot slots[16];
-    if (device < 0 || device >= 16) return nullptr;
-    Slot &sl = slots[device];
+// Process-wide grow-only scratch buffer per device (volume / iso-surface stages).  The caller holds the device's
+// scratch lock for its whole call (P2sScratchLock), so concurrent host threads serialise on it instead of each keeping
+// ~2 GB of HBM alive until the process exits; p2s_release_scratch() gives the memory back.
+namespace {
+struct DevScratch {
+    std::mutex mu;
+    void *p = nullptr;
+    size_t cap = 0;
+};
+DevScratch g_scratch[P2S_MAX_DEVICES];
+}  // namespace
+
+P2sScratchLock::P2sScratchLock(int device) : dev_(device) {
+    if (dev_ >= 0 && dev_ < P2S_MAX_DEVICES) g_scratch[dev_].mu.lock();
+}
+P2sScratchLock::~P2sScratchLock() {
+    if (dev_ >= 0 && dev_ < P2S_MAX_DEVICES) g_scratch[dev_].mu.unlock();
+}
+void *P2sScratchLock::get(size_t bytes) {
+    if (dev_ < 0 || dev_ >= P2S_MAX_DEVICES) return nullptr;
+    DevScratch &sl = g_scratch[dev_];
     if (bytes <= sl.cap) return sl.p;
     if (sl.p) (void)hipFree(sl.p);
     sl.p = nullptr;
@@ -46,6 +63,22 @@ int p2s_device_count(void) {
         return 0;
     }
     return n;
+}
+
+int p2s_release_scratch(int device) {
+    if (device < 0 || device >= P2S_MAX_DEVICES || device >= p2s_device_count()) {
+        p2s_set_error("p2s_release_scratch: no HIP device %d", device);
+        return P2S_ENODEVICE;
+    }
+    P2S_HIP_CHECK(hipSetDevice(device));
+    {
+        std::lock_guard<std::mutex> g(g_scratch[device].mu);     // waits for a running volume / iso-surface call
+        if (g_scratch[device].p) (void)hipFree(g_scratch[device].p);
+        g_scratch[device].p = nullptr;
+        g_scratch[device].cap = 0;
+    }
+    p2s_cloud_pool_release(device);
+    return P2S_OK;
 }
 
 int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_floats,

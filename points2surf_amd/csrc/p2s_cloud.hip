@@ -14,6 +14,7 @@
 #include "p2s_internal.h"
 #include <vector>
 #include <cstdlib>
+#include <mutex>
 
 // a5 must reproduce numpy's fp32 results bit for bit: no FMA contraction anywhere in this file, and
 // sqrtf / operator/ (correctly rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt);
@@ -595,7 +596,264 @@ __global__ __launch_bounds__(64) void p2s_patch_from_ids_kernel(const float *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// a2: cell index built ON THE DEVICE (replaces cKDTree(pts, leaf_size=1000), source/data_loader.py:40-42)
+//   bbox + finite check -> [one 32-byte read-back: the only blocking call] -> cell ids + histogram -> 3-D summed-area
+//   table (three axis scans) -> cell_start derived from the SAT -> scatter -> in-cell rank by original id
+// The result is the STABLE counting sort of the points by cell (original order inside a cell), i.e. independent of the
+// order the atomics retire in: bit-identical to oracle/cloud_index_oracle.py.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f32_ordered(float v) {
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ inline float f32_from_ordered(uint32_t o) {
+    const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// rec[0..2] = min (ordered encoding), rec[3..5] = max, rec[6] = lowest index of a non-finite point (or 0xffffffff)
+__global__ __launch_bounds__(256) void p2s_bbox_kernel(const float *__restrict__ pts, int n, uint32_t *__restrict__ rec) {
+    __shared__ uint32_t red[4][7];
+    uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u}, bad = 0xffffffffu;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = pts[3 * (size_t)i + a];
+            if (!(v == v) || isinf(v)) bad = min(bad, (uint32_t)i);
+            const uint32_t o = f32_ordered(v);
+            lo[a] = min(lo[a], o);
+            hi[a] = max(hi[a], o);
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], d));
+            hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], d));
+        }
+        bad = min(bad, (uint32_t)__shfl_xor((int)bad, d));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        for (int a = 0; a < 3; ++a) {
+            red[wave][a] = lo[a];
+            red[wave][3 + a] = hi[a];
+        }
+        red[wave][6] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int j = threadIdx.x;
+        uint32_t v = red[0][j];
+        for (int w = 1; w < 4; ++w) v = (j >= 3 && j < 6) ? max(v, red[w][j]) : min(v, red[w][j]);
+        if (j >= 3 && j < 6) atomicMax(&rec[j], v);
+        else atomicMin(&rec[j], v);
+    }
+}
+
+struct CellGeom {
+    float lo[3];
+    float inv;
+    int G;
+};
+
+__global__ __launch_bounds__(256) void p2s_cell_hist_kernel(const float *__restrict__ pts, int n, CellGeom g,
+                                                            int *__restrict__ cid, int *__restrict__ cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int cx = cell_coord(pts[3 * (size_t)i + 0], g.lo[0], g.inv, g.G);
+    const int cy = cell_coord(pts[3 * (size_t)i + 1], g.lo[1], g.inv, g.G);
+    const int cz = cell_coord(pts[3 * (size_t)i + 2], g.lo[2], g.inv, g.G);
+    const int c = (cx * g.G + cy) * g.G + cz;
+    cid[i] = c;
+    atomicAdd(&cnt[c], 1);
+}
+
+// SAT pass 1 (z): one wave per (x, y) row of the count grid; inclusive scan along z into sat[x+1][y+1][1..G]
+__global__ __launch_bounds__(256) void p2s_sat_z_kernel(const int *__restrict__ cnt, int G, int *__restrict__ sat) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= G * G) return;
+    const int x = row / G, y = row % G;
+    const int G1 = G + 1;
+    int carry = 0;
+    for (int z0 = 0; z0 < G; z0 += 64) {
+        const int z = z0 + lane;
+        const int v = z < G ? cnt[(size_t)row * G + z] : 0;
+        int sacc = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(sacc, d);
+            if (lane >= d) sacc += t;
+        }
+        if (z < G) sat[((size_t)(x + 1) * G1 + (y + 1)) * G1 + z + 1] = carry + sacc;
+        carry += __shfl(sacc, 63);
+    }
+}
+// SAT passes 2 / 3: running sums along y (stride G1) / x (stride G1^2); one thread per line, consecutive threads =
+// consecutive z -> coalesced
+__global__ __launch_bounds__(256) void p2s_sat_axis_kernel(int *__restrict__ sat, int G, int axis) {
+    const int G1 = G + 1;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= G * G) return;
+    const int z = t % G + 1, o = t / G + 1;            // o = x (axis 1: scan y) or y (axis 0: scan x)
+    size_t base, stride;
+    if (axis == 1) {
+        base = ((size_t)o * G1) * G1 + z;
+        stride = G1;
+    } else {
+        base = ((size_t)o) * G1 + z;
+        stride = (size_t)G1 * G1;
+    }
+    int run = 0;
+    for (int j = 1; j <= G; ++j) {
+        run += sat[base + j * stride];
+        sat[base + j * stride] = run;
+    }
+}
+// cell_start[c] = number of points in cells with a smaller linear index = three box counts of the SAT
+__global__ __launch_bounds__(256) void p2s_cell_start_kernel(const int *__restrict__ sat, int G, int n,
+                                                             int *__restrict__ cell_start, int *__restrict__ fill) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int ncell = G * G * G;
+    if (c > ncell) return;
+    if (c == ncell) {
+        cell_start[c] = n;
+        return;
+    }
+    const int G1 = G + 1;
+    const int z = c % G, y = (c / G) % G, x = c / (G * G);
+    auto S = [&](int a, int b, int d) { return sat[((size_t)a * G1 + b) * G1 + d]; };
+    const int before = S(x, G, G) + (S(x + 1, y, G) - S(x, y, G)) +
+                       (S(x + 1, y + 1, z) - S(x, y + 1, z) - S(x + 1, y, z) + S(x, y, z));
+    cell_start[c] = before;
+    fill[c] = before;
+}
+__global__ __launch_bounds__(256) void p2s_cell_scatter_kernel(const float *__restrict__ pts, const int *__restrict__ cid, int n,
+                                                               int *__restrict__ fill, float4 *__restrict__ tmp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int dst = atomicAdd(&fill[cid[i]], 1);
+    float4 v;
+    v.x = pts[3 * (size_t)i + 0];
+    v.y = pts[3 * (size_t)i + 1];
+    v.z = pts[3 * (size_t)i + 2];
+    v.w = __int_as_float(i);
+    tmp[dst] = v;
+}
+// the atomics above place a cell's points in arbitrary order: rank every point inside its cell by original id
+__global__ __launch_bounds__(256) void p2s_cell_rank_kernel(const float4 *__restrict__ tmp, const int *__restrict__ cell_start,
+                                                            int n, CellGeom g, float4 *__restrict__ spts) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float4 v = tmp[p];
+    const int c = (cell_coord(v.x, g.lo[0], g.inv, g.G) * g.G + cell_coord(v.y, g.lo[1], g.inv, g.G)) * g.G +
+                  cell_coord(v.z, g.lo[2], g.inv, g.G);
+    const int s0 = cell_start[c], e0 = cell_start[c + 1];
+    const int id = __float_as_int(v.w);
+    int rank = 0;
+    for (int j = s0; j < e0; ++j) rank += (__float_as_int(tmp[j].w) < id) ? 1 : 0;
+    spts[s0 + rank] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-memory cache of the cloud handles.  The drop-in creates one cloud handle per shape: hipMalloc / hipFree per
+// shape are blocking calls (and hipFree drains the device).  Freed blocks are kept per device and handed to the next
+// handle; sizes are rounded to 1/8 octave so that clouds of similar size reuse each other's blocks.
+// ---------------------------------------------------------------------------------------------
+struct PoolBlock {
+    void *p;
+    size_t bytes;
+};
+struct DevPool {
+    std::mutex mu;
+    std::vector<PoolBlock> free_list, used;
+    size_t cached = 0;
+};
+DevPool g_pool[P2S_MAX_DEVICES];
+constexpr size_t POOL_MAX_CACHED = (size_t)4 << 30;      // per device; beyond that freed blocks go back to HIP
+
+size_t pool_round(size_t bytes) {
+    bytes = std::max<size_t>(bytes, 256);
+    size_t p2 = 256;
+    while (p2 < bytes) p2 <<= 1;          // smallest power of two >= bytes
+    const size_t step = p2 / 16;          // 1/8 octave of the octave below
+    return (bytes + step - 1) / step * step;
+}
+
 }  // namespace
+
+void *p2s_pool_alloc(int device, size_t bytes) {
+    if (device < 0 || device >= P2S_MAX_DEVICES) return nullptr;
+    const size_t want = pool_round(bytes);
+    DevPool &pl = g_pool[device];
+    std::lock_guard<std::mutex> g(pl.mu);
+    int best = -1;
+    for (int i = 0; i < (int)pl.free_list.size(); ++i)
+        if (pl.free_list[i].bytes >= want && pl.free_list[i].bytes <= 2 * want &&
+            (best < 0 || pl.free_list[i].bytes < pl.free_list[best].bytes))
+            best = i;
+    PoolBlock b;
+    if (best >= 0) {
+        b = pl.free_list[best];
+        pl.free_list.erase(pl.free_list.begin() + best);
+        pl.cached -= b.bytes;
+    } else {
+        b.p = nullptr;
+        b.bytes = want;
+        if (hipMalloc(&b.p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            // give the cache back to HIP and retry once
+            for (auto &f : pl.free_list) (void)hipFree(f.p);
+            pl.free_list.clear();
+            pl.cached = 0;
+            if (hipMalloc(&b.p, want) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+        }
+    }
+    pl.used.push_back(b);
+    return b.p;
+}
+
+// the caller guarantees that no work touching the block is in flight
+void p2s_pool_free(int device, void *p) {
+    if (!p || device < 0 || device >= P2S_MAX_DEVICES) return;
+    DevPool &pl = g_pool[device];
+    std::lock_guard<std::mutex> g(pl.mu);
+    for (size_t i = 0; i < pl.used.size(); ++i) {
+        if (pl.used[i].p != p) continue;
+        const PoolBlock b = pl.used[i];
+        pl.used.erase(pl.used.begin() + i);
+        if (pl.cached + b.bytes > POOL_MAX_CACHED) {
+            (void)hipFree(b.p);
+        } else {
+            pl.free_list.push_back(b);
+            pl.cached += b.bytes;
+        }
+        return;
+    }
+    (void)hipFree(p);       // not ours (cannot happen): do not leak
+}
+
+void p2s_cloud_pool_release(int device) {
+    if (device < 0 || device >= P2S_MAX_DEVICES) return;
+    DevPool &pl = g_pool[device];
+    std::lock_guard<std::mutex> g(pl.mu);
+    for (auto &f : pl.free_list) (void)hipFree(f.p);
+    pl.free_list.clear();
+    pl.cached = 0;
+}
+
+void p2s_cloud_note_stream(p2s_cloud_s *c, hipStream_t s) {
+    for (int i = 0; i < c->n_streams; ++i)
+        if (c->streams[i] == s) return;
+    if (c->n_streams < 4) c->streams[c->n_streams++] = s;
+    else c->many_streams = true;
+}
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -607,94 +865,94 @@ int p2s_cloud_create(const float *pts_dev, int n, int device, void *stream, p2s_
         p2s_set_error("p2s_cloud_create: bad argument (n=%d)", n);
         return P2S_EINVAL;
     }
-    if (p2s_device_count() <= device || device < 0) {
+    if (p2s_device_count() <= device || device < 0 || device >= P2S_MAX_DEVICES) {
         p2s_set_error("p2s_cloud_create: no HIP device %d", device);
         return P2S_ENODEVICE;
     }
     P2S_HIP_CHECK(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
-    std::vector<float> h((size_t)n * 3);
-    P2S_HIP_CHECK(hipMemcpyAsync(h.data(), pts_dev, h.size() * 4, hipMemcpyDeviceToHost, s));
-    P2S_HIP_CHECK(hipStreamSynchronize(s));
-
     // uniform cell grid over the bounding box; ~10 points per occupied cell for surface-like clouds
-    float lo[3] = {h[0], h[1], h[2]}, hi[3] = {h[0], h[1], h[2]};
-    for (int i = 0; i < n; ++i)
-        for (int a = 0; a < 3; ++a) {
-            const float v = h[3 * (size_t)i + a];
-            if (!(v == v) || std::isinf(v)) {
-                p2s_set_error("p2s_cloud_create: non-finite coordinate at point %d", i);
-                return P2S_EINVAL;
-            }
-            lo[a] = std::min(lo[a], v);
-            hi[a] = std::max(hi[a], v);
-        }
     int G = (int)std::ceil(std::sqrt((double)n / 32.0));
     G = std::max(4, std::min(G, 128));
+    const size_t ncell = (size_t)G * G * G;
+    const int G1 = G + 1;
+    const size_t nsat = (size_t)G1 * G1 * G1;
+    // one arena: pts | spts | tmp | cid | cnt / fill | cell_start | sat | bbox record (256-byte aligned pieces)
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_pts = 0, o_spts = o_pts + al((size_t)n * 12), o_tmp = o_spts + al((size_t)n * 16),
+                 o_cid = o_tmp + al((size_t)n * 16), o_cnt = o_cid + al((size_t)n * 4), o_start = o_cnt + al((ncell + 1) * 4),
+                 o_sat = o_start + al((ncell + 1) * 4), o_rec = o_sat + al(nsat * 4), o_tot = o_rec + 256, total = o_tot + 256;
+    p2s_cloud_s *c = new p2s_cloud_s();
+    c->device = device;
+    p2s_cloud_note_stream(c, s);
+    c->arena = (char *)p2s_pool_alloc(device, total);
+    if (!c->arena) {
+        p2s_set_error("p2s_cloud_create: device allocation of %zu bytes failed", total);
+        delete c;
+        return P2S_ENOMEM;
+    }
+    auto fail = [&](int code) {
+        (void)hipStreamSynchronize(s);
+        p2s_cloud_destroy(c);
+        return code;
+    };
+#define CLOUD_HIP(expr)                                                                                    \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) {                                                                            \
+            p2s_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);      \
+            return fail(P2S_EHIP);                                                                         \
+        }                                                                                                  \
+    } while (0)
+    c->pts = (float *)(c->arena + o_pts);
+    c->spts = (float4 *)(c->arena + o_spts);
+    float4 *tmp = (float4 *)(c->arena + o_tmp);
+    int *cid = (int *)(c->arena + o_cid);
+    int *cnt = (int *)(c->arena + o_cnt);
+    c->cell_start = (int *)(c->arena + o_start);
+    c->sat = (int *)(c->arena + o_sat);
+    uint32_t *rec = (uint32_t *)(c->arena + o_rec);
+    c->totals = (long long *)(c->arena + o_tot);
+    // the handle owns a copy of the points (the caller's tensor may go away)
+    CLOUD_HIP(hipMemcpyAsync(c->pts, pts_dev, (size_t)n * 12, hipMemcpyDeviceToDevice, s));
+    const uint32_t rec0[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0u};
+    CLOUD_HIP(hipMemcpyAsync(rec, rec0, sizeof(rec0), hipMemcpyHostToDevice, s));
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(p2s_bbox_kernel, dim3(std::min(nb, 1024u)), dim3(256), 0, s, c->pts, n, rec);
+    CLOUD_HIP(hipGetLastError());
+    // scratch that does not depend on the box is cleared while the record travels
+    CLOUD_HIP(hipMemsetAsync(cnt, 0, (ncell + 1) * 4, s));
+    CLOUD_HIP(hipMemsetAsync(c->sat, 0, nsat * 4, s));
+    uint32_t h[8];
+    CLOUD_HIP(hipMemcpyAsync(h, rec, sizeof(h), hipMemcpyDeviceToHost, s));
+    CLOUD_HIP(hipStreamSynchronize(s));            // the one blocking call: bounding box + non-finite check
+    if (h[6] != 0xffffffffu) {
+        p2s_set_error("p2s_cloud_create: non-finite coordinate at point %u", h[6]);
+        return fail(P2S_EINVAL);
+    }
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = f32_from_ordered(h[a]);
+        hi[a] = f32_from_ordered(h[3 + a]);
+    }
     float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
     if (!(ext > 0.f)) ext = 1.0f;
     const float cell = ext / (float)G * 1.0001f;
     const float inv = 1.0f / cell;
-
-    const size_t ncell = (size_t)G * G * G;
-    std::vector<int> cnt(ncell + 1, 0), cid((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        const int cx = cell_coord(h[3 * (size_t)i + 0], lo[0], inv, G);
-        const int cy = cell_coord(h[3 * (size_t)i + 1], lo[1], inv, G);
-        const int cz = cell_coord(h[3 * (size_t)i + 2], lo[2], inv, G);
-        cid[i] = (cx * G + cy) * G + cz;
-        cnt[cid[i]]++;
-    }
-    const int G1 = G + 1;
-    std::vector<int> sat((size_t)G1 * G1 * G1, 0);
-    for (int x = 1; x <= G; ++x)
-        for (int y = 1; y <= G; ++y) {
-            int run = 0;
-            for (int z = 1; z <= G; ++z) {
-                run += cnt[((size_t)(x - 1) * G + (y - 1)) * G + (z - 1)];
-                sat[((size_t)x * G1 + y) * G1 + z] = run + sat[((size_t)(x - 1) * G1 + y) * G1 + z] +
-                                                     sat[((size_t)x * G1 + (y - 1)) * G1 + z] -
-                                                     sat[((size_t)(x - 1) * G1 + (y - 1)) * G1 + z];
-            }
-        }
-    std::vector<int> start(ncell + 1);
-    {
-        int acc = 0;
-        for (size_t c = 0; c < ncell; ++c) {
-            start[c] = acc;
-            acc += cnt[c];
-        }
-        start[ncell] = acc;
-    }
-    std::vector<int> fill(start.begin(), start.end() - 1);
-    std::vector<float4> sp((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        const int dst = fill[cid[i]]++;
-        float4 v;
-        v.x = h[3 * (size_t)i + 0];
-        v.y = h[3 * (size_t)i + 1];
-        v.z = h[3 * (size_t)i + 2];
-        int id = i;
-        memcpy(&v.w, &id, 4);
-        sp[dst] = v;
-    }
-
-    p2s_cloud_s *c = new p2s_cloud_s();
-    c->device = device;
-    bool ok = hipMalloc(&c->pts, (size_t)n * 12) == hipSuccess && hipMalloc(&c->spts, (size_t)n * 16) == hipSuccess &&
-              hipMalloc(&c->cell_start, (ncell + 1) * 4) == hipSuccess &&
-              hipMalloc(&c->sat, sat.size() * 4) == hipSuccess && hipMalloc(&c->totals, 16) == hipSuccess;
-    if (ok) {
-        ok = hipMemcpy(c->pts, h.data(), (size_t)n * 12, hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemcpy(c->spts, sp.data(), (size_t)n * 16, hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemcpy(c->cell_start, start.data(), (ncell + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemcpy(c->sat, sat.data(), sat.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
-    }
-    if (!ok) {
-        p2s_set_error("p2s_cloud_create: device allocation/copy failed: %s", hipGetErrorString(hipGetLastError()));
-        p2s_cloud_destroy(c);
-        return P2S_ENOMEM;
-    }
+    CellGeom g;
+    for (int a = 0; a < 3; ++a) g.lo[a] = lo[a];
+    g.inv = inv;
+    g.G = G;
+    hipLaunchKernelGGL(p2s_cell_hist_kernel, dim3(nb), dim3(256), 0, s, c->pts, n, g, cid, cnt);
+    hipLaunchKernelGGL(p2s_sat_z_kernel, dim3((unsigned)((G * G + 3) / 4)), dim3(256), 0, s, cnt, G, c->sat);
+    hipLaunchKernelGGL(p2s_sat_axis_kernel, dim3((unsigned)((G * G + 255) / 256)), dim3(256), 0, s, c->sat, G, 1);
+    hipLaunchKernelGGL(p2s_sat_axis_kernel, dim3((unsigned)((G * G + 255) / 256)), dim3(256), 0, s, c->sat, G, 0);
+    hipLaunchKernelGGL(p2s_cell_start_kernel, dim3((unsigned)((ncell + 1 + 255) / 256)), dim3(256), 0, s, c->sat, G, n,
+                       c->cell_start, cnt);
+    hipLaunchKernelGGL(p2s_cell_scatter_kernel, dim3(nb), dim3(256), 0, s, c->pts, cid, n, cnt, tmp);
+    hipLaunchKernelGGL(p2s_cell_rank_kernel, dim3(nb), dim3(256), 0, s, tmp, c->cell_start, n, g, c->spts);
+    CLOUD_HIP(hipGetLastError());
+#undef CLOUD_HIP
     c->d.pts = c->pts;
     c->d.spts = c->spts;
     c->d.cell_start = c->cell_start;
@@ -710,17 +968,44 @@ int p2s_cloud_create(const float *pts_dev, int n, int device, void *stream, p2s_
 int p2s_cloud_destroy(p2s_cloud_t c) {
     if (!c) return P2S_OK;
     (void)hipSetDevice(c->device);
-    if (c->pts) (void)hipFree(c->pts);
-    if (c->spts) (void)hipFree(c->spts);
-    if (c->cell_start) (void)hipFree(c->cell_start);
-    if (c->sat) (void)hipFree(c->sat);
-    if (c->occ) (void)hipFree(c->occ);
-    if (c->blk_cnt) (void)hipFree(c->blk_cnt);
-    if (c->totals) (void)hipFree(c->totals);
-    if (c->qcache) (void)hipFree(c->qcache);
-    if (c->shuffle_perm) (void)hipFree(c->shuffle_perm);
-    if (c->wc_plan) (void)hipFree(c->wc_plan);
+    // the blocks go back to the cache: nothing may still be reading them
+    if (c->many_streams) (void)hipDeviceSynchronize();
+    else
+        for (int i = 0; i < c->n_streams; ++i) (void)hipStreamSynchronize(c->streams[i]);
+    if (c->grid_ev) (void)hipEventDestroy(c->grid_ev);
+    p2s_pool_free(c->device, c->arena);
+    p2s_pool_free(c->device, c->occ);
+    p2s_pool_free(c->device, c->blk_cnt);
+    p2s_pool_free(c->device, c->qcache);
+    p2s_pool_free(c->device, c->shuffle_perm);
+    p2s_pool_free(c->device, c->wc_plan);
     delete c;
+    return P2S_OK;
+}
+
+/* test / diagnostic access to the index: any output may be NULL.  geom_host: lo[3], inv_cell; sizes from *G_host:
+ * cell_start (G^3 + 1) int32, sat (G + 1)^3 int32, sorted n x (x, y, z, original id as int bits).  Synchronises. */
+int p2s_cloud_index_export(p2s_cloud_t c, int32_t *G_host, float *geom_host, int32_t *cell_start_host, int32_t *sat_host,
+                           float *sorted_host, void *stream) {
+    if (!c) {
+        p2s_set_error("p2s_cloud_index_export: null handle");
+        return P2S_EINVAL;
+    }
+    P2S_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    p2s_cloud_note_stream(c, s);
+    const int G = c->d.G;
+    if (G_host) *G_host = G;
+    if (geom_host) {
+        for (int a = 0; a < 3; ++a) geom_host[a] = c->d.lo[a];
+        geom_host[3] = c->d.inv_cell;
+    }
+    if (cell_start_host)
+        P2S_HIP_CHECK(hipMemcpyAsync(cell_start_host, c->cell_start, ((size_t)G * G * G + 1) * 4, hipMemcpyDeviceToHost, s));
+    if (sat_host)
+        P2S_HIP_CHECK(hipMemcpyAsync(sat_host, c->sat, (size_t)(G + 1) * (G + 1) * (G + 1) * 4, hipMemcpyDeviceToHost, s));
+    if (sorted_host) P2S_HIP_CHECK(hipMemcpyAsync(sorted_host, c->spts, (size_t)c->d.n * 16, hipMemcpyDeviceToHost, s));
+    P2S_HIP_CHECK(hipStreamSynchronize(s));
     return P2S_OK;
 }
 
@@ -755,6 +1040,9 @@ int p2s_cloud_grid(p2s_cloud_s *c, int res, int eps, const float **q_out, long l
         return P2S_EINVAL;
     }
     if (c->qc_n >= 0 && c->qc_res == res && c->qc_eps == eps) {
+        // the compaction was queued on grid_stream and not waited for: other streams order themselves behind it
+        if (c->grid_ev && s != c->grid_stream) P2S_HIP_CHECK(hipStreamWaitEvent(s, c->grid_ev, 0));
+        p2s_cloud_note_stream(c, s);
         *q_out = c->qcache;
         *n_out = c->qc_n;
         return P2S_OK;
@@ -765,25 +1053,37 @@ int p2s_cloud_grid(p2s_cloud_s *c, int res, int eps, const float **q_out, long l
     const size_t words = (vox + 31) / 32;
     const long long rm = res - 1;
     const long long nblk = (rm * rm * rm + 255) / 256;
+    p2s_cloud_note_stream(c, s);
+    // scratch from the device's block cache (p2s_pool_alloc): no hipMalloc on the per-shape path once it is warm.
+    // Replaced blocks may still be read by work queued on the handle's streams: drain them first (rare path)
+    auto drain = [&]() {
+        if (c->many_streams) (void)hipDeviceSynchronize();
+        else
+            for (int i = 0; i < c->n_streams; ++i) (void)hipStreamSynchronize(c->streams[i]);
+    };
     if (words > c->occ_words) {
-        if (c->occ) (void)hipFree(c->occ);
-        c->occ = nullptr;
+        if (c->occ) {
+            drain();
+            p2s_pool_free(c->device, c->occ);
+        }
         c->occ_words = 0;
-        if (hipMalloc(&c->occ, words * 4) != hipSuccess) {
-            (void)hipGetLastError();
-            p2s_set_error("p2s_query_grid: hipMalloc(%zu bytes) failed", words * 4);
+        c->occ = (uint32_t *)p2s_pool_alloc(c->device, words * 4);
+        if (!c->occ) {
+            p2s_set_error("p2s_query_grid: device allocation of %zu bytes failed", words * 4);
             return P2S_ENOMEM;
         }
         c->occ_words = words;
     }
     if ((size_t)nblk > c->blk_cap) {
-        if (c->blk_cnt) (void)hipFree(c->blk_cnt);
-        c->blk_cnt = nullptr;
+        if (c->blk_cnt) {
+            drain();
+            p2s_pool_free(c->device, c->blk_cnt);
+        }
         c->blk_cap = 0;
         // counts (int) followed by offsets (long long)
-        if (hipMalloc(&c->blk_cnt, (size_t)nblk * 4 + (size_t)nblk * 8 + 64) != hipSuccess) {
-            (void)hipGetLastError();
-            p2s_set_error("p2s_query_grid: hipMalloc(block scan) failed");
+        c->blk_cnt = (int *)p2s_pool_alloc(c->device, (size_t)nblk * 4 + (size_t)nblk * 8 + 64);
+        if (!c->blk_cnt) {
+            p2s_set_error("p2s_query_grid: device allocation (block scan) failed");
             return P2S_ENOMEM;
         }
         c->blk_cap = (size_t)nblk;
@@ -812,23 +1112,27 @@ int p2s_cloud_grid(p2s_cloud_s *c, int res, int eps, const float **q_out, long l
     }
     const long long n = host_tot[0];
     if (n > c->qc_cap) {
-        if (c->qcache) (void)hipFree(c->qcache);
-    if (c->shuffle_perm) (void)hipFree(c->shuffle_perm);
-        c->qcache = nullptr;
+        if (c->qcache) {
+            drain();
+            p2s_pool_free(c->device, c->qcache);
+        }
         c->qc_cap = 0;
-        if (hipMalloc(&c->qcache, (size_t)n * 12) != hipSuccess) {
-            (void)hipGetLastError();
-            p2s_set_error("p2s_query_grid: hipMalloc(%lld query points) failed", n);
+        c->qcache = (float *)p2s_pool_alloc(c->device, (size_t)n * 12);
+        if (!c->qcache) {
+            p2s_set_error("p2s_query_grid: device allocation of %lld query points failed", n);
             return P2S_ENOMEM;
         }
         c->qc_cap = n;
     }
     if (n > 0) {
+        // stream-ordered on `s`; consumers on other streams order themselves behind it with an event (run_pipeline)
         hipLaunchKernelGGL(p2s_grid_compact_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, c->occ, res, go, c->blk_cnt,
                            blk_off, c->qcache, n);
         P2S_LAUNCH_CHECK("p2s_grid_compact_kernel<1>");
-        P2S_HIP_CHECK(hipStreamSynchronize(s));    // the grid may be consumed on other streams from here on
     }
+    if (!c->grid_ev) P2S_HIP_CHECK(hipEventCreateWithFlags(&c->grid_ev, hipEventDisableTiming));
+    P2S_HIP_CHECK(hipEventRecord(c->grid_ev, s));
+    c->grid_stream = s;
     c->qc_res = res;
     c->qc_eps = eps;
     c->qc_n = n;
@@ -856,6 +1160,7 @@ int p2s_knn_patch(p2s_cloud_t c, const float *query_dev, int64_t nq, int k, int3
     }
     if (nq == 0) return P2S_OK;
     P2S_HIP_CHECK(hipSetDevice(c->device));
+    p2s_cloud_note_stream(c, (hipStream_t)stream);
     const unsigned grid = (unsigned)std::min<int64_t>(nq, 256 * 64);
     hipLaunchKernelGGL(p2s_knn_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, c->d, query_dev, (long long)nq, k,
                        ids_out_dev, patch_ps_out_dev, radius_out_dev);
@@ -870,6 +1175,7 @@ int p2s_gather_points(p2s_cloud_t c, const int32_t *ids_dev, int64_t n_ids, floa
     }
     if (n_ids == 0) return P2S_OK;
     P2S_HIP_CHECK(hipSetDevice(c->device));
+    p2s_cloud_note_stream(c, (hipStream_t)stream);
     hipLaunchKernelGGL(p2s_gather_kernel, dim3((unsigned)((n_ids + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        c->d.pts, ids_dev, (long long)n_ids, c->d.n, pts_out_dev);
     P2S_LAUNCH_CHECK("p2s_gather_kernel");
@@ -1004,14 +1310,15 @@ int p2s_subsample_shuffle_pad(p2s_rng_t r, p2s_cloud_t c, int64_t nq, int n, int
     if (nq == 0) return P2S_OK;
     P2S_HIP_CHECK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
+    p2s_cloud_note_stream(c, s);
     int rc = p2s_rng_session_close(r, s);
     if (rc) return rc;
     if (!c->shuffle_perm) {
         std::vector<int> id((size_t)c->d.n);
         for (int i = 0; i < c->d.n; ++i) id[i] = i;
-        if (hipMalloc(&c->shuffle_perm, (size_t)c->d.n * 4) != hipSuccess) {
-            (void)hipGetLastError();
-            p2s_set_error("p2s_subsample_shuffle_pad: hipMalloc failed");
+        c->shuffle_perm = (int *)p2s_pool_alloc(c->device, (size_t)c->d.n * 4);
+        if (!c->shuffle_perm) {
+            p2s_set_error("p2s_subsample_shuffle_pad: device allocation failed");
             return P2S_ENOMEM;
         }
         P2S_HIP_CHECK(hipMemcpy(c->shuffle_perm, id.data(), id.size() * 4, hipMemcpyHostToDevice));
@@ -1030,6 +1337,7 @@ int p2s_patch_from_ids(p2s_cloud_t c, const int32_t *ids_dev, const int32_t *per
     }
     if (nq == 0) return P2S_OK;
     P2S_HIP_CHECK(hipSetDevice(c->device));
+    p2s_cloud_note_stream(c, (hipStream_t)stream);
     const unsigned grid = (unsigned)std::min<int64_t>(nq, 256 * 64);
     hipLaunchKernelGGL(p2s_patch_from_ids_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, c->d.pts, ids_dev,
                        perm_before_dev, c->d.n, query_dev, (long long)nq, k, patch_ps_out_dev, radius_out_dev);

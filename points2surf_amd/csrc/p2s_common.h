@@ -10,10 +10,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void p2s_set_error(const char *fmt, ...);
-// grow-only scratch buffer of the calling host thread on `device` (volume / iso-surface stages: ~0.5 ms of
-// hipMalloc + hipFree per call otherwise); valid until the thread's next request on that device; nullptr on failure.
-// Callers synchronise their stream before returning, so the buffer is idle between calls.
-void *p2s_scratch(int device, size_t bytes);
+// Process-wide grow-only scratch buffer per device (volume / iso-surface stages: ~0.5 ms of hipMalloc + hipFree per
+// call otherwise).  A caller holds the lock for its whole call -- host threads serialise per device -- and synchronises
+// its stream before it returns, so the buffer is idle whenever the lock is free.  p2s_release_scratch() frees it.
+constexpr int P2S_MAX_DEVICES = 16;
+class P2sScratchLock {
+public:
+    explicit P2sScratchLock(int device);
+    ~P2sScratchLock();
+    P2sScratchLock(const P2sScratchLock &) = delete;
+    P2sScratchLock &operator=(const P2sScratchLock &) = delete;
+    void *get(size_t bytes);          // nullptr on failure; valid until the next get() on this device
+private:
+    int dev_;
+};
+void p2s_cloud_pool_release(int device);     // p2s_cloud.hip: cached cloud arenas of the device
 
 #define P2S_HIP_CHECK(expr)                                                                   \
     do {                                                                                      \

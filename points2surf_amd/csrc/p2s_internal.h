@@ -76,10 +76,16 @@ struct CloudDev {
 struct p2s_cloud_s {
     int device = 0;
     CloudDev d = {};
+    // one block of the device's cache (p2s_pool_alloc) holds pts, spts, cell_start, sat, totals + the build scratch
+    char *arena = nullptr;
     float *pts = nullptr;
     float4 *spts = nullptr;
     int *cell_start = nullptr;
     int *sat = nullptr;
+    // streams that may have work on this handle's memory in flight: drained before its blocks return to the cache
+    hipStream_t streams[4] = {};
+    int n_streams = 0;
+    bool many_streams = false;
     // query-grid scratch (grown on demand)
     uint32_t *occ = nullptr;
     size_t occ_words = 0;
@@ -91,6 +97,8 @@ struct p2s_cloud_s {
     float *qcache = nullptr;
     int qc_res = 0, qc_eps = 0;
     long long qc_n = -1, qc_cap = 0;
+    hipEvent_t grid_ev = nullptr;  // recorded behind the compaction of the cached grid on grid_stream
+    hipStream_t grid_stream = nullptr;
     // summation plan of np.sum(float32[n]) for the weighted sub-sample (p2s_wchoice.hip), built on first use
     int *wc_plan = nullptr;        // device: leaves [L][3], ops [O][3], level offsets [levels+1]
     int wc_leaves = 0, wc_ops_at = 0, wc_lvl_at = 0, wc_levels = 0, wc_root = 0, wc_nodes = 0;
@@ -123,8 +131,14 @@ struct p2s_rng_s {
     size_t wc_cap_q = 0, wc_cap_n = 0, wc_cap_k = 0;
 };
 
+// per-device cache of device-memory blocks for the cloud handles (p2s_cloud.hip)
+void *p2s_pool_alloc(int device, size_t bytes);
+void p2s_pool_free(int device, void *p);
+void p2s_cloud_note_stream(p2s_cloud_s *c, hipStream_t s);
+
 // query grid of (res, eps), computed once per cloud handle and kept on the device (p2s_cloud.hip); *q is owned by
-// the handle and valid until the next call with other parameters; synchronises `s`
+// the handle and valid until the next call with other parameters; stream-ordered on `s` (synchronises it once to
+// learn the count)
 int p2s_cloud_grid(p2s_cloud_s *c, int res, int eps, const float **q, long long *n, hipStream_t s);
 
 // serial generator (p2s_cloud.hip) and parallel generator (p2s_rng.hip)

@@ -556,7 +556,8 @@ extern "C" int p2s_marching_cubes(const float *vol_dev, int grid_res, float *ver
     // scratch: vmask (1) + tcount (1) + vbase (4) + tbase (8) per point; block totals + offsets; results
     const long long nchunk = (nblk + 1023) / 1024;
     const size_t bytes = (size_t)nvox * 14 + (size_t)nblk * (8 + 16) + (size_t)nchunk * 16 + 64 * 8 + 256;
-    char *scratch = (char *)p2s_scratch(device, bytes);
+    P2sScratchLock scratch_lock(device);
+    char *scratch = (char *)scratch_lock.get(bytes);
     if (!scratch) {
         p2s_set_error("p2s_marching_cubes: hipMalloc(%zu bytes) failed", bytes);
         return P2S_ENOMEM;

@@ -206,6 +206,8 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, hi));
     }
     hipStream_t sa = m->overlap ? m->aux : s;
+    p2s_cloud_note_stream(c, s);
+    p2s_cloud_note_stream(c, sa);
     const int64_t nq = q_end - q_begin;
     if (nq <= 0) return P2S_OK;
     const int C = (int)std::min<int64_t>(chunk, nq);

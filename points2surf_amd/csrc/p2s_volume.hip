@@ -618,7 +618,7 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
         p2s_set_error("p2s_sdf_volume: bad argument (res=%d sigma=%d)", grid_res, sigma);
         return P2S_EINVAL;
     }
-    if (p2s_device_count() <= device || device < 0) {
+    if (p2s_device_count() <= device || device < 0 || device >= P2S_MAX_DEVICES) {
         p2s_set_error("p2s_sdf_volume: no HIP device %d", device);
         return P2S_ENODEVICE;
     }
@@ -630,7 +630,8 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
     // unknown_initially (1) + new sign (1) + z sums (1) + zy sums (2) bytes per voxel
     const size_t scratch_bytes = (size_t)nvox * (fast ? 2 : 7) + sizeof(VolState) + 256 + (size_t)(nvox / 512 + 64) * 12;
     const size_t counts_at = (scratch_bytes + 63) & ~(size_t)63;
-    char *scratch = (char *)p2s_scratch(device, counts_at + (2 * NSHARD + 2) * 8);
+    P2sScratchLock scratch_lock(device);     // also guards the per-device pinned mailboxes below
+    char *scratch = (char *)scratch_lock.get(counts_at + (2 * NSHARD + 2) * 8);
     if (!scratch) {
         p2s_set_error("p2s_sdf_volume: hipMalloc(%zu bytes) failed", counts_at);
         return P2S_ENOMEM;
@@ -687,10 +688,14 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
         // when the verdict is there: no copy and no event between the sweeps (a verdict copied out behind batches of 16
         // launches cost six 10-us gaps and ~17 exit-at-once launches of 4.8 us: 9 % of the run at 256^3).
         const int ahead = getenv("P2S_VOLUME_AHEAD") ? std::max(1, atoi(getenv("P2S_VOLUME_AHEAD"))) : 4;
-        static thread_local VolMail *mail_h = nullptr;
-        static thread_local VolMail *mail_d = nullptr;
+        // one mailbox per device (allocated with that device current, portable: visible to every context), used
+        // under the device's scratch lock
+        static VolMail *mail_h_dev[P2S_MAX_DEVICES] = {};
+        static VolMail *mail_d_dev[P2S_MAX_DEVICES] = {};
+        VolMail *&mail_h = mail_h_dev[device];
+        VolMail *&mail_d = mail_d_dev[device];
         if (!mail_h && !getenv("P2S_VOLUME_NO_MAILBOX")) {
-            if (hipHostMalloc((void **)&mail_h, sizeof(VolMail), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            if (hipHostMalloc((void **)&mail_h, sizeof(VolMail), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess ||
                 hipHostGetDevicePointer((void **)&mail_d, mail_h, 0) != hipSuccess) {
                 (void)hipGetLastError();
                 mail_h = mail_d = nullptr;               // fall back to the copy-per-batch protocol below
@@ -748,10 +753,12 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
             // copy-per-batch protocol (no mapped host memory, or the mailbox stayed silent): the verdict of batch j is
             // copied out behind it and looked at only after batch j + 1 has been queued
             const int batch = getenv("P2S_VOLUME_BATCH") ? std::max(1, atoi(getenv("P2S_VOLUME_BATCH"))) : 16;
-            static thread_local VolState *pinned = nullptr;
-            static thread_local hipEvent_t look[2] = {nullptr, nullptr};
+            static VolState *pinned_dev[P2S_MAX_DEVICES] = {};
+            static hipEvent_t look_dev[P2S_MAX_DEVICES][2] = {};
+            VolState *&pinned = pinned_dev[device];
+            hipEvent_t *look = look_dev[device];
             if (!pinned) {
-                if (hipHostMalloc((void **)&pinned, 2 * sizeof(VolState), hipHostMallocDefault) != hipSuccess ||
+                if (hipHostMalloc((void **)&pinned, 2 * sizeof(VolState), hipHostMallocPortable) != hipSuccess ||
                     hipEventCreateWithFlags(&look[0], hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&look[1], hipEventDisableTiming) != hipSuccess) {
                     pinned = nullptr;

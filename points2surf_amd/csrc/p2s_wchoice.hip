@@ -1587,9 +1587,9 @@ int wc_build_plan(p2s_cloud_s *c) {
     for (int L = 1; L <= n_levels; ++L) offs[L] = offs[L - 1] + lvl_off[L];
     const size_t lvl_at = blob.size();
     blob.insert(blob.end(), offs.begin(), offs.end());
-    if (hipMalloc(&c->wc_plan, blob.size() * 4) != hipSuccess) {
-        (void)hipGetLastError();
-        p2s_set_error("weighted sub-sample: hipMalloc of the summation plan failed");
+    c->wc_plan = (int *)p2s_pool_alloc(c->device, blob.size() * 4);
+    if (!c->wc_plan) {
+        p2s_set_error("weighted sub-sample: device allocation of the summation plan failed");
         return P2S_ENOMEM;
     }
     P2S_HIP_CHECK(hipMemcpy(c->wc_plan, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
@@ -1667,6 +1667,7 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     if (nq == 0) return P2S_OK;
     P2S_HIP_CHECK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
+    p2s_cloud_note_stream(c, s);
     int rc = wc_build_plan(c);
     if (rc) return rc;
     int K = 1024;

@@ -46,6 +46,13 @@ def upload(array, device):
     return torch.from_numpy(np.ascontiguousarray(array)).to(device)
 
 
+def release_scratch(device=None):
+    """give the library's cached device memory (blocks of destroyed cloud handles, volume / iso-surface scratch) back
+    to HIP (p2s_release_scratch)"""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    _lib.check(_lib.load().p2s_release_scratch(int(dev)))
+
+
 class Model:
     """Engine-side model: BN-folded, MFMA-packed weights resident in HBM.
 
@@ -156,6 +163,24 @@ class Cloud:
             self.close()
         except Exception:
             pass
+
+    def index_export(self):
+        """test / diagnostic read-back of the device-built neighbour index: dict with G, lo [3], inv_cell,
+        cell_start [G^3+1], sat [(G+1)^3], sorted_xyz [n,3] float32, sorted_id [n] int32"""
+        G = ctypes.c_int32(0)
+        geom = np.zeros(4, dtype=np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_cloud_index_export(self.handle, ctypes.byref(G), geom.ctypes.data_as(ctypes.c_void_p),
+                                                       None, None, None, _stream_ptr(self.device)))
+            g = int(G.value)
+            cell_start = np.zeros(g ** 3 + 1, dtype=np.int32)
+            sat = np.zeros((g + 1) ** 3, dtype=np.int32)
+            srt = np.zeros((self.n, 4), dtype=np.float32)
+            _lib.check(self.lib.p2s_cloud_index_export(
+                self.handle, None, None, cell_start.ctypes.data_as(ctypes.c_void_p), sat.ctypes.data_as(ctypes.c_void_p),
+                srt.ctypes.data_as(ctypes.c_void_p), _stream_ptr(self.device)))
+        return {'G': g, 'lo': geom[:3].copy(), 'inv_cell': float(geom[3]), 'cell_start': cell_start, 'sat': sat,
+                'sorted_xyz': np.ascontiguousarray(srt[:, :3]), 'sorted_id': np.ascontiguousarray(srt[:, 3]).view(np.int32)}
 
     def query_grid(self, grid_resolution, epsilon):
         """a1 -> q [Q,3] float32 on the device (C order of the voxel index)."""

@@ -84,6 +84,11 @@ def mesh_distances(file_in, file_ref, samples_per_model=10000, seed=0, device=No
             v, f = np.zeros((0, 3)), np.zeros((0, 3), np.int64)
         if v.shape[0] == 0 or f.shape[0] == 0:
             return -1.0, -1.0, -1.0, -1.0
+        f = np.asarray(f)
+        if f.ndim != 2 or f.shape[1] != 3 or f.min() < 0 or f.max() >= v.shape[0] or not np.isfinite(v).all():
+            # malformed / truncated mesh: the reference's try/except around trimesh ends in (-1, -1, -1, -1)
+            # (source/base/evaluation.py:244-245); never hand out-of-range indices to the device kernels
+            return -1.0, -1.0, -1.0, -1.0
         vt = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev)
         ft = torch.from_numpy(np.ascontiguousarray(f, dtype=np.int32)).to(dev)
         s = sample_surface_even(vt, ft, samples_per_model, rng)

@@ -107,7 +107,15 @@ def query_range(n_queries, world, rank):
 def skip_queries(cloud, rng_dev, cfg, queries, sub_sample_size, chunk=4096):
     """advance the RNG stream past ``queries`` ([m,3] device tensor, in order) without inference"""
     m = int(queries.shape[0])
-    if m == 0 or cfg.get('fixed_subsample'):      # fixed: every query re-seeds the generator, nothing carries over
+    if m == 0:
+        return
+    # fixed_subsample: every query re-seeds the generator, nothing carries over -- but ``rng.seed(42)`` sits INSIDE the
+    # N >= sub_sample_size branch (reference source/base/utils.py:210-211): a cloud with fewer points still shuffles
+    # shape.pts from the dataset-wide stream, also in fixed mode (the NULL-ids skip takes the shuffle + pad path)
+    if cfg.get('fixed_subsample') and cloud.n >= sub_sample_size:
+        return
+    if cloud.n < sub_sample_size:
+        rng_dev.skip(cloud, sub_sample_size, n_queries=m)
         return
     if cfg.get('uniform_subsample'):
         rng_dev.skip(cloud, sub_sample_size, n_queries=m)

@@ -20,8 +20,22 @@ _FC4_BIAS_SHIFT = {'p2s_max': (6.289174, 2.416443), 'p2s_vanilla': (2.6854432, 4
                    'p2s_large_kNN': (4.9557, 2.6857), 'p2s_regression': (3.7676,), 'p2s_shared_encoder': (-0.2, -3.9804)}
 
 
+# Second synthetic weight set of p2s_vanilla: the same weights with the bias of the SIGN logit moved by the median of
+# that logit over the 128^3 query grid of the abc_minimal test shape (-1.30, measured with oracle/torch_port.py on 500
+# random queries of the grid; the default set is positive for 0.9 % of those queries), so that the decision
+# ``sign logit >= 0`` (reference source/sdf_nn.py:16-21) is close for many queries and a sign-flip count has power.
+_SIGN_BIAS_EXTRA = {'p2s_vanilla_mixed': ('p2s_vanilla', 1.30)}
+
+
 def make_weights(model='p2s_max', seed=1234, net_size_max=1024, output_dim=None):
     """Returns ({name: float32 ndarray} without ``module.`` prefix, cfg dict)."""
+    if isinstance(model, str) and model in _SIGN_BIAS_EXTRA:
+        base, extra = _SIGN_BIAS_EXTRA[model]
+        w, cfg_out = make_weights(base, seed=seed, net_size_max=net_size_max, output_dim=output_dim)
+        b = w['fc4.bias'].copy()
+        b[1] = np.float32(b[1] + np.float32(extra))
+        w['fc4.bias'] = b
+        return w, cfg_out
     cfg = dict(NAMED_MODELS[model]) if isinstance(model, str) else dict(model)
     if output_dim is None:
         output_dim = int(cfg.get('output_dim', 2))
