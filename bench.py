@@ -1,19 +1,23 @@
 #!/usr/bin/env python
 """Headline benchmark: SDF queries/s per GPU, p2s_max, 256^3 query grid (BASELINE.json metric).
 
-A *step* = one complete shape per rank: near-surface query grid of a 256^3 volume -> for every query the
-300-NN patch (fp64-exact), the 1000-point global sub-sample (numpy-legacy MT19937 stream), the
-PointNet encoders + decoder -> SDF.  The workload is the committed ``abc_minimal`` test shape
-(tests/golden/abc_minimal/04_pts/00994122..., 34,693 points, Q = 307,237 queries at 256^3, eps 3) -- the input the
-parity tests pin against the unmodified reference -- with seeded random-init weights (no pretrained weights offline).
-The cloud is resident in HBM when the timed region starts.
+A *step* = one COMPLETE shape per rank, host to host (reference source/points_to_surf_eval.py:358-404 for one shape):
+the cloud starts in host memory -> upload -> neighbour index built on the device (the reference builds a cKDTree,
+source/data_loader.py:40-42) -> near-surface query grid of the 256^3 volume (source/sdf.py:46-79) -> for every query
+the 300-NN patch (fp64-exact), the 1000-point global sub-sample (numpy-legacy MT19937 stream), the PointNet encoders +
+decoder -> SDF -> download to host memory.  A fresh cloud handle per step: nothing is cached between steps.
+The dataset is the three committed ``abc_minimal`` clouds (tests/golden/abc_minimal/04_pts: 59,979 / 86,648 / 34,693
+points; Q = 572 k / 499 k / 307 k queries at 256^3, eps 3) taken round-robin as ONE dataset with one sub-sample stream
+-- the inputs the parity tests pin against the unmodified reference -- with seeded random-init weights (no pretrained
+weights offline).
 
   python bench.py --gpus N --steps K --warmup W [--rng-mode dataset|per_shape]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 N > 1: one process per GPU (``--gpus N`` without a torchrun environment re-executes itself under
 ``torch.distributed.run`` with N ranks; fewer than N visible devices is an error, never a silent 1-GPU run).  The
-dataset is ``N x (W + K)`` copies of the shape in one list; shape i belongs to rank i mod N (weak scaling).
+dataset is ``N x (W + K)`` shapes in one list; shape i belongs to rank i mod N and every rank gets the same cloud in
+the same step (weak scaling).
   --rng-mode dataset (default, exact): ONE sub-sample stream over the whole dataset, as the reference's
       ``--workers 0`` run: every rank also consumes the draws of the shapes it does not own
       (sharding.skip_shape_stream), so every shape's SDF is bit-identical to the single-process run.
@@ -21,10 +25,13 @@ dataset is ``N x (W + K)`` copies of the shape in one list; shape i belongs to r
       reference from the second shape on).
 The per-shape SDF arrays are gathered to rank 0 over RCCL at the end of every step (sharding.gather_variable, the
 path's only exchange).  Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (p2s_chain_kernel,
-MFMA-bound) from HIP events recorded on the launch stream during the timed steps; ``cpu_baseline`` times the
-torch-CPU port of the reference's path (oracle/torch_port.py) on this box's host cores on a bounded sample;
-``self_check`` (after the timed region, rank 0) compares a fresh device run of the same shape with that port's
-output and with the full-grid golden written by the unmodified reference.
+MFMA-bound) from HIP events recorded on the launch stream during the timed steps; ``cloud_resident`` repeats the r02
+measurement (cloud handle + query grid kept across steps, SDF left on the device) beside the headline; ``secondary``
+(N = 1) carries one complete-shape pass each of p2s_vanilla fp32 and of p2s_max with the split bf16x3 encoder
+(BASELINE configs[3]) on the test shape, each checked over the full grid against the reference's golden;
+``cpu_baseline`` times the torch-CPU port of the reference's path (oracle/torch_port.py) on this box's host cores on
+a bounded sample; ``self_check`` (after the timed region, rank 0) runs the three clouds as one dataset from a fresh
+stream and compares every query with the goldens written by the unmodified reference.
 """
 import argparse
 import json
@@ -46,9 +53,14 @@ BYTES_PER_QUERY = 15620             # minimal HBM traffic per query, SURVEY.md 8
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md
 GRID_RES, EPSILON = 256, 3
 SEED_DATA = 40938661
-FIXTURE_SHAPE = '00994122_57d9d4755722f9d2d7436f0a_trimesh_000'
-FIXTURE_CLOUD = os.path.join(REPO, 'tests', 'golden', 'abc_minimal', '04_pts', FIXTURE_SHAPE + '.xyz.npy')
-GOLDEN_FMT = os.path.join(REPO, 'tests', 'golden', 'ref_rec_p2s_max_testset_grid%d.npz')      # 128, 256 (default), 512
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+ABC3 = ['00011084_fddd53ce45f640f3ab922328_trimesh_019', '00016513_3d6966cd42eb44ab8f4224f2_trimesh_053',
+        '00994122_57d9d4755722f9d2d7436f0a_trimesh_000']          # tests/golden/abc_minimal/abc3.txt (dataset order)
+FIXTURE_SHAPE = ABC3[2]                                           # abc_minimal/testset.txt
+
+
+def cloud_path(name):
+    return os.path.join(GOLDEN, 'abc_minimal', '04_pts', name + '.xyz.npy')
 
 
 def parse():
@@ -56,8 +68,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--dataset', choices=['abc3', 'fixture'], default=None,
+                    help='abc3 (default at 256^3): the three abc_minimal clouds round-robin; fixture: the test shape only')
     ap.add_argument('--points', type=int, default=0,
-                    help='0 (default): the abc_minimal fixture cloud; > 0: synthetic cloud of that many points')
+                    help='> 0: a synthetic cloud of that many points instead of the abc_minimal clouds (no golden check)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='target CPU-baseline duration (0 = skip)')
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--rng-mode', choices=['dataset', 'per_shape'], default='dataset')
@@ -66,6 +80,7 @@ def parse():
                          '(--bf16 or --bf16 1); split precision with 2 / 3 bf16 pieces per operand (--bf16 2 / 3)')
     ap.add_argument('--res', type=int, default=GRID_RES,
                     help='query-grid resolution; the headline metric is quoted at 256 (other values: BASELINE configs 1/4)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the p2s_vanilla / bf16x3 secondary passes')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
     return ap.parse_args()
 
@@ -90,11 +105,21 @@ def cpu_baseline(w, cfg, cloud, queries, target_seconds, grid_res=GRID_RES):
     t0 = time.time()
     sdf = port.infer_queries(cloud, queries[:n], rng, batch=500)
     dt = time.time() - t0
+    ref_note = None
+    try:
+        with open(os.path.join(GOLDEN, 'meta_sizes.json')) as f:
+            m = json.load(f)['ref_rec_p2s_max_testset_grid256']
+        ref_note = ('the UNMODIFIED reference (points_to_surf_eval, torch CPU, %d threads, build container) made %.1f '
+                    'queries/s on the full 256^3 grid of the test shape when it wrote the golden '
+                    '(tests/golden/meta_sizes.json)' % (m['threads'], m['reference_queries_per_s']))
+    except Exception:
+        pass
     rec = {'value': n / dt, 'unit': 'queries/s', 'cores': int(threads), 'kind': 'port',
-           'sample': 'first %d of the same %d^3-grid queries (kNN cKDTree + RandomState sub-sample + torch-CPU '
-                     'forward, batch 500), %.1f s' % (n, grid_res, dt),
+           'sample': 'first %d of the %d^3-grid queries of the dataset\'s first shape (kNN cKDTree + RandomState '
+                     'sub-sample + torch-CPU forward, batch 500), %.1f s' % (n, grid_res, dt),
            'host_cpus': os.cpu_count(), 'torch': torch.__version__,
-           'torch_threads': int(threads), 'blas': 'mkl' if torch.backends.mkl.is_available() else 'other'}
+           'torch_threads': int(threads), 'blas': 'mkl' if torch.backends.mkl.is_available() else 'other',
+           'reference_itself': ref_note}
     return rec, sdf
 
 
@@ -113,6 +138,92 @@ def respawn(args):
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def complete_shape(engine, model, pts_host, rng, res, chunk, ev=None):
+    """ONE complete shape, host to host: upload + index build + query grid + inference + download.  A fresh cloud handle
+    (no cached grid).  ``ev``: optional dict of lists collecting (cloud build, download) milliseconds from events.
+    Returns (SDF in host memory, the device tensor it was copied from)."""
+    import torch
+    e0 = e1 = e1b = e2 = e3 = None
+    if ev is not None:
+        e0, e1, e1b, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(5))
+        e0.record()
+    cloud = engine.Cloud(pts_host)                  # H2D + p2s_cloud_create (bbox, histogram, SAT, counting sort)
+    if ev is not None:
+        e1.record()
+    nq = cloud.count_queries(res, EPSILON)          # a1: voxelise, dilate, count (one host sync), compact
+    if ev is not None:
+        e1b.record()
+    sdf, _ = engine.infer_shape(model, cloud, rng, res, EPSILON, chunk=chunk, want_queries=False, n_queries=nq)
+    if ev is not None:
+        e2.record()
+    out = sdf.cpu()                                 # D2H; synchronises
+    if ev is not None:
+        e3.record()
+        e3.synchronize()
+        ev.setdefault('ms_cloud', []).append(e0.elapsed_time(e1))
+        ev.setdefault('ms_grid', []).append(e1.elapsed_time(e1b))
+        ev.setdefault('ms_d2h', []).append(e2.elapsed_time(e3))
+    cloud.close()
+    return out, sdf
+
+
+def golden_check(engine, parity, model, w, cfg, shapes, res, sdfs, tol, bf16):
+    """every query of the run ``sdfs`` (one array per shape, one stream from SEED_DATA in dataset order) against the
+    goldens the unmodified reference wrote.  Signs: a flipped sign is accepted as an fp32 TIE only if BOTH the device's
+    own sign logit and the CPU port's sign logit for that query (same inputs) lie within parity.TIE_LOGIT of zero."""
+    rec = {'shapes': [], 'queries': 0, 'max_abs_dsdf': 0.0, 'max_abs_diff_unmasked': 0.0, 'sign_flips': 0,
+           'sign_flips_not_ties': 0, 'flipped': []}
+    ok = True
+    for si, (name, pts, ref) in enumerate(shapes):
+        if ref is None:
+            rec['shapes'].append({'shape': name[:8], 'golden': None})
+            continue
+        sdf = sdfs[si]
+        if ref.shape != sdf.shape:
+            rec['shapes'].append({'shape': name[:8], 'error': 'shape %s vs golden %s' % (sdf.shape, ref.shape)})
+            ok = False
+            continue
+        cmp_ = parity.compare_sdf(sdf, ref)
+        fl = cmp_['flipped']
+        unmasked = float(np.abs(sdf - ref).max()) if sdf.size else 0.0
+        srec = {'shape': name[:8], 'queries': int(ref.shape[0]), 'max_abs_dsdf': cmp_['max_abs_dsdf'],
+                'max_abs_diff_unmasked': unmasked, 'sign_flips': int(fl.size)}
+        rec['queries'] += int(ref.shape[0])
+        rec['max_abs_dsdf'] = max(rec['max_abs_dsdf'], cmp_['max_abs_dsdf'])
+        rec['max_abs_diff_unmasked'] = max(rec['max_abs_diff_unmasked'], unmasked)
+        rec['sign_flips'] += int(fl.size)
+        not_ties = int(fl.size)
+        if 0 < fl.size <= 8 and not bf16:
+            not_ties = 0
+            # position a stream at this shape's first draw: skip the shapes before it
+            for j in fl:
+                rng = engine.Rng(SEED_DATA)
+                for name2, pts2, _ in shapes[:si]:
+                    c2 = engine.Cloud(pts2)
+                    from points2surf_amd import sharding
+                    sharding.skip_shape_stream(c2, rng, cfg, res, EPSILON, model.sub_sample_size)
+                    c2.close()
+                cloud = engine.Cloud(pts)
+                q_all = cloud.query_grid(res, EPSILON)
+                patch, sub, one = engine.query_inputs(model, cloud, rng, q_all, int(j))
+                lg_dev = float(model.forward(patch, sub, one)[0][0, 1])
+                from oracle.torch_port import TorchPort
+                lg_cpu = float(TorchPort(w, cfg).forward(patch.cpu().numpy(), sub.cpu().numpy(), one.cpu().numpy())[0, 1])
+                tie = abs(lg_dev) < parity.TIE_LOGIT and abs(lg_cpu) < parity.TIE_LOGIT
+                not_ties += 0 if tie else 1
+                rec['flipped'].append({'shape': name[:8], 'query': int(j), 'sdf': float(sdf[j]), 'ref': float(ref[j]),
+                                       'sign_logit_device': lg_dev, 'sign_logit_cpu_port': lg_cpu, 'fp32_tie': bool(tie)})
+                cloud.close()
+        elif fl.size:
+            rec['flipped'] += [{'shape': name[:8], 'query': int(j), 'sdf': float(sdf[j]), 'ref': float(ref[j])} for j in fl[:16]]
+        srec['sign_flips_not_ties'] = not_ties
+        rec['sign_flips_not_ties'] += not_ties
+        rec['shapes'].append(srec)
+        if cmp_['max_abs_dsdf'] > tol or (not bf16 and not_ties):
+            ok = False
+    return rec, ok
 
 
 def main():
@@ -147,13 +258,26 @@ def main():
         cfg = dict(cfg, encoder_bf16=int(args.bf16))
     model = engine.Model(w, cfg)
     model.set_profiling(True)
+
+    # ---- the dataset: (name, host cloud, golden SDF or None) in dataset order ---------------------------------
+    dataset = args.dataset or ('abc3' if args.res == GRID_RES else 'fixture')
+    shapes = []
     if args.points > 0:
-        pts = synth.make_cloud(args.points, seed=1000)
+        shapes.append(('synthetic%d' % args.points, synth.make_cloud(args.points, seed=1000), None))
         workload = 'synthetic %d-point cloud' % args.points
+        golden_file = None
     else:
-        pts = np.ascontiguousarray(np.load(FIXTURE_CLOUD)[:, :3], dtype=np.float32)
-        workload = 'abc_minimal test shape %s (%d points; tests/golden/abc_minimal)' % (FIXTURE_SHAPE, pts.shape[0])
-    cloud = engine.Cloud(pts)
+        names = ABC3 if dataset == 'abc3' else [FIXTURE_SHAPE]
+        golden_file = os.path.join(GOLDEN, 'ref_rec_p2s_max_%s_grid%d.npz' % ('abc3' if dataset == 'abc3' else 'testset', args.res))
+        g = np.load(golden_file) if os.path.isfile(golden_file) else None
+        if g is None and dataset == 'fixture' and args.res == 32:       # the stage-wise fixture of oracle/make_golden.py
+            golden_file = os.path.join(GOLDEN, 'ref_p2s_max_grid32.npz')
+            g = {'rec_0': np.load(golden_file)['sdf_full']}
+        for i, n in enumerate(names):
+            pts = np.ascontiguousarray(np.load(cloud_path(n))[:, :3], dtype=np.float32)
+            shapes.append((n, pts, None if g is None else g['rec_%d' % i]))
+        workload = ('abc_minimal clouds %s (%s points; tests/golden/abc_minimal) round-robin as one dataset'
+                    % (', '.join(n[:8] for n in names), ' / '.join(str(s[1].shape[0]) for s in shapes)))
     n_sub = model.sub_sample_size
     rng = engine.Rng(SEED_DATA)
 
@@ -163,10 +287,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # dataset = world x (warmup + steps) copies of the shape; shape i -> rank i mod world
-    def run_step(step):
+    # dataset = world x (warmup + steps) shapes; shape i -> rank i mod world; all ranks work on the same cloud in a step
+    ev = {}
+
+    def run_step(step, timed):
         """all shapes of dataset round ``step``: mine is inferred, the others' draws are skipped (exact mode)"""
-        out = None
+        out = dev = None
+        pts = shapes[step % len(shapes)][1]
         for r in range(world):
             shape_ind = step * world + r
             if args.rng_mode == 'per_shape':
@@ -175,27 +302,31 @@ def main():
                 key = np.random.RandomState((SEED_DATA + shape_ind) & 0xffffffff).get_state()[1]   # init_genrand
                 rng.set_state(key, 624)
             if r == rank:
-                out, _ = engine.infer_shape(model, cloud, rng, args.res, EPSILON, chunk=args.chunk, want_queries=False)
+                out, dev = complete_shape(engine, model, pts, rng, args.res, args.chunk, ev if timed else None)
             else:
-                sharding.skip_shape_stream(cloud, rng, cfg, args.res, EPSILON, n_sub)
-        return out
+                other = engine.Cloud(pts)            # a rank has to index + voxelise a shape to know its draw count
+                sharding.skip_shape_stream(other, rng, cfg, args.res, EPSILON, n_sub)
+                other.close()
+        return out, dev
 
     sdf = None
     for s in range(args.warmup):
-        sdf = run_step(s)
+        sdf, _ = run_step(s, False)
     barrier()
     t0 = time.time()
     n_queries = 0
     acc = {}
     gathered = 0
+    per_shape_q = {}
     for s in range(args.steps):
-        sdf = run_step(args.warmup + s)
+        sdf, sdf_dev = run_step(args.warmup + s, True)
         n_queries += int(sdf.shape[0])
+        per_shape_q[shapes[(args.warmup + s) % len(shapes)][0][:8]] = int(sdf.shape[0])
         for k, v in model.counters().items():
             acc[k] = acc.get(k, 0) + v
         if world > 1:
             # final gather of the variable-length per-shape SDF to rank 0 (RCCL over xGMI): the only exchange
-            parts = sharding.gather_variable(sdf, dst=0)
+            parts = sharding.gather_variable(sdf_dev, dst=0)
             if rank == 0:
                 gathered += sum(int(p.shape[0]) for p in parts)
     barrier()
@@ -228,7 +359,7 @@ def main():
         # committed under profiles/; they cannot be collected from inside this process
         traffic, traffic_src = None, None
         if not args.bf16:
-            for rnd in ('r02', 'r01'):
+            for rnd in ('r03', 'r02', 'r01'):
                 try:
                     with open(os.path.join(REPO, 'profiles', rnd, 'pmc_summary.json')) as f:
                         ck = json.load(f)['chain_kernel']
@@ -238,16 +369,23 @@ def main():
                     break
                 except Exception:
                     continue
+        stage = {k: acc[k] for k in sorted(acc) if k.startswith('ms_')}
+        stage['ms_cloud'] = float(sum(ev.get('ms_cloud', [])))          # upload + index build (events around engine.Cloud)
+        stage['ms_grid'] = float(sum(ev.get('ms_grid', [])))            # a1 incl. its host sync (the handle is fresh: no cached grid)
+        stage['ms_d2h'] = float(sum(ev.get('ms_d2h', [])))
         out = {
             'metric': 'SDF queries/sec/GPU (p2s_max, %d^3 grid%s)' % (args.res, (', bf16 encoder' if args.bf16 == 1 else ', split bf16x%d encoder' % args.bf16) if args.bf16 else ''),
             'value': value, 'unit': 'queries/s',
             'n_gpus': world if not share else 1, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / max(args.steps, 1) * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': ('bf16' if args.bf16 == 1 else 'bf16x%d' % args.bf16) if args.bf16 else 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': ('bf16' if args.bf16 == 1 else 'bf16x%d' % args.bf16) if args.bf16 else 'f32',
+            'data': 'abc_minimal clouds of the reference repository (committed fixtures); seeded random-init weights' if not args.points else 'synthetic',
             'config': {'workload': 'BASELINE.json configs[%d]: p2s_max, grid_res=%d, eps=3, kNN patch=300 / global ' % ({128: 1, 512: 4}.get(args.res, 2), args.res) +
-                                   'sub=1000, fp32; %s, one shape per rank per step; seeded random-init weights '
-                                   '(Famous set / pretrained weights not available offline)' % workload,
-                       'queries_per_shape_rank0': int(sdf.shape[0]),
+                                   'sub=1000, fp32; %s, one COMPLETE shape per rank per step (host cloud -> upload -> '
+                                   'device index build -> query grid -> inference -> SDF in host memory; fresh handle, '
+                                   'nothing cached); seeded random-init weights (Famous set / pretrained weights not '
+                                   'available offline)' % workload,
+                       'queries_per_shape': per_shape_q,
                        'parallelism': 'shape-sharded x%d' % world + (' (REHEARSAL: all ranks share one GPU, gloo)' if share else ''),
                        'rng_mode': args.rng_mode,
                        'shapes_per_hour': world * args.steps / dt * 3600.0,
@@ -256,48 +394,93 @@ def main():
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'p2s_chain_bf16_kernel' if args.bf16 else 'p2s_chain_kernel', 'launches': int(launches), 'avg_launch_ms': avg_launch_ms,
                          'algorithmic_flop_per_launch': flop_per_launch, 'mfma_passes_per_product': passes,
+                         'whole_step_frac': value / world * FLOP_PER_QUERY * passes / 1e12 / peak,
                          'hbm_algorithmic_GBps': value / world * BYTES_PER_QUERY / 1e9},
-            'stage_ms_rank0': {k: acc[k] for k in sorted(acc) if k.startswith('ms_')},
+            'stage_ms_rank0': stage,
         }
-        # ---- after the timed region: the output of this very workload against the checkers --------------------
-        check = {}
-        rng_chk = engine.Rng(SEED_DATA)
-        sdf_chk, _ = engine.infer_shape(model, cloud, rng_chk, args.res, EPSILON, chunk=args.chunk, want_queries=False)
-        sdf_chk = sdf_chk.cpu().numpy()
+
+        def bail(what, check):
+            out['self_check'] = check
+            print(json.dumps(out), flush=True)
+            raise SystemExit('bench.py self-check FAILED %s: %s' % (what, json.dumps(check)))
+
+        # ---- after the timed region -----------------------------------------------------------------------------
         tol = 0.25 if args.bf16 == 1 else 1e-4      # north_star: SDF within 1e-4 fp32 of the reference (plain bf16: reported only)
-        golden = GOLDEN_FMT % args.res
-        if args.points == 0 and os.path.isfile(golden):
-            ref = np.load(golden)['rec_0']
-            ok = ref.shape == sdf_chk.shape
-            rec = {'file': os.path.relpath(golden, REPO), 'queries': int(ref.shape[0])}
-            if ok:
-                cmp_ = parity.compare_sdf(sdf_chk, ref)
-                fl = cmp_['flipped']
-                rec.update({'max_abs_dsdf': cmp_['max_abs_dsdf'], 'sign_flips': int(fl.size)})
-                if 0 < fl.size <= 8 and not args.bf16:
-                    # sign = (sign logit >= 0): a flip is an fp32 TIE iff the device's own sign logit is within the logit
-                    # accuracy of zero (the reference's answer for such a query depends on its batch composition / threads)
-                    q_all = cloud.query_grid(args.res, EPSILON)
-                    lg = [float(engine.query_logits(model, cloud, engine.Rng(SEED_DATA), q_all, int(j))[1]) for j in fl]
-                    rec['flipped_sign_logits'] = lg
-                    rec['sign_flips_not_ties'] = parity.not_ties(lg)
-                else:
-                    rec['sign_flips_not_ties'] = int(fl.size)
+        check = {}
+        # (1) the three clouds as ONE dataset from a fresh stream, every query against the reference's goldens
+        rng_chk = engine.Rng(SEED_DATA)
+        sdfs = [complete_shape(engine, model, pts, rng_chk, args.res, args.chunk)[0].numpy() for _, pts, _ in shapes]
+        if any(ref is not None for _, _, ref in shapes):
+            rec, ok = golden_check(engine, parity, model, w, cfg, shapes, args.res, sdfs, tol, args.bf16)
+            rec['file'] = os.path.relpath(golden_file, REPO)
             check['vs_reference_golden'] = rec
-            if not ok or rec['max_abs_dsdf'] > tol or (not args.bf16 and rec['sign_flips_not_ties'] != 0):
-                out['self_check'] = check
-                print(json.dumps(out), flush=True)
-                raise SystemExit('bench.py self-check FAILED against the reference golden: %s' % check)
+            if not ok:
+                bail('against the reference golden', check)
+        elif golden_file is not None:
+            check['vs_reference_golden'] = {'file': os.path.relpath(golden_file, REPO), 'missing': True}
+        # (2) the r02 measurement beside the headline: cloud handles + query grids resident, SDF left on the device
+        if world == 1:
+            resident = [engine.Cloud(pts) for _, pts, _ in shapes]
+            rng_res = engine.Rng(SEED_DATA)
+            for c in resident:
+                c.query_grid(args.res, EPSILON)
+            engine.infer_shape(model, resident[0], rng_res, args.res, EPSILON, chunk=args.chunk, want_queries=False)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            nres = 0
+            for c in resident:
+                s_, _ = engine.infer_shape(model, c, rng_res, args.res, EPSILON, chunk=args.chunk, want_queries=False)
+                nres += int(s_.shape[0])
+            torch.cuda.synchronize()
+            dres = time.time() - t1
+            out['cloud_resident'] = {'value': nres / dres, 'unit': 'queries/s', 'shapes': len(resident), 'seconds': dres,
+                                     'note': 'cloud handle + query grid cached across steps, SDF left in HBM (what BENCH_r02 measured)'}
+            for c in resident:
+                c.close()
+        # (3) secondary passes: configs[3]'s model and the fast exact encoder, complete shapes, full-grid checks
+        if world == 1 and not args.no_secondary and not args.bf16 and args.points == 0 and args.res == GRID_RES:
+            sec = {}
+            fixture = np.ascontiguousarray(np.load(cloud_path(FIXTURE_SHAPE))[:, :3], dtype=np.float32)
+            for key, mname, extra in (('p2s_vanilla_fp32', 'p2s_vanilla', {}), ('p2s_max_bf16x3', 'p2s_max', {'encoder_bf16': 3})):
+                w2, cfg2 = synth.make_weights(mname)
+                cfg2 = dict(cfg2, **extra)
+                m2 = engine.Model(w2, cfg2)
+                m2.set_profiling(True)
+                complete_shape(engine, m2, fixture, engine.Rng(SEED_DATA), args.res, args.chunk)       # warm-up
+                torch.cuda.synchronize()
+                r2 = engine.Rng(SEED_DATA)
+                t1 = time.time()
+                s2 = complete_shape(engine, m2, fixture, r2, args.res, args.chunk)[0].numpy()
+                d2 = time.time() - t1
+                cnt = m2.counters()
+                gfile = os.path.join(GOLDEN, 'ref_rec_%s_testset_grid%d.npz' % (mname, args.res))
+                srec = {'value': s2.shape[0] / d2, 'unit': 'queries/s', 'ms_per_step': d2 * 1e3, 'queries': int(s2.shape[0]),
+                        'model': mname, 'dtype': 'bf16x3' if extra else 'f32',
+                        'workload': 'one complete shape (host to host) of the abc_minimal test shape at %d^3' % args.res,
+                        'chain_ms': cnt['ms_chain_stn'] + cnt['ms_chain_main'], 'chain_launches': int(cnt['launches_chain'])}
+                if os.path.isfile(gfile):
+                    ref2 = np.load(gfile)['rec_0']
+                    rec2, ok2 = golden_check(engine, parity, m2, w2, cfg2, [(FIXTURE_SHAPE, fixture, ref2)], args.res, [s2], 1e-4, 0)
+                    rec2['file'] = os.path.relpath(gfile, REPO)
+                    srec['vs_reference_golden'] = {k: rec2[k] for k in ('file', 'queries', 'max_abs_dsdf', 'max_abs_diff_unmasked',
+                                                                        'sign_flips', 'sign_flips_not_ties', 'flipped')}
+                    if not ok2:
+                        check['secondary_' + key] = srec
+                        bail('in the secondary pass ' + key, check)
+                sec[key] = srec
+                m2.close()
+            out['secondary'] = sec
+        # (4) the CPU baseline on the first shape's first queries, and the device against it
         if args.cpu_seconds > 0 and world == 1:
-            q = cloud.query_grid(args.res, EPSILON).cpu().numpy()
-            out['cpu_baseline'], sdf_cpu = cpu_baseline(w, cfg, pts, q, args.cpu_seconds, args.res)
+            c0 = engine.Cloud(shapes[0][1])
+            q = c0.query_grid(args.res, EPSILON).cpu().numpy()
+            c0.close()
+            out['cpu_baseline'], sdf_cpu = cpu_baseline(w, cfg, shapes[0][1], q, args.cpu_seconds, args.res)
             n = sdf_cpu.shape[0]
-            check['vs_cpu_port'] = {'queries': int(n), 'max_abs_dsdf': float(np.abs(sdf_cpu - sdf_chk[:n]).max()),
-                                    'sign_flips': int((np.sign(sdf_cpu) != np.sign(sdf_chk[:n])).sum())}
+            check['vs_cpu_port'] = {'queries': int(n), 'max_abs_dsdf': float(np.abs(sdf_cpu - sdfs[0][:n]).max()),
+                                    'sign_flips': int((np.sign(sdf_cpu) != np.sign(sdfs[0][:n])).sum())}
             if check['vs_cpu_port']['max_abs_dsdf'] > tol or (not args.bf16 and check['vs_cpu_port']['sign_flips']):
-                out['self_check'] = check
-                print(json.dumps(out), flush=True)
-                raise SystemExit('bench.py self-check FAILED against the CPU port: %s' % check)
+                bail('against the CPU port', check)
         elif world == 1:
             out['cpu_baseline'] = None
         out['self_check'] = check

@@ -182,6 +182,14 @@ class Cloud:
         return {'G': g, 'lo': geom[:3].copy(), 'inv_cell': float(geom[3]), 'cell_start': cell_start, 'sat': sat,
                 'sorted_xyz': np.ascontiguousarray(srt[:, :3]), 'sorted_id': np.ascontiguousarray(srt[:, 3]).view(np.int32)}
 
+    def count_queries(self, grid_resolution, epsilon):
+        """a1: compute the query grid of (res, eps) on the handle (kept there for the pipeline) and return its size"""
+        n = ctypes.c_int64(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_query_grid(self.handle, int(grid_resolution), int(epsilon), None, 0,
+                                               ctypes.byref(n), _stream_ptr(self.device)), allow=(_lib.P2S_ECAPACITY,))
+        return int(n.value)
+
     def query_grid(self, grid_resolution, epsilon):
         """a1 -> q [Q,3] float32 on the device (C order of the voxel index)."""
         n = ctypes.c_int64(0)
@@ -334,10 +342,10 @@ class Rng:
         return ids, pts
 
 
-def query_logits(model, cloud, rng, queries, index):
-    """Diagnostic: the decoder logits of query ``index`` of a shape whose queries (in order) are ``queries``, with ``rng``
-    positioned at the shape's first draw -- the stream is advanced past the queries before it (NULL-ids path), then this
-    one query goes through a4..a8.  Used to classify sign flips against a reference as fp32 ties (|sign logit| ~ 0)."""
+def query_inputs(model, cloud, rng, queries, index):
+    """Diagnostic: the network inputs of query ``index`` of a shape whose queries (in order) are ``queries``, with
+    ``rng`` positioned at the shape's first draw -- the stream is advanced past the queries before it (NULL-ids path),
+    then a4..a6 for this one query.  Returns (patch_ps [1,k,3], sub_ms [1,n,3], query [1,3]) device tensors."""
     n = model.sub_sample_size
     q = _f32c(queries, model.device).reshape(-1, 3)
     if index > 0:
@@ -351,19 +359,25 @@ def query_logits(model, cloud, rng, queries, index):
     else:
         _, sub = rng.subsample_weighted(cloud, one, n)
     _, patch, _ = cloud.knn_patch(one, model.points_per_patch, want_ids=False)
-    logits, _ = model.forward(patch, sub.reshape(1, n, 3), one)
+    return patch, sub.reshape(1, n, 3), one
+
+
+def query_logits(model, cloud, rng, queries, index):
+    """Diagnostic: the decoder logits of that query (see query_inputs).  Used to classify sign flips against a
+    reference as fp32 ties (|sign logit| ~ 0)."""
+    patch, sub, one = query_inputs(model, cloud, rng, queries, index)
+    logits, _ = model.forward(patch, sub, one)
     return logits[0]
 
 
-def infer_shape(model, cloud, rng, grid_resolution, epsilon, q_begin=0, q_end=-1, chunk=0, want_queries=True):
-    """Fused per-shape pipeline (p2s_infer_shape).  Returns (sdf [n] device tensor, q [n,3] or None)."""
+def infer_shape(model, cloud, rng, grid_resolution, epsilon, q_begin=0, q_end=-1, chunk=0, want_queries=True,
+                n_queries=None):
+    """Fused per-shape pipeline (p2s_infer_shape).  Returns (sdf [n] device tensor, q [n,3] or None).
+    ``n_queries``: the size of the query grid if the caller already asked for it (Cloud.count_queries)."""
     dev = model.device
     lib = model.lib
-    n = ctypes.c_int64(0)
     with torch.cuda.device(dev):
-        _lib.check(lib.p2s_query_grid(cloud.handle, int(grid_resolution), int(epsilon), None, 0, ctypes.byref(n),
-                                      _stream_ptr(dev)), allow=(_lib.P2S_ECAPACITY,))
-        Q = n.value
+        Q = cloud.count_queries(grid_resolution, epsilon) if n_queries is None else int(n_queries)
         qe = Q if q_end < 0 else q_end
         nq = max(qe - q_begin, 0)
         sdf = torch.empty((max(nq, 1),), dtype=torch.float32, device=dev)

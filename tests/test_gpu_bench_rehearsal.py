@@ -26,5 +26,27 @@ def test_two_ranks_on_one_gpu(mode):
     assert len(lines) == 1, r.stdout[-1500:]                      # rank 0 alone prints
     d = json.loads(lines[0])
     assert d['config']['rng_mode'] == mode and 'REHEARSAL' in d['config']['parallelism'] and d['n_gpus'] == 1
-    assert d['config']['queries_per_shape_rank0'] == 2976 and d['value'] > 0 and d['steps'] == 2
+    assert d['config']['queries_per_shape'] == {'00994122': 2976} and d['value'] > 0 and d['steps'] == 2
     assert d['roofline']['launches'] > 0 and 'cpu_baseline' not in d
+    assert d['stage_ms_rank0']['ms_cloud'] > 0 and d['stage_ms_rank0']['ms_grid'] > 0      # fresh handle per step
+    g = d['self_check']['vs_reference_golden']
+    assert g['queries'] == 2976 and g['sign_flips'] == 0 and g['max_abs_dsdf'] < 1e-4
+
+
+def test_eight_ranks_three_clouds_at_the_real_world_size():
+    """the control flow SCALE will run -- 8 ranks, the three abc_minimal clouds round-robin as one
+    dataset with the exact dataset-wide stream (7 skipped shapes per rank and step), gather to rank 0 -- rehearsed with
+    the ranks sharing this GPU over gloo; rank 0's self-check compares all three clouds with the reference's golden."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['P2S_BENCH_SHARE_GPU'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--backend', 'gloo', '--steps', '3',
+                        '--warmup', '1', '--res', '64', '--dataset', 'abc3'], env=env, capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    lines = [l for l in r.stdout.split('\n') if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert 'x8' in d['config']['parallelism'] and len(d['config']['queries_per_shape']) == 3
+    g = d['self_check']['vs_reference_golden']
+    assert g['file'].endswith('ref_rec_p2s_max_abc3_grid64.npz') and len(g['shapes']) == 3
+    assert g['sign_flips'] == 0 and g['max_abs_dsdf'] < 1e-4 and g['queries'] == sum(d['config']['queries_per_shape'].values())
