@@ -276,21 +276,26 @@ int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int64_t n, int 
 /* ------------------------------------------------------------------------------------------
  * "next" row: iso-surface of the clamped volume at level 0 -- the step the reference hands to
  * scikit-image, `measure.marching_cubes_lewiner(volume, 0)` (reference source/sdf.py:211-215) -- followed by the
- * vertex transform ((v + 0.5) / res - 0.5) * 2 (:223, model_space != 0) and trimesh.repair.fix_inversion
- * (:224-225, fix_inversion != 0: faces are flipped when the signed volume is negative; *inverted reports it).
- * Marching cubes with the asymptotic decider on ambiguous faces (watertight; scikit-image's Lewiner tables are not
- * available offline, so its exact vertex / face counts are unpinned -- see DESIGN.md).  vol_dev [res]^3 float32,
- * C order; verts_out_dev [cap_verts][3] float32 (index coordinates, or model space), faces_out_dev
- * [cap_faces][3] int32.  *n_verts / *n_faces always receive the full counts; P2S_ECAPACITY if a capacity is too
- * small (call with capacities 0 to size the buffers).  Synchronises `stream`.  Output order is deterministic.
+ * vertex transform ((v + 0.5) / res - 0.5) * 2 (:223, float32 arithmetic like numpy; model_space != 0) and
+ * trimesh.repair.fix_inversion (:224-225, fix_inversion != 0: faces are flipped when the signed volume is negative;
+ * *inverted reports it).
+ * The algorithm is the one scikit-image 0.18.3 runs: Lewiner et al. 2003 -- case / face-test / interior-test look-up
+ * tables, tunnel tilings, centre vertex --, "inside" = value > 0, vertices interpolated with the weights
+ * 1 / (eps + |value|), every face reversed (gradient_direction='descent').  The mesh equals scikit-image's vertex
+ * position for vertex position and triangle for triangle (pinned on the reference's volumes); only the
+ * ORDER of vertices and faces is this library's (grid points / cells in C order).
+ * vol_dev [res]^3 float32, C order; verts_out_dev [cap_verts][3] float32 (array-index coordinates, or model space),
+ * faces_out_dev [cap_faces][3] int32.  *n_verts / *n_faces always receive the full counts; P2S_ECAPACITY if a capacity
+ * is too small (call with capacities 0 to size the buffers).  Synchronises `stream`.
  * ------------------------------------------------------------------------------------------ */
 int p2s_marching_cubes(const float *vol_dev, int grid_res, float *verts_out_dev, int64_t cap_verts,
                        int32_t *faces_out_dev, int64_t cap_faces, int64_t *n_verts, int64_t *n_faces,
                        int model_space, int fix_inversion, int *inverted, int device, void *stream);
-/* the generated triangulation table (host): configuration cfg = corner signs (bits 0-7, corner i at
- * (i & 1, i >> 1 & 1, i >> 2 & 1)) | face decisions << 8 (bit f = axis * 2 + side: inside corners connected);
- * edges36: cube edge ids (axis * 4 + u + 2 v), 3 per triangle, -1 padded */
-int p2s_mc_table_entry(int cfg, int32_t *n_tri, int32_t *edges36);
+/* single-cube diagnostic, host arithmetic (the decision code the kernels run): values8 = the cube's values minus the
+ * level in Lewiner's corner order (0 (0,0,0) 1 (1,0,0) 2 (1,1,0) 3 (0,1,0) 4 (0,0,1) 5 (1,0,1) 6 (1,1,1) 7 (0,1,1) as
+ * x, y, z).  *row = the selected row of the tiling table (-1: none), edges36 = its cube edge ids, 3 per triangle,
+ * 12 = the centre vertex, -1 padded */
+int p2s_mc_cell(const float *values8, int32_t *row, int32_t *n_tri, int32_t *edges36);
 
 /* ------------------------------------------------------------------------------------------
  * "next" row: mesh metrics (reference source/base/evaluation.py:222-305): even surface sampling

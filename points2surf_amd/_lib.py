@@ -66,7 +66,7 @@ PROTOTYPES = {
                                ctypes.POINTER(ctypes.c_int32), c_void_p]),
     'p2s_marching_cubes': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, ctypes.POINTER(c_int64),
                                    ctypes.POINTER(c_int64), c_int, c_int, ctypes.POINTER(c_int), c_int, c_void_p]),
-    'p2s_mc_table_entry': (c_int, [c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    'p2s_mc_cell': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), c_void_p]),
     'p2s_rng_random_sample': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     'p2s_mesh_sample_surface': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                         ctypes.POINTER(ctypes.c_double), c_int, c_void_p]),
