@@ -29,6 +29,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef P2S_BF16_MT
 #define P2S_BF16_MT 64
 #endif
+#ifndef P2S_BF16_HOLD
+#define P2S_BF16_HOLD 1      // split modes: pieces whose conv3 A fragments stay in registers (the rest: LDS per k-step)
+#endif
 constexpr int MT = P2S_BF16_MT;  // points per tile (64 or 128: larger tiles halve the L2 weight stream of conv3)
 constexpr int NB = MT / 32;      // 32-row blocks per tile
 constexpr int PPL = MT / 64;     // points per lane in the first layer
@@ -123,14 +126,17 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
     // piece q of a weight array sits args.piece_stride halfs (per-item W1': args.w1_piece_stride) behind piece 0
     const unsigned short *w1p = reinterpret_cast<const unsigned short *>(br.w1) + (long long)item * br.w1_item_stride;
     const long long ps = args.piece_stride, ps1 = br.w1_item_stride ? args.w1_piece_stride : args.piece_stride;
-    __amdgpu_buffer_rsrc_t rs0b[NS], rs1[NS], rs2[NS], rs3[NS];
-#pragma unroll
-    for (int q = 0; q < NS; ++q) {
-        rs0b[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(reinterpret_cast<const unsigned short *>(br.w0b) + q * ps), 0, 4096 * 2, 0x00020000);
-        rs1[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(w1p + q * ps1), 0, 4096 * 2, 0x00020000);
-        rs2[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(reinterpret_cast<const unsigned short *>(br.w2) + q * ps), 0, 8192 * 2, 0x00020000);
-        rs3[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(reinterpret_cast<const unsigned short *>(br.w3) + q * ps), 0, 128 * 1024 * 2, 0x00020000);
-    }
+    // ONE descriptor per layer spanning all pieces; piece q is selected through the scalar offset (q * stride bytes):
+    // 4 descriptors instead of 4 * NS (12 descriptors = 48 SGPRs spilled into VGPR lanes and were re-read in the loops)
+    const int pb = (int)(ps * 2), pb1 = (int)(ps1 * 2);          // piece strides in bytes
+    const __amdgpu_buffer_rsrc_t rs0b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short *>(reinterpret_cast<const unsigned short *>(br.w0b)), 0, (NS - 1) * pb + 4096 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(w1p), 0,
+                                                                          (NS - 1) * pb1 + 4096 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short *>(reinterpret_cast<const unsigned short *>(br.w2)), 0, (NS - 1) * pb + 8192 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short *>(reinterpret_cast<const unsigned short *>(br.w3)), 0, (NS - 1) * pb + 128 * 1024 * 2, 0x00020000);
     const int lane16 = lane * 16;
 
     float cx = 0.f, cy = 0.f, cz = 0.f;
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
                 for (int kb = 0; kb < 4; ++kb) {
                     u32x4 b[NS];
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) b[q] = bufld(rs0b[q], lane16, (nt * 4 + kb) * 1024);
+                    for (int q = 0; q < NS; ++q) b[q] = bufld(rs0b, lane16, q * pb + (nt * 4 + kb) * 1024);
 #pragma unroll
                     for (int r = 0; r < NB / 2; ++r)
 #pragma unroll
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
                 for (int kb = 0; kb < 4; ++kb) {
                     u32x4 b[NS];
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) b[q] = bufld(rs1[q], lane16, (nt * 4 + kb) * 1024);
+                    for (int q = 0; q < NS; ++q) b[q] = bufld(rs1, lane16, q * pb1 + (nt * 4 + kb) * 1024);
 #pragma unroll
                     for (int r = 0; r < NB / 2; ++r)
 #pragma unroll
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
             for (int kb = 0; kb < 4; ++kb) {
                 u32x4 b[NS];
 #pragma unroll
-                for (int q = 0; q < NS; ++q) b[q] = bufld(rs2[q], lane16, (wave * 4 + kb) * 1024);
+                for (int q = 0; q < NS; ++q) b[q] = bufld(rs2, lane16, q * pb + (wave * 4 + kb) * 1024);
 #pragma unroll
                 for (int r = 0; r < NB; ++r)
 #pragma unroll
@@ -270,10 +276,15 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
         }
         __syncthreads();
         // ---- conv3 (128 -> 1024) + max over the 64 points: wave w owns column tiles [8w, 8w+8) ----
+        // The A fragments of the first HOLD pieces stay in registers for all 8 column tiles (64 VGPRs per piece); the
+        // other pieces are re-read from LDS in every k-step (conflict-free 16-byte reads, 2 x (NS - HOLD) per 2 NS (NS+1)/2
+        // MFMAs).  Holding all three pieces of the split mode needs 192 VGPRs for A alone and spilled (r02: 48 B/lane,
+        // 4.9x the algorithmic write traffic).
         {
-            u32x4 af[NS][NB][8];
+            constexpr int HOLD = (NS == 1) ? 1 : ((P2S_BF16_HOLD < NS) ? P2S_BF16_HOLD : NS);
+            u32x4 af[HOLD > 0 ? HOLD : 1][NB][8];
 #pragma unroll
-            for (int p = 0; p < NS; ++p)
+            for (int p = 0; p < HOLD; ++p)
 #pragma unroll
                 for (int r = 0; r < NB; ++r)
 #pragma unroll
@@ -288,13 +299,19 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
                 for (int kb = 0; kb < 8; ++kb) {
                     u32x4 b[NS];
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) b[q] = bufld(rs3[q], lane16, soff + kb * 1024);
+                    for (int q = 0; q < NS; ++q) b[q] = bufld(rs3, lane16, q * pb + soff + kb * 1024);
+                    u32x4 a[NS][NB];
+#pragma unroll
+                    for (int p = 0; p < NS; ++p)
+#pragma unroll
+                        for (int r = 0; r < NB; ++r)
+                            a[p][r] = (p < HOLD) ? af[p < HOLD ? p : 0][r][kb] : lds_a(bufB + p * SB, HB, 32 * r, kb, lane);
 #pragma unroll
                     for (int r = 0; r < NB; ++r)
 #pragma unroll
                         for (int p = NS - 1; p >= 0; --p)
 #pragma unroll
-                            for (int q = NS - 1 - p; q >= 0; --q) acc[r] = mfma_bf16(af[p][r][kb], b[q], acc[r]);
+                            for (int q = NS - 1 - p; q >= 0; --q) acc[r] = mfma_bf16(a[p][r], b[q], acc[r]);
                 }
                 float m = acc[0][0];
 #pragma unroll
