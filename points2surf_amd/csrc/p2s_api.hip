@@ -177,6 +177,7 @@ int p2s_model_destroy(p2s_model_t m) {
     for (auto &ev : m->evpool)
         if (ev) (void)hipEventDestroy(ev);
     if (m->aux) (void)hipStreamDestroy(m->aux);
+    if (m->prep) (void)hipStreamDestroy(m->prep);
     delete m;
     return P2S_OK;
 }

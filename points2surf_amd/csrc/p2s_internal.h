@@ -13,7 +13,9 @@ struct PipeBuffers {
     float *qrot[2] = {};            // [C][3]   rotated query points (GT-query pass)
     double *rot[2] = {};            // [C][9]   per-query rotation (GT-query pass)
     hipEvent_t ready[2] = {};       // data path of the buffer finished (aux stream)
-    hipEvent_t freed[2] = {};       // encoders finished reading the buffer (main stream)
+    hipEvent_t freed[2] = {};       // the gather has read the sub-sample ids of the buffer (prep stream)
+    hipEvent_t prepped[2] = {};     // kNN patch + gathered sub-sample of the buffer are complete (prep stream)
+    hipEvent_t done[2] = {};        // encoders finished reading the buffer (main stream)
     hipEvent_t grid = nullptr;
     int32_t *knn_ids[2] = {};       // [C][k]   } only for clouds with fewer points than the sub-sample
     int32_t *perm[2] = {};          // [C][N]   } (shape.pts is shuffled in place by every query)
@@ -42,6 +44,7 @@ struct p2s_model_s {
     p2s_counters counters = {};
     // auxiliary stream: the data path (kNN, sub-sample) of chunk i+1, i+2 overlaps the encoders of chunk i
     hipStream_t aux = nullptr;     // high-priority stream of the sub-sample generator
+    hipStream_t prep = nullptr;    // high-priority stream of kNN + gather of chunk i+1 (runs under the encoders of chunk i)
     bool overlap = true;
     PipeBuffers pipe;
     int fault_chunk = -1;          // test hook (p2s_debug_fault_chunk): fail with P2S_EHIP before this chunk

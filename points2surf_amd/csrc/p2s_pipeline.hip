@@ -30,6 +30,8 @@ void p2s_pipe_free(p2s_model_s *m) {
         if (b.rot[i]) (void)hipFree(b.rot[i]);
         if (b.ready[i]) (void)hipEventDestroy(b.ready[i]);
         if (b.freed[i]) (void)hipEventDestroy(b.freed[i]);
+        if (b.prepped[i]) (void)hipEventDestroy(b.prepped[i]);
+        if (b.done[i]) (void)hipEventDestroy(b.done[i]);
     }
     if (b.grid) (void)hipEventDestroy(b.grid);
     b = PipeBuffers();
@@ -52,7 +54,9 @@ int pipe_reserve(p2s_model_s *m, int C, int k, int n, bool small) {
              (!small || (hipMalloc(&b.knn_ids[i], (size_t)C * k * 4) == hipSuccess &&
                          hipMalloc(&b.perm[i], (size_t)C * n * 4) == hipSuccess)) &&
              hipEventCreateWithFlags(&b.ready[i], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&b.freed[i], hipEventDisableTiming) == hipSuccess;
+             hipEventCreateWithFlags(&b.freed[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&b.prepped[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&b.done[i], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) {
         (void)hipGetLastError();
@@ -206,8 +210,22 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, hi));
     }
     hipStream_t sa = m->overlap ? m->aux : s;
+    // OPT-IN (P2S_PREP_STREAM=1): kNN + gather of chunk i+1 on a third stream, under the encoders of chunk i.  Measured
+    // (r03, 3 clouds at 256^3): 177.6 k vs 177.3 k queries/s -- the 149 ms of kNN per 1.38 M queries move INTO the
+    // encoder launches one for one (ms_chain_stn 3702 -> 3849): a single-wave, LDS-latency-bound kNN workgroup that takes
+    // a workgroup slot of an MFMA-saturated CU costs that CU the same time it would have cost alone.  Off by default so
+    // that the encoder launch durations (roofline) are those of the kernel alone.  The small-cloud path and the
+    // GT-query pass stay in program order on the main stream either way.
+    const bool prep_overlap = m->overlap && getenv("P2S_PREP_STREAM") && c->d.n >= n && !r_rot;
+    if (prep_overlap && !m->prep) {
+        int lo = 0, hi = 0;
+        P2S_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->prep, hipStreamNonBlocking, hi));
+    }
+    hipStream_t sp = prep_overlap ? m->prep : s;
     p2s_cloud_note_stream(c, s);
     p2s_cloud_note_stream(c, sa);
+    p2s_cloud_note_stream(c, sp);
     const int64_t nq = q_end - q_begin;
     if (nq <= 0) return P2S_OK;
     const int C = (int)std::min<int64_t>(chunk, nq);
@@ -224,7 +242,9 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
     // model-owned chunk buffers are idle again
     auto fail = [&](int code) {
         const hipError_t e1 = hipStreamSynchronize(s);
-        const hipError_t e2 = (sa != s) ? hipStreamSynchronize(sa) : hipSuccess;
+        hipError_t e2 = (sa != s) ? hipStreamSynchronize(sa) : hipSuccess;
+        const hipError_t e3 = (sp != s) ? hipStreamSynchronize(sp) : hipSuccess;
+        if (e2 == hipSuccess) e2 = e3;
         if (code == P2S_OK && (e1 != hipSuccess || e2 != hipSuccess)) {
             p2s_set_error("p2s pipeline: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
             return (int)P2S_EHIP;
@@ -239,9 +259,10 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
             return fail(P2S_EHIP);                                                                         \
         }                                                                                                  \
     } while (0)
-    if (sa != s) {
+    if (sa != s || sp != s) {
         PIPE_HIP(hipEventRecord(b.grid, s));
-        PIPE_HIP(hipStreamWaitEvent(sa, b.grid, 0));
+        if (sa != s) PIPE_HIP(hipStreamWaitEvent(sa, b.grid, 0));
+        if (sp != s) PIPE_HIP(hipStreamWaitEvent(sp, b.grid, 0));
     }
 
     const int64_t nchunks = (nq + C - 1) / C;
@@ -265,9 +286,38 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         return P2S_OK;
     };
 
+    // kNN patch + radius and the gathered sub-sample of chunk ci into buffer ci % nbuf (stream sp)
+    auto prepare = [&](int64_t ci) -> int {
+        const int bi = (int)(ci % nbuf);
+        const int64_t q0 = q_begin + ci * C;
+        const int cur = (int)std::min<int64_t>(C, q_end - q0);
+        const float *qc = q_all + (size_t)q0 * 3;
+        // the encoders of chunk ci - nbuf read this buffer
+        if (sp != s && ci >= nbuf) PIPE_HIP(hipStreamWaitEvent(sp, b.done[bi], 0));
+        const int ek0 = p2s_prof_mark(m, sp);
+        int rc2 = small ? p2s_knn_patch(c, qc, cur, k, b.knn_ids[bi], nullptr, nullptr, sp)
+                        : p2s_knn_patch(c, qc, cur, k, nullptr, b.patch[bi], b.radius[bi], sp);
+        if (rc2) return fail(rc2);
+        p2s_prof_span(m, ST_KNN, ek0, p2s_prof_mark(m, sp));
+        if (sa != sp) PIPE_HIP(hipStreamWaitEvent(sp, b.ready[bi], 0));
+        if (small) {       // the patch is gathered from the array as the queries before this one left it
+            rc2 = p2s_patch_from_ids(c, b.knn_ids[bi], b.perm[bi], qc, cur, k, b.patch[bi], b.radius[bi], sp);
+            if (rc2) return fail(rc2);
+        }
+        rc2 = p2s_gather_points(c, b.sub_ids[bi], (int64_t)cur * n, b.sub[bi], sp);
+        if (rc2) return fail(rc2);
+        // the producer only writes sub_ids: free for chunk ci + nbuf as soon as the gather has read them
+        if (sa != sp) PIPE_HIP(hipEventRecord(b.freed[bi], sp));
+        if (sp != s) PIPE_HIP(hipEventRecord(b.prepped[bi], sp));
+        return P2S_OK;
+    };
+
     // prologue: up to nbuf chunks of ids in flight
     for (int64_t ci = 0; ci < std::min<int64_t>(nbuf, nchunks); ++ci)
         if ((rc = produce(ci))) return rc;
+    if (sp != s)
+        for (int64_t ci = 0; ci < std::min<int64_t>(nbuf, nchunks); ++ci)
+            if ((rc = prepare(ci))) return rc;
     for (int64_t ci = 0; ci < nchunks; ++ci) {
         const int bi = (int)(ci % nbuf);
         const int64_t q0 = q_begin + ci * C;
@@ -278,20 +328,8 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
             p2s_set_error("p2s pipeline: injected fault before chunk %lld (p2s_debug_fault_chunk)", (long long)ci);
             return fail(P2S_EHIP);
         }
-        const int ek0 = p2s_prof_mark(m, s);
-        rc = small ? p2s_knn_patch(c, qc, cur, k, b.knn_ids[bi], nullptr, nullptr, s)
-                   : p2s_knn_patch(c, qc, cur, k, nullptr, b.patch[bi], b.radius[bi], s);
-        if (rc) return fail(rc);
-        p2s_prof_span(m, ST_KNN, ek0, p2s_prof_mark(m, s));
-        if (sa != s) PIPE_HIP(hipStreamWaitEvent(s, b.ready[bi], 0));
-        if (small) {       // the patch is gathered from the array as the queries before this one left it
-            rc = p2s_patch_from_ids(c, b.knn_ids[bi], b.perm[bi], qc, cur, k, b.patch[bi], b.radius[bi], s);
-            if (rc) return fail(rc);
-        }
-        rc = p2s_gather_points(c, b.sub_ids[bi], (int64_t)cur * n, b.sub[bi], s);
-        if (rc) return fail(rc);
-        // the producer only writes sub_ids: free for chunk ci + nbuf as soon as the gather has read them
-        if (sa != s) PIPE_HIP(hipEventRecord(b.freed[bi], s));
+        if (sp != s) PIPE_HIP(hipStreamWaitEvent(s, b.prepped[bi], 0));
+        else if ((rc = prepare(ci))) return rc;
         if (r_rot) {
             // data_loader.py:381-393: rotate sub-sample (model space), patch (patch space) and the query point
             if ((rc = p2s_random_rotations(r_rot, cur, b.rot[bi], s))) return fail(rc);
@@ -303,8 +341,11 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         rc = p2s_run_chunk(m, b.patch[bi], b.sub[bi], qc, b.radius[bi], cur, nullptr, sdf_out_dev + (q0 - q_begin),
                            nullptr, nullptr, s);
         if (rc) return fail(rc);
-        if (ci + nbuf < nchunks)
+        if (sp != s) PIPE_HIP(hipEventRecord(b.done[bi], s));
+        if (ci + nbuf < nchunks) {
             if ((rc = produce(ci + nbuf))) return rc;
+            if (sp != s && (rc = prepare(ci + nbuf))) return rc;
+        }
     }
 #undef PIPE_HIP
     m->counters.queries += nq;
