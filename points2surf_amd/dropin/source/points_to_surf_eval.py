@@ -227,7 +227,7 @@ def points_to_surf_eval(eval_opt):
     world, rank, local_rank = _sharding.dist_env()
     if world > 1 and 'MASTER_PORT' in os.environ:        # launched by torchrun (tests run "ranks" one after the other)
         _sharding.init_process_group()
-    device = _engine.select_device(eval_opt.gpu_idx if world == 1 else local_rank)
+    device = _engine.select_device(eval_opt.gpu_idx if world == 1 else _sharding.local_device_index(local_rank))
 
     for model_name in models:
         print('Random Seed: %d' % eval_opt.seed)

@@ -145,7 +145,9 @@ def implicit_surface_to_mesh(query_dist_ms, query_pts_ms, volume_out_file, mc_ou
     else:
         if os.path.dirname(mc_out_file):
             os.makedirs(os.path.dirname(mc_out_file), exist_ok=True)
-        ply.write_ply(mc_out_file, v.cpu().numpy(), f.cpu().numpy())
+        # trimesh.Trimesh(vertices=v, faces=f) of the reference (:224) merges coincident vertices before the export
+        mv, mf = ply.merge_vertices(v.cpu().numpy(), f.cpu().numpy())
+        ply.write_ply(mc_out_file, mv, mf)
 
 
 def implicit_surface_to_mesh_file(query_dist_ms_file, query_pts_ms_file, volume_out_file, mc_out_file, grid_res, sigma,

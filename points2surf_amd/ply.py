@@ -126,3 +126,29 @@ def read_ply(path):
             dt = np.dtype([(p[-1], bo + types[p[0]]) for p in props])
             off += dt.itemsize * count
     return verts, faces
+
+
+def merge_vertices(vertices, faces, digits=8):
+    """What ``trimesh.Trimesh(vertices=v, faces=f)`` (``process=True``, the constructor default the reference uses,
+    source/sdf.py:224) does to the mesh before it is exported: ``merge_vertices`` -- referenced vertices whose
+    coordinates agree after rounding to ``tol.merge`` = 1e-8 become one vertex, in order of first occurrence; faces are
+    re-indexed, none is removed (``validate=False``).  The iso-surface of a volume with exact zeros (and of scikit-image's
+    eps-offset vertices next to them) has such coincident vertices.  Restated from trimesh 3.x
+    (``trimesh/grouping.py:merge_vertices``, ``trimesh/base.py:process``); trimesh is not installed here: UNPINNED.
+    Host-side post-processing of the export, like the PLY writer itself."""
+    v = np.asarray(vertices)
+    f = np.asarray(faces)
+    if len(v) == 0 or len(f) == 0:
+        return v, f
+    referenced = np.zeros(len(v), dtype=bool)
+    referenced[f.reshape(-1)] = True
+    rows = np.round(v[referenced].astype(np.float64) * 10 ** digits).astype(np.int64)
+    _, first, inv = np.unique(rows, axis=0, return_index=True, return_inverse=True)
+    inv = np.asarray(inv).reshape(-1)
+    order = np.argsort(first, kind='stable')                 # unique rows in order of first occurrence
+    rank = np.empty(len(order), dtype=np.int64)
+    rank[order] = np.arange(len(order))
+    inverse = np.zeros(len(v), dtype=np.int64)
+    inverse[referenced] = rank[inv]
+    mask = np.nonzero(referenced)[0][first[order]]
+    return v[mask], inverse[f].astype(f.dtype)

@@ -55,13 +55,25 @@ def init_process_group(backend=None):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        # P2S_DIST_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (RCCL
+        # refuses two ranks on one device); the collectives then run on host memory (collective_device)
+        backend = os.environ.get('P2S_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     kw = {}
     if backend == 'nccl':
         torch.cuda.set_device(local_rank)
         kw['device_id'] = torch.device('cuda', local_rank)
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return world, rank, local_rank
+
+
+def local_device_index(local_rank):
+    """the device of a rank: its LOCAL_RANK, or (rehearsal with P2S_DIST_BACKEND=gloo on fewer GPUs) LOCAL_RANK modulo
+    the number of visible devices"""
+    import torch
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n > 0 and local_rank >= n and os.environ.get('P2S_DIST_BACKEND', 'nccl') != 'nccl':
+        return local_rank % n
+    return local_rank
 
 
 def collective_device(device):

@@ -213,3 +213,56 @@ def test_query_range_sharding_is_identical_to_single_process(name, dropin_source
         assert np.array_equal(np.load(os.path.join(single, 'rec', 'query_pts_ms', n + '.xyz.npy')),
                               np.load(os.path.join(sharded, 'rec', 'query_pts_ms', n + '.xyz.npy')))
     assert not [f for f in os.listdir(os.path.join(sharded, 'rec', '.parts')) if f.endswith('.npz')]
+
+
+@pytest.mark.parametrize('shard', ['shapes', 'queries'])
+def test_dropin_under_the_real_launcher_two_ranks(shard, dropin_source, tmp_path, fixture_cloud, monkeypatch):
+    """the drop-in under ``python -m torch.distributed.run --nproc-per-node 2 -m
+    points2surf_amd.dropin.run <script>`` -- real rendezvous, real process group (gloo: both ranks share this GPU), LPT
+    shape assignment / contiguous query ranges, skipped stream of the other rank, atomic assembly of the pieces -- writes
+    the same files as the single-process run."""
+    import socket
+    import subprocess
+    ev, _ = dropin_source
+    root = str(tmp_path / 'ds')
+    rng = np.random.default_rng(2)
+    names = []
+    os.makedirs(os.path.join(root, '04_pts'), exist_ok=True)
+    for i, n in enumerate((8000, 5000, 11000)):
+        sel = rng.choice(fixture_cloud.shape[0], n, replace=False)
+        names.append('shape_%d' % i)
+        np.save(os.path.join(root, '04_pts', names[-1] + '.xyz.npy'), fixture_cloud[np.sort(sel)])
+    with open(os.path.join(root, 'testset.txt'), 'w') as f:
+        f.write('\n'.join(names) + '\n')
+    modeldir = str(tmp_path / 'models')
+    _write_model_files(modeldir, 'p2s_max')
+    args = ['--indir', root, '--dataset', 'testset.txt', '--modeldir', modeldir, '--models', 'p2s_max',
+            '--query_grid_resolution', '24', '--epsilon', '3', '--batchSize', '400']
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR', 'P2S_SHARD'):
+        monkeypatch.delenv(k, raising=False)
+    single = str(tmp_path / 'single')
+    opt = ev.parse_arguments(args + ['--outdir', single])
+    opt.reconstruction = True
+    ev.points_to_surf_eval(opt)
+    # the script a user of the reference would run: the reconstruction pass of full_eval.py (:44-49)
+    script = str(tmp_path / 'rec_pass.py')
+    with open(script, 'w') as f:
+        f.write('import sys\nfrom source import points_to_surf_eval\n'
+                'opt = points_to_surf_eval.parse_arguments(sys.argv[1:])\nopt.reconstruction = True\n'
+                'points_to_surf_eval.points_to_surf_eval(opt)\n')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    sharded = str(tmp_path / 'sharded')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env.update(P2S_DIST_BACKEND='gloo', P2S_SHARD=shard, PYTHONPATH=REPO + os.pathsep + env.get('PYTHONPATH', ''))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), '-m', 'points2surf_amd.dropin.run', script] + args +
+                       ['--outdir', sharded], env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    for n in names:
+        a = np.load(os.path.join(single, 'rec', 'dist_ms', n + '.xyz.npy'))
+        b = np.load(os.path.join(sharded, 'rec', 'dist_ms', n + '.xyz.npy'))
+        assert a.shape == b.shape and a.size > 500 and np.array_equal(a, b), n
+        assert np.array_equal(np.load(os.path.join(single, 'rec', 'query_pts_ms', n + '.xyz.npy')),
+                              np.load(os.path.join(sharded, 'rec', 'query_pts_ms', n + '.xyz.npy')))

@@ -135,6 +135,7 @@ def test_full_eval_call_sequence_matches_reference(model, dropin_eval, tmp_path)
         q = np.load(os.path.join(res_dir_rec, 'query_pts_ms', n + '.xyz.npy'))
         vol_ref = p2s_oracle.sdf_volume(q, ref, 32, 5, 13.0)
         ov, of, _ = mc_oracle.marching_cubes(vol_ref.astype(np.float32))
+        ov, of = ply.merge_vertices(ov, of)           # Trimesh(process=True) of the reference (restated, unpinned)
         print('%s shape %d mesh: %d vertices, %d faces (oracle on the reference SDF: %d, %d)'
               % (model, i, mv.shape[0], mf.shape[0], ov.shape[0], of.shape[0]))
         assert (mv.shape[0], mf.shape[0]) == (ov.shape[0], of.shape[0])          # identical counts
