@@ -79,6 +79,27 @@ def test_full_grid128_matches_reference(model):
     _compare(_run_dataset(model, 'testset', 128), g, meta)
 
 
+def test_full_grid128_sign_decision_with_power():
+    """with the default synthetic weights p2s_vanilla's SDF is positive for 0.9 % of the 128^3
+    queries -- almost every sign logit is far from zero, so "0 flips" said little.  ``p2s_vanilla_mixed`` = the same
+    weights with the sign logit's bias moved by its median over this grid: the reference's golden is positive for
+    49.96 % of the 68,088 queries, i.e. the decision ``sign logit >= 0`` (sdf_nn.py:16-21) is as tight as it can be --
+    and still not one sign differs (weighted sub-sample, QSTN, fp32 encoders)."""
+    g, meta = _golden('rec', 'p2s_vanilla_mixed', 'testset', 128)
+    assert 0.3 < meta['shapes'][0]['pos_frac'] < 0.7
+    out = _run_dataset('p2s_vanilla_mixed', 'testset', 128)
+    _compare(out, g, meta)
+    assert 0.3 < float((out[0][0] > 0).mean()) < 0.7
+
+
+@pytest.mark.parametrize('res', [256])
+def test_three_clouds_one_stream_256_matches_reference(res):
+    """the benchmarked dataset -- all three abc_minimal clouds as ONE dataset at 256^3, 1,378,242
+    queries from one continuous stream -- against the golden the unmodified reference wrote (~6 h of CPU)"""
+    g, meta = _golden('rec', 'p2s_max', 'abc3', res)
+    _compare(_run_dataset('p2s_max', 'abc3', res), g, meta)
+
+
 @pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
 def test_full_grid256_matches_reference(model):
     """BASELINE configs[2] (the benchmarked workload): every one of the 307,237 queries of the 256^3 grid"""
