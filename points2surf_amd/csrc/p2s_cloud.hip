@@ -208,46 +208,77 @@ __device__ void knn_prune(KnnList &L, int lane) {
     }
 }
 
-// scan cells [lo, hi]; if has_ex, cells inside [exlo, exhi] were scanned before and are skipped
+// scan cells [lo, hi]; if has_ex, cells inside [exlo, exhi] were scanned before and are skipped.
+// The box is a set of z-contiguous cell runs, one per (x, y) column (two where the column crosses the excluded box).
+// Walking them one after the other costs two dependent L2 round trips per run for ~10 points (r02: 49 runs per query,
+// most lanes idle).  Instead: up to 64 runs at a time, one LANE per run fetches its point range, a wave scan turns the
+// run lengths into offsets, and all 64 lanes then walk the FLATTENED point list of the batch (the run of a flat index
+// is found by a 6-step binary search over the offsets in LDS).  The order candidates enter the list in does not matter:
+// every consumer sorts by (distance, id).
 __device__ void knn_scan(const CloudDev &c, KnnList &L, const int lo[3], const int hi[3], bool has_ex,
-                         const int exlo[3], const int exhi[3], double qx, double qy, double qz, int lane) {
+                         const int exlo[3], const int exhi[3], double qx, double qy, double qz, int lane,
+                         int *run_start, int *run_off) {
     const int G = c.G;
-    for (int cx = lo[0]; cx <= hi[0]; ++cx) {
-        for (int cy = lo[1]; cy <= hi[1]; ++cy) {
+    const int nx = hi[0] - lo[0] + 1, ny = hi[1] - lo[1] + 1;
+    const int ncol = nx * ny;
+    // run index r -> column r >> 1, segment r & 1 (segment 1 only exists for columns inside the xy-exclusion)
+    for (int r0 = 0; r0 < 2 * ncol; r0 += 64) {
+        const int r = r0 + lane;
+        int start = 0, cnt = 0;
+        if (r < 2 * ncol) {
+            const int col = r >> 1, seg = r & 1;
+            const int cx = lo[0] + col / ny, cy = lo[1] + col % ny;
             const bool inside_xy = has_ex && cx >= exlo[0] && cx <= exhi[0] && cy >= exlo[1] && cy <= exhi[1];
-            const int nseg = inside_xy ? 2 : 1;
-            for (int sgi = 0; sgi < nseg; ++sgi) {
-                int za, zb;
-                if (!inside_xy) { za = lo[2]; zb = hi[2]; }
-                else if (sgi == 0) { za = lo[2]; zb = exlo[2] - 1; }
-                else { za = exhi[2] + 1; zb = hi[2]; }
-                if (za > zb) continue;
-                const int rowbase = (cx * G + cy) * G;
-                const int start = c.cell_start[rowbase + za];
-                const int end = c.cell_start[rowbase + zb + 1];
-                for (int base = start; base < end; base += 64) {
-                    const int i = base + lane;
-                    bool keep = false;
-                    unsigned long long key = 0;
-                    int id = 0;
-                    if (i < end) {
-                        const float4 p = c.spts[i];
-                        const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
-                        const double d2 = dx * dx + dy * dy + dz * dz;
-                        keep = d2 <= L.thr2;
-                        key = (unsigned long long)__double_as_longlong(d2);
-                        id = __float_as_int(p.w);
-                    }
-                    const unsigned long long m = __ballot(keep);
-                    if (keep) {
-                        const int off = L.len + __popcll(m & ((1ull << lane) - 1ull));
-                        L.keys[off] = key;
-                        L.ids[off] = id;
-                    }
-                    L.len += __popcll(m);
-                    if (L.len > KNN_CAP - 64) knn_prune(L, lane);
-                }
+            int za = lo[2], zb = hi[2];
+            if (inside_xy) {
+                if (seg == 0) zb = exlo[2] - 1;
+                else za = exhi[2] + 1;
+            } else if (seg == 1) {
+                zb = za - 1;                                  // no second segment
             }
+            if (za <= zb) {
+                const int rowbase = (cx * G + cy) * G;
+                start = c.cell_start[rowbase + za];
+                cnt = c.cell_start[rowbase + zb + 1] - start;
+            }
+        }
+        // exclusive scan of the run lengths
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        const int total = __shfl(incl, 63);
+        __syncthreads();                                      // the previous batch's readers are done
+        run_start[lane] = start;
+        run_off[lane] = incl - cnt;
+        __syncthreads();
+        for (int f0 = 0; f0 < total; f0 += 64) {
+            const int f = f0 + lane;
+            bool keep = false;
+            unsigned long long key = 0;
+            int id = 0;
+            if (f < total) {
+                int a = 0;                                    // last run whose offset is <= f (empty runs share offsets:
+#pragma unroll                                                //  the search lands on the last of them, the non-empty one)
+                for (int step = 32; step >= 1; step >>= 1)
+                    if (a + step < 64 && run_off[a + step] <= f) a += step;
+                const float4 p = c.spts[run_start[a] + (f - run_off[a])];
+                const double dx = qx - (double)p.x, dy = qy - (double)p.y, dz = qz - (double)p.z;
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                keep = d2 <= L.thr2;
+                key = (unsigned long long)__double_as_longlong(d2);
+                id = __float_as_int(p.w);
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int off = L.len + __popcll(m & ((1ull << lane) - 1ull));
+                L.keys[off] = key;
+                L.ids[off] = id;
+            }
+            L.len += __popcll(m);
+            if (L.len > KNN_CAP - 64) knn_prune(L, lane);
         }
     }
 }
@@ -258,6 +289,7 @@ __global__ __launch_bounds__(64) void p2s_knn_kernel(CloudDev c, const float *__
                                                      float *__restrict__ radius_out) {
     __shared__ unsigned long long keys[KNN_CAP];
     __shared__ int lids[KNN_CAP];
+    __shared__ int run_start[64], run_off[64];
     const int lane = threadIdx.x;
     const int G = c.G;
     for (long long qi = blockIdx.x; qi < nq; qi += gridDim.x) {
@@ -279,7 +311,7 @@ __global__ __launch_bounds__(64) void p2s_knn_kernel(CloudDev c, const float *__
         }
         KnnList L{keys, lids, 0, INFINITY, k};
         __syncthreads();
-        knn_scan(c, L, lo, hi, false, lo, hi, qx, qy, qz, lane);
+        knn_scan(c, L, lo, hi, false, lo, hi, qx, qy, qz, lane, run_start, run_off);
         knn_prune(L, lane);   // exact k-th distance among the cube's points: an upper bound of the true one
         // every point within sqrt(thr2) of q lies in cells [lo2, hi2] (conservative: radius rounded up, and
         // cell_coord is monotone)
@@ -295,7 +327,7 @@ __global__ __launch_bounds__(64) void p2s_knn_kernel(CloudDev c, const float *__
         }
         if (grow) {
             const int before = L.len;
-            knn_scan(c, L, lo2, hi2, true, lo, hi, qx, qy, qz, lane);
+            knn_scan(c, L, lo2, hi2, true, lo, hi, qx, qy, qz, lane, run_start, run_off);
             if (L.len != before) knn_prune(L, lane);
         }
         __syncthreads();
