@@ -7,10 +7,10 @@
 // each wave streams its own 32-column panel from L2 with coalesced 16-byte loads (no LDS for W);
 // the activation tile [64 rows x 128 k] is staged in LDS once per k-chunk and shared by 4 waves.
 #include "p2s_common.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int GM = 64;     // rows per workgroup
 constexpr int GK = 128;    // k chunk staged in LDS
 constexpr int GS = 132;    // LDS row stride
 
@@ -18,8 +18,13 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// grid: (ceil(M/64), N/128, Z); block 256: wave w -> column tile (blockIdx.y*4 + w), 2 row tiles
+// grid: (ceil(M / (32 RT)), N/128, Z); block 256: wave w -> column tile (blockIdx.y*4 + w), RT row tiles of 32.
+// RT = 2 halves the weight stream per output; RT = 1 doubles the number of workgroups for the layers whose grid would
+// not fill the chip (a 4096-query chunk gives the 512- and 256-column layers 512 / 256 workgroups of 64 rows for 1024
+// workgroup slots: M = 4096 is all the parallelism there is).
+template <int RT>
 __global__ __launch_bounds__(256) void p2s_gemm_kernel(GemmArgs g) {
+    constexpr int GM = 32 * RT;
     __shared__ __attribute__((aligned(16))) float As[GM * GS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -43,9 +48,9 @@ __global__ __launch_bounds__(256) void p2s_gemm_kernel(GemmArgs g) {
 
     for (int kc = 0; kc < g.K; kc += GK) {
         __syncthreads();
-        // stage A[m0:m0+64][kc:kc+128]: 8 rows per pass, 32 lanes x 16 B per row (coalesced)
+        // stage A[m0:m0+GM][kc:kc+128]: 8 rows per pass, 32 lanes x 16 B per row (coalesced)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < GM / 8; ++i) {
             const int r = (tid >> 5) + 8 * i;
             int m = m0 + r;
             if (m >= g.M) m = g.M - 1;
@@ -65,11 +70,12 @@ __global__ __launch_bounds__(256) void p2s_gemm_kernel(GemmArgs g) {
             f32x4 nb = b;
             if (kg < GK / 8 - 1) nb = *reinterpret_cast<const f32x4 *>(wk + (kg + 1) * 256);
             const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p + 8 * kg);
-            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(a1p + 8 * kg);
+            f32x4 a1 = a0;
+            if (RT == 2) a1 = *reinterpret_cast<const f32x4 *>(a1p + 8 * kg);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 acc0 = mfma32(a0[t], b[t], acc0);
-                acc1 = mfma32(a1[t], b[t], acc1);
+                if (RT == 2) acc1 = mfma32(a1[t], b[t], acc1);
             }
             b = nb;
         }
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(256) void p2s_gemm_kernel(GemmArgs g) {
         // NaN-propagating ReLU (torch.relu(NaN) = NaN; fmaxf would swallow it)
         if (g.relu) { v0 = (v0 < 0.f) ? 0.f : v0; v1 = (v1 < 0.f) ? 0.f : v1; }
         if (m0 + r < g.M) C[(long long)(m0 + r) * g.ldc + col] = v0;
-        if (m0 + 32 + r < g.M) C[(long long)(m0 + 32 + r) * g.ldc + col] = v1;
+        if (RT == 2 && m0 + 32 + r < g.M) C[(long long)(m0 + 32 + r) * g.ldc + col] = v1;
     }
 }
 
@@ -182,8 +188,17 @@ int p2s_launch_gemm(const GemmArgs &g, hipStream_t stream) {
         p2s_set_error("gemm: unsupported shape M=%d N=%d K=%d Z=%d", g.M, g.N, g.K, g.Z);
         return P2S_EINVAL;
     }
-    dim3 grid((g.M + GM - 1) / GM, g.N / 128, g.Z);
-    hipLaunchKernelGGL(p2s_gemm_kernel, grid, dim3(256), 0, stream, g);
+    // 64-row workgroups when they fill the 1024 workgroup slots of the chip at least twice, else 32-row ones
+    const long long wg64 = (long long)((g.M + 63) / 64) * (g.N / 128) * g.Z;
+    static const int force_rt = getenv("P2S_GEMM_RT") ? atoi(getenv("P2S_GEMM_RT")) : 0;     // development: 1 / 2
+    const bool rt2 = force_rt ? force_rt == 2 : wg64 >= 2048;
+    if (rt2) {
+        dim3 grid((g.M + 63) / 64, g.N / 128, g.Z);
+        hipLaunchKernelGGL(p2s_gemm_kernel<2>, grid, dim3(256), 0, stream, g);
+    } else {
+        dim3 grid((g.M + 31) / 32, g.N / 128, g.Z);
+        hipLaunchKernelGGL(p2s_gemm_kernel<1>, grid, dim3(256), 0, stream, g);
+    }
     P2S_LAUNCH_CHECK("p2s_gemm_kernel");
     return P2S_OK;
 }
