@@ -27,8 +27,9 @@ The per-shape SDF arrays are gathered to rank 0 over RCCL at the end of every st
 path's only exchange).  Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (p2s_chain_kernel,
 MFMA-bound) from HIP events recorded on the launch stream during the timed steps; ``cloud_resident`` repeats the r02
 measurement (cloud handle + query grid kept across steps, SDF left on the device) beside the headline; ``secondary``
-(N = 1) carries one complete-shape pass each of p2s_vanilla fp32 and of p2s_max with the split bf16x3 encoder
-(BASELINE configs[3]) on the test shape, each checked over the full grid against the reference's golden;
+(N = 1) carries one complete-shape pass each of p2s_vanilla fp32, of p2s_max with the split bf16x3 encoder and of both
+models with the fp16-pair encoder (BASELINE configs[3]: reduced-precision encoder + fp32 decoder, here at fp32
+accuracy) on the test shape, each checked over the full grid against the reference's golden;
 ``cpu_baseline`` times the torch-CPU port of the reference's path (oracle/torch_port.py) on this box's host cores on
 a bounded sample; ``self_check`` (after the timed region, rank 0) runs the three clouds as one dataset from a fresh
 stream and compares every query with the goldens written by the unmodified reference.
@@ -75,9 +76,10 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='target CPU-baseline duration (0 = skip)')
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--rng-mode', choices=['dataset', 'per_shape'], default='dataset')
-    ap.add_argument('--bf16', nargs='?', const=1, default=0, type=int, choices=[0, 1, 2, 3],
+    ap.add_argument('--bf16', nargs='?', const=1, default=0, type=int, choices=[0, 1, 2, 3, 4],
                     help='secondary modes (BASELINE configs[3]), NOT the headline metric: bf16 encoder + fp32 decoder '
-                         '(--bf16 or --bf16 1); split precision with 2 / 3 bf16 pieces per operand (--bf16 2 / 3)')
+                         '(--bf16 or --bf16 1); split precision with 2 / 3 bf16 pieces per operand (--bf16 2 / 3); fp16 pair per operand '
+                         '(--bf16 4: 3 fp16 MFMAs per product)')
     ap.add_argument('--res', type=int, default=GRID_RES,
                     help='query-grid resolution; the headline metric is quoted at 256 (other values: BASELINE configs 1/4)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the p2s_vanilla / bf16x3 secondary passes')
@@ -352,7 +354,7 @@ def main():
         flop_per_launch = FLOP_CHAIN_PER_QUERY * n_queries / launches
         # split precision executes 3 (two pieces) / 6 (three pieces) bf16 MFMA passes per algorithmic product: the
         # roofline of those modes is priced in executed bf16 FLOP against the dense bf16 peak
-        passes = {0: 1, 1: 1, 2: 3, 3: 6}[int(args.bf16)]
+        passes = {0: 1, 1: 1, 2: 3, 3: 6, 4: 3}[int(args.bf16)]
         achieved = passes * flop_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
         peak = 2500.0 if args.bf16 else PEAK_FP32_MFMA_TFLOPS     # dense MFMA peak of the compute dtype
         # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
@@ -374,11 +376,11 @@ def main():
         stage['ms_grid'] = float(sum(ev.get('ms_grid', [])))            # a1 incl. its host sync (the handle is fresh: no cached grid)
         stage['ms_d2h'] = float(sum(ev.get('ms_d2h', [])))
         out = {
-            'metric': 'SDF queries/sec/GPU (p2s_max, %d^3 grid%s)' % (args.res, (', bf16 encoder' if args.bf16 == 1 else ', split bf16x%d encoder' % args.bf16) if args.bf16 else ''),
+            'metric': 'SDF queries/sec/GPU (p2s_max, %d^3 grid%s)' % (args.res, (', bf16 encoder' if args.bf16 == 1 else (', fp16-pair encoder' if args.bf16 == 4 else ', split bf16x%d encoder' % args.bf16)) if args.bf16 else ''),
             'value': value, 'unit': 'queries/s',
             'n_gpus': world if not share else 1, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / max(args.steps, 1) * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': ('bf16' if args.bf16 == 1 else 'bf16x%d' % args.bf16) if args.bf16 else 'f32',
+            'vs_baseline': None, 'dtype': ('bf16' if args.bf16 == 1 else ('fp16x2' if args.bf16 == 4 else 'bf16x%d' % args.bf16)) if args.bf16 else 'f32',
             'data': 'abc_minimal clouds of the reference repository (committed fixtures); seeded random-init weights' if not args.points else 'synthetic',
             'config': {'workload': 'BASELINE.json configs[%d]: p2s_max, grid_res=%d, eps=3, kNN patch=300 / global ' % ({128: 1, 512: 4}.get(args.res, 2), args.res) +
                                    'sub=1000, fp32; %s, one COMPLETE shape per rank per step (host cloud -> upload -> '
@@ -441,7 +443,9 @@ def main():
         if world == 1 and not args.no_secondary and not args.bf16 and args.points == 0 and args.res == GRID_RES:
             sec = {}
             fixture = np.ascontiguousarray(np.load(cloud_path(FIXTURE_SHAPE))[:, :3], dtype=np.float32)
-            for key, mname, extra in (('p2s_vanilla_fp32', 'p2s_vanilla', {}), ('p2s_max_bf16x3', 'p2s_max', {'encoder_bf16': 3})):
+            for key, mname, extra in (('p2s_vanilla_fp32', 'p2s_vanilla', {}), ('p2s_max_bf16x3', 'p2s_max', {'encoder_bf16': 3}),
+                                      ('p2s_max_fp16x2', 'p2s_max', {'encoder_bf16': 4}),
+                                      ('p2s_vanilla_fp16x2', 'p2s_vanilla', {'encoder_bf16': 4})):
                 w2, cfg2 = synth.make_weights(mname)
                 cfg2 = dict(cfg2, **extra)
                 m2 = engine.Model(w2, cfg2)
@@ -455,7 +459,7 @@ def main():
                 cnt = m2.counters()
                 gfile = os.path.join(GOLDEN, 'ref_rec_%s_testset_grid%d.npz' % (mname, args.res))
                 srec = {'value': s2.shape[0] / d2, 'unit': 'queries/s', 'ms_per_step': d2 * 1e3, 'queries': int(s2.shape[0]),
-                        'model': mname, 'dtype': 'bf16x3' if extra else 'f32',
+                        'model': mname, 'dtype': {0: 'f32', 3: 'bf16x3', 4: 'fp16x2'}[extra.get('encoder_bf16', 0)],
                         'workload': 'one complete shape (host to host) of the abc_minimal test shape at %d^3' % args.res,
                         'chain_ms': cnt['ms_chain_stn'] + cnt['ms_chain_main'], 'chain_launches': int(cnt['launches_chain'])}
                 if os.path.isfile(gfile):

@@ -66,7 +66,11 @@ typedef struct {
     int32_t encoder_bf16;        /* 0 (default): exact fp32.  1: per-point encoder layers on bf16 MFMA (fp32 accumulate; first
                                     layer, STN/QSTN heads, fold and decoder stay fp32) -- outside the 1e-4 contract.
                                     2 / 3: split precision, every operand as 2 / 3 bf16 pieces (3 / 6 bf16 MFMAs per
-                                    product, 16 / 24 mantissa bits): see DESIGN.md for the measured deviation      */
+                                    product, 16 / 24 mantissa bits).  4: fp16 PAIR per operand, x = h0 + h1 * 2^-11 with
+                                    the residual scaled into the normal range and a second accumulator (3 fp16 MFMAs per
+                                    product, 22 mantissa bits): as exact as fp32 on the reference's goldens at 2.5x its
+                                    throughput; activations beyond the half range (6e4) poison the query AND make the
+                                    next p2s_infer_shape / p2s_infer_queries return P2S_EINVAL.  See DESIGN.md        */
     int32_t fixed_subsample;     /* train --fixed_subsample 1 (ablation): the generator is re-seeded with 42 before every
                                     query's draw (reference source/base/utils.py:210-211)                       */
     int32_t single_transformer;  /* train --single_transformer 1 (p2s_shared_encoder): ONE encoder over cat(patch,

@@ -137,13 +137,14 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
             *it.dst = total;
             total += (size_t)it.K * it.N;
         }
-        const int ns = cfg->encoder_bf16;              // 1 plain bf16, 2 / 3 split precision (bf16 pieces per operand)
-        if (ns < 1 || ns > 3) {
+        if (cfg->encoder_bf16 < 1 || cfg->encoder_bf16 > 4) {
             (void)hipFree(m->blob);
             delete m;
-            p2s_set_error("p2s_model_create: encoder_bf16 = %d (0 fp32, 1 bf16, 2 / 3 split bf16)", ns);
+            p2s_set_error("p2s_model_create: encoder_bf16 = %d (0 fp32, 1 bf16, 2 / 3 split bf16, 4 fp16 pair)", cfg->encoder_bf16);
             return P2S_EINVAL;
         }
+        const int ns = p2s_enc_pieces(*cfg);           // 1 plain bf16, 2 / 3 split bf16 pieces, 2 for the fp16 pair
+        const int f16 = p2s_enc_f16(*cfg);
         m->h_total = total;
         if (hipMalloc(&m->blob_h, total * 2 * ns) != hipSuccess) {
             (void)hipGetLastError();
@@ -155,12 +156,20 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
         for (int piece = 0; piece < ns; ++piece)
             for (auto &it : items) {
                 const int rc = p2s_launch_pack_bf16(m->blob + it.src, m->blob_h + (size_t)piece * total + *it.dst, it.K, it.N, 0, 0,
-                                                    1, piece, nullptr);
+                                                    1, piece, f16, nullptr);
                 if (rc) {
                     p2s_model_destroy(m);
                     return rc;
                 }
             }
+        if (f16) {
+            if (hipMalloc(&m->range_flag, 4) != hipSuccess || hipMemset(m->range_flag, 0, 4) != hipSuccess) {
+                (void)hipGetLastError();
+                p2s_model_destroy(m);
+                p2s_set_error("hipMalloc(range flag) failed");
+                return P2S_ENOMEM;
+            }
+        }
         P2S_HIP_CHECK(hipDeviceSynchronize());
     }
     *out = m;
@@ -174,6 +183,7 @@ int p2s_model_destroy(p2s_model_t m) {
     if (m->ws) (void)hipFree(m->ws);
     if (m->blob) (void)hipFree(m->blob);
     if (m->blob_h) (void)hipFree(m->blob_h);
+    if (m->range_flag) (void)hipFree(m->range_flag);
     for (auto &ev : m->evpool)
         if (ev) (void)hipEventDestroy(ev);
     if (m->aux) (void)hipStreamDestroy(m->aux);
@@ -201,7 +211,7 @@ int p2s_get_counters(p2s_model_t m, p2s_counters *out) {
 static size_t ws_floats_per_query(const p2s_model_s *m) {
     size_t n = 2 * 1024 + 2 * 512 + 2 * 256 + 2 * 4096 + 2 * 4096 + 2 * 1024 + 1024 + 256 + 128;
     if (m->cfg.use_point_stn) n += 2 * 1024 + 512 + 256 + 16;
-    if (m->cfg.encoder_bf16) n += 4096 * (size_t)m->cfg.encoder_bf16;   // W1' of both encoders as bf16 fragments, per piece
+    if (m->cfg.encoder_bf16) n += 4096 * (size_t)p2s_enc_pieces(m->cfg);   // W1' of both encoders as 16-bit fragments, per piece
     return n;
 }
 
@@ -251,7 +261,7 @@ Ws carve(const p2s_model_s *m, int C) {
         w.qh2 = take((size_t)C * 256);
         w.rot = take((size_t)C * 16);
     }
-    w.w1h = m->cfg.encoder_bf16 ? reinterpret_cast<unsigned short *>(take((size_t)C * 4096 * m->cfg.encoder_bf16)) : nullptr;
+    w.w1h = m->cfg.encoder_bf16 ? reinterpret_cast<unsigned short *>(take((size_t)C * 4096 * p2s_enc_pieces(m->cfg))) : nullptr;
     return w;
 }
 
@@ -276,7 +286,9 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         // rotation is applied to the sub-sample and to the patch (:337-339) -- the same kernels, other points
         ChainArgs a;
         memset(&a, 0, sizeof(a));
-        a.ns = m->cfg.encoder_bf16;
+        a.ns = p2s_enc_pieces(m->cfg);
+        a.f16 = p2s_enc_f16(m->cfg);
+        a.range_flag = m->range_flag;
         a.piece_stride = (long long)m->h_total;
         a.w1_piece_stride = (long long)2 * C * 4096;
         ChainBranch &b = a.br[0];
@@ -317,7 +329,9 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
     // ---- pass 1: stem + STN trunk + max-pool, both encoders (global items first: longest first) ----
     ChainArgs a;
     memset(&a, 0, sizeof(a));
-    a.ns = m->cfg.encoder_bf16;
+    a.ns = p2s_enc_pieces(m->cfg);
+    a.f16 = p2s_enc_f16(m->cfg);
+    a.range_flag = m->range_flag;
     a.piece_stride = (long long)m->h_total;
     a.w1_piece_stride = (long long)2 * C * 4096;
     for (int slot = 0; slot < 2; ++slot) {
@@ -389,8 +403,9 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
             b.w3 = reinterpret_cast<const float *>(m->blob_h + m->h_m3[e]);
         }
     }
-    for (int piece = 0; bf16 && piece < m->cfg.encoder_bf16; ++piece)
-        if ((rc = p2s_launch_pack_bf16(w.w1p, w.w1h + (size_t)piece * 2 * C * 4096, 64, 64, 4096, 4096, 2 * C, piece, s))) return rc;
+    for (int piece = 0; bf16 && piece < p2s_enc_pieces(m->cfg); ++piece)
+        if ((rc = p2s_launch_pack_bf16(w.w1p, w.w1h + (size_t)piece * 2 * C * 4096, 64, 64, 4096, 4096, 2 * C, piece,
+                                       p2s_enc_f16(m->cfg), s))) return rc;
     if ((rc = bf16 ? p2s_launch_chain_bf16(a, s) : p2s_launch_chain(a, s))) return rc;
     const int ev3 = p2s_prof_mark(m, s);
     m->counters.launches_chain += 2;
@@ -426,6 +441,18 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
     p2s_prof_span(m, ST_CHAIN_MAIN, ev2, ev3);
     p2s_prof_span(m, ST_DECODER, ev3, ev4);
     return P2S_OK;
+}
+
+int p2s_model_check_range(p2s_model_s *m, hipStream_t s) {
+    if (!m->range_flag) return P2S_OK;
+    int h = 0;
+    P2S_HIP_CHECK(hipMemcpyAsync(&h, m->range_flag, 4, hipMemcpyDeviceToHost, s));
+    P2S_HIP_CHECK(hipStreamSynchronize(s));
+    if (!h) return P2S_OK;
+    P2S_HIP_CHECK(hipMemsetAsync(m->range_flag, 0, 4, s));
+    p2s_set_error("fp16 pair encoder (encoder_bf16 = 4): an activation left the half range (> 6e4); the affected queries "
+                  "came out as 1.0 -- use encoder_bf16 = 3 or 0 for this model");
+    return P2S_EINVAL;
 }
 
 int p2s_prof_mark(p2s_model_s *m, hipStream_t s) {

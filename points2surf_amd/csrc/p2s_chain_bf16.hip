@@ -18,12 +18,23 @@
 // NS bf16 pieces  x = x0 + x1 (+ x2),  x_p = bf16(residual),  and a product is the sum of the piece products with
 // p + q < NS (3 MFMAs for NS = 2, 6 for NS = 3), all into the same fp32 accumulator: 16 / 24 mantissa bits per operand
 // at 1/16 of the fp32 MFMA cost per piece product.  Arithmetic model + measured deviation: DESIGN.md "bf16 modes".
+//
+// fp16 pair mode (template parameter F16; cfg.encoder_bf16 = 4, "fp16x2"): every operand as TWO fp16 numbers,
+//   x = h0 + h1 * 2^-11,   h0 = fp16(x),   h1 = fp16((x - h0) * 2^11)     (22 mantissa bits; the residual is scaled so
+// that it never goes subnormal), and a product = h0 h0' into one fp32 accumulator, (h0 h1' + h1 h0') into a second one
+// that enters with the factor 2^-11 at the end -- THREE v_mfma_f32_32x32x16_f16 per product instead of the six bf16
+// ones of the three-piece mode, for the same deviation from fp32 (relative feature error 5e-7 vs 4e-7 in the CPU model;
+// two bf16 pieces: 1.3e-5).  fp16 ends at 65504: an activation beyond 6e4 poisons its item (NaN -> SDF 1.0, like a
+// non-finite input) AND raises the model's sticky range flag, which p2s_infer_shape / p2s_infer_queries report as an
+// error (the reference's activations stay below 20 with the weights at hand).
 #include "p2s_common.h"
 #include <cmath>
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef P2S_BF16_MT
@@ -31,6 +42,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef P2S_BF16_HOLD
 #define P2S_BF16_HOLD 1      // split modes: pieces whose conv3 A fragments stay in registers (the rest: LDS per k-step)
+#endif
+// fp16 pair mode: pieces whose conv3 A fragments stay in registers / workgroups per CU the register budget is set for
+// (53 KB of LDS allow 3).  Measured, ms per 4096 queries for both chain passes: HOLD 0 / WG 3 (127 VGPRs): 8.20;
+// HOLD 1 / WG 3 (168 VGPRs + 20 B scratch): 8.09; HOLD 1 / WG 2: 8.50; HOLD 2 / WG 2: 8.31 -> everything from LDS, 3 per CU
+#ifndef P2S_F16_HOLD
+#define P2S_F16_HOLD 0
+#endif
+#ifndef P2S_F16_WG
+#define P2S_F16_WG 3
 #endif
 constexpr int MT = P2S_BF16_MT;  // points per tile (64 or 128: larger tiles halve the L2 weight stream of conv3)
 constexpr int NB = MT / 32;      // 32-row blocks per tile
@@ -53,8 +73,14 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
+template <bool F16>
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 
 __device__ __forceinline__ u32x4 bufld(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
@@ -69,9 +95,16 @@ __device__ __forceinline__ u32x4 lds_a(const unsigned short *buf, int H, int row
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-// two fp32 values -> NS bf16 pieces each (piece p = bf16 of the residual); out[p] = packed pair (a low half, b high half)
-template <int NS>
+// two fp32 values -> NS pieces each; out[p] = packed pair (a low half, b high half).
+// bf16: piece p = bf16 of the residual.  fp16 pair: h0 = fp16(x), h1 = fp16((x - h0) * 2^11).
+template <int NS, bool F16>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[NS]) {
+    if (F16) {
+        out[0] = pack_f16(a, b);
+        const f16x2 h = __builtin_bit_cast(f16x2, out[0]);
+        if (NS > 1) out[NS > 1 ? 1 : 0] = pack_f16((a - (float)h[0]) * 2048.0f, (b - (float)h[1]) * 2048.0f);
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < NS; ++p) {
         out[p] = pack_bf16(a, b);
@@ -82,18 +115,29 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[NS]
     }
 }
 
-// acc (+ bias, ReLU) -> bf16 pieces into buf[p][row0 + r][col0 + c]
-template <int NS>
-__device__ __forceinline__ void store_tile(const f32x16 &acc, unsigned short *buf, int H, int pstride, int row0, int col0,
-                                           const float *__restrict__ bias, int lane) {
+constexpr float F16_LIMIT = 6.0e4f;       // |activation| beyond this does not fit fp16 (max 65504)
+constexpr float F16_SCALE = 1.0f / 2048.0f;
+
+// acc (+ bias, ReLU) -> pieces into buf[p][row0 + r][col0 + c].  fp16 pair: the value is acc[0] + acc[1] * 2^-11
+template <int NS, bool F16>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[F16 ? 2 : 1], unsigned short *buf, int H, int pstride, int row0, int col0,
+                                           const float *__restrict__ bias, int lane, bool &range_bad) {
     const int c = col0 + (lane & 31);
     const float b = bias[c];
     unsigned short *dst = buf + (row0 + 4 * (lane >> 5)) * H + c;
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
         const int r = (i & 3) + 8 * (i >> 2);             // rows r and r + 1
+        float v0 = acc[0][i], v1 = acc[0][i + 1];
+        if (F16) {
+            v0 += acc[F16 ? 1 : 0][i] * F16_SCALE;
+            v1 += acc[F16 ? 1 : 0][i + 1] * F16_SCALE;
+        }
+        v0 = fmaxf(v0 + b, 0.0f);
+        v1 = fmaxf(v1 + b, 0.0f);
+        if (F16) range_bad = range_bad || v0 > F16_LIMIT || v1 > F16_LIMIT;
         unsigned u[NS];
-        split_pair<NS>(fmaxf(acc[i] + b, 0.0f), fmaxf(acc[i + 1] + b, 0.0f), u);
+        split_pair<NS, F16>(v0, v1, u);
 #pragma unroll
         for (int p = 0; p < NS; ++p) {
             dst[p * pstride + r * H] = (unsigned short)u[p];
@@ -102,8 +146,9 @@ __device__ __forceinline__ void store_tile(const f32x16 &acc, unsigned short *bu
     }
 }
 
-template <int NS>
-__global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_bf16_kernel(ChainArgs args) {
+template <int NS, bool F16>
+__global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 : 2)) void p2s_chain_bf16_kernel(ChainArgs args) {
+    constexpr int NA = F16 ? 2 : 1;                       // accumulators per tile (fp16 pair: second one scaled by 2^-11)
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_bf16[];
     constexpr int SA = MT * HA, SB = MT * HB;             // halfs per piece
     unsigned short *bufA = lds_bf16;                      // [NS][MT][HA]
@@ -155,6 +200,7 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
 #pragma unroll
     for (int i = 0; i < 8; ++i) rmax[i] = -INFINITY;
     bool bad = false;       // non-finite input poisons the item (torch propagates NaN through conv / ReLU / max)
+    bool range_bad = false; // fp16 pair mode: an activation beyond the half range
 
     const int ntiles = (P + MT - 1) / MT;
     for (int tile = 0; tile < ntiles; ++tile) {
@@ -194,8 +240,9 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
                     v = fmaf(w0a[128 + o], x2, v);
                     sv[u] = fmaxf(v, 0.0f);
                 }
+                if (F16) range_bad = range_bad || sv[0] > F16_LIMIT || sv[1] > F16_LIMIT;
                 unsigned u[NS];
-                split_pair<NS>(sv[0], sv[1], u);
+                split_pair<NS, F16>(sv[0], sv[1], u);
 #pragma unroll
                 for (int p = 0; p < NS; ++p) *reinterpret_cast<unsigned *>(dst + p * SA + c) = u[p];
             }
@@ -206,9 +253,11 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
             // ---- conv0b: bufA -> bufB[:, 0:64]; wave = (row block, column tile) ----
             {
                 const int rt = wave >> 1, nt = wave & 1;          // row blocks rt, rt + 2, ...; column tile nt
-                f32x16 acc[NB / 2];
+                f32x16 acc[NB / 2][NA];
 #pragma unroll
-                for (int r = 0; r < NB / 2; ++r) acc[r] = f32x16{};
+                for (int r = 0; r < NB / 2; ++r)
+#pragma unroll
+                    for (int t = 0; t < NA; ++t) acc[r][t] = f32x16{};
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
                     u32x4 b[NS];
@@ -220,19 +269,22 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
                         for (int p = NS - 1; p >= 0; --p) {              // small terms first
                             const u32x4 a = lds_a(bufA + p * SA, HA, 32 * (rt + 2 * r), kb, lane);
 #pragma unroll
-                            for (int q = NS - 1 - p; q >= 0; --q) acc[r] = mfma_bf16(a, b[q], acc[r]);
+                            for (int q = NS - 1 - p; q >= 0; --q)
+                                acc[r][F16 ? p + q : 0] = mfma_bf16<F16>(a, b[q], acc[r][F16 ? p + q : 0]);
                         }
                 }
 #pragma unroll
-                for (int r = 0; r < NB / 2; ++r) store_tile<NS>(acc[r], bufB, HB, SB, 32 * (rt + 2 * r), 32 * nt, br.b0b, lane);
+                for (int r = 0; r < NB / 2; ++r) store_tile<NS, F16>(acc[r], bufB, HB, SB, 32 * (rt + 2 * r), 32 * nt, br.b0b, lane, range_bad);
             }
             __syncthreads();
             // ---- conv1 (STN pass: shared weights; main pass: this item's W1' = W1 . trans2): bufB -> bufA ----
             {
                 const int rt = wave >> 1, nt = wave & 1;
-                f32x16 acc[NB / 2];
+                f32x16 acc[NB / 2][NA];
 #pragma unroll
-                for (int r = 0; r < NB / 2; ++r) acc[r] = f32x16{};
+                for (int r = 0; r < NB / 2; ++r)
+#pragma unroll
+                    for (int t = 0; t < NA; ++t) acc[r][t] = f32x16{};
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
                     u32x4 b[NS];
@@ -244,19 +296,22 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
                         for (int p = NS - 1; p >= 0; --p) {
                             const u32x4 a = lds_a(bufB + p * SB, HB, 32 * (rt + 2 * r), kb, lane);
 #pragma unroll
-                            for (int q = NS - 1 - p; q >= 0; --q) acc[r] = mfma_bf16(a, b[q], acc[r]);
+                            for (int q = NS - 1 - p; q >= 0; --q)
+                                acc[r][F16 ? p + q : 0] = mfma_bf16<F16>(a, b[q], acc[r][F16 ? p + q : 0]);
                         }
                 }
 #pragma unroll
-                for (int r = 0; r < NB / 2; ++r) store_tile<NS>(acc[r], bufA, HA, SA, 32 * (rt + 2 * r), 32 * nt, br.b1, lane);
+                for (int r = 0; r < NB / 2; ++r) store_tile<NS, F16>(acc[r], bufA, HA, SA, 32 * (rt + 2 * r), 32 * nt, br.b1, lane, range_bad);
             }
             __syncthreads();
         }
         // ---- conv2 (64 -> 128): bufA -> bufB; wave = column tile, both row blocks ----
         {
-            f32x16 acc[NB];
+            f32x16 acc[NB][NA];
 #pragma unroll
-            for (int r = 0; r < NB; ++r) acc[r] = f32x16{};
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int t = 0; t < NA; ++t) acc[r][t] = f32x16{};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 u32x4 b[NS];
@@ -268,11 +323,12 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
                     for (int p = NS - 1; p >= 0; --p) {
                         const u32x4 a = lds_a(bufA + p * SA, HA, 32 * r, kb, lane);
 #pragma unroll
-                        for (int q = NS - 1 - p; q >= 0; --q) acc[r] = mfma_bf16(a, b[q], acc[r]);
+                        for (int q = NS - 1 - p; q >= 0; --q)
+                            acc[r][F16 ? p + q : 0] = mfma_bf16<F16>(a, b[q], acc[r][F16 ? p + q : 0]);
                     }
             }
 #pragma unroll
-            for (int r = 0; r < NB; ++r) store_tile<NS>(acc[r], bufB, HB, SB, 32 * r, 32 * wave, br.b2, lane);
+            for (int r = 0; r < NB; ++r) store_tile<NS, F16>(acc[r], bufB, HB, SB, 32 * r, 32 * wave, br.b2, lane, range_bad);
         }
         __syncthreads();
         // ---- conv3 (128 -> 1024) + max over the 64 points: wave w owns column tiles [8w, 8w+8) ----
@@ -281,7 +337,8 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
         // MFMAs).  Holding all three pieces of the split mode needs 192 VGPRs for A alone and spilled (r02: 48 B/lane,
         // 4.9x the algorithmic write traffic).
         {
-            constexpr int HOLD = (NS == 1) ? 1 : ((P2S_BF16_HOLD < NS) ? P2S_BF16_HOLD : NS);
+            constexpr int HOLDW = F16 ? P2S_F16_HOLD : P2S_BF16_HOLD;
+            constexpr int HOLD = (NS == 1) ? 1 : ((HOLDW < NS) ? HOLDW : NS);
             u32x4 af[HOLD > 0 ? HOLD : 1][NB][8];
 #pragma unroll
             for (int p = 0; p < HOLD; ++p)
@@ -292,9 +349,11 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
 #pragma unroll
             for (int ct = 0; ct < 8; ++ct) {
                 const int soff = (wave * 8 + ct) * 8 * 1024;        // bytes: 8 k-blocks of 64 lanes x 16 B per column tile
-                f32x16 acc[NB];
+                f32x16 acc[NB][NA];
 #pragma unroll
-                for (int r = 0; r < NB; ++r) acc[r] = f32x16{};
+                for (int r = 0; r < NB; ++r)
+#pragma unroll
+                    for (int t = 0; t < NA; ++t) acc[r][t] = f32x16{};
 #pragma unroll
                 for (int kb = 0; kb < 8; ++kb) {
                     u32x4 b[NS];
@@ -311,13 +370,15 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
 #pragma unroll
                         for (int p = NS - 1; p >= 0; --p)
 #pragma unroll
-                            for (int q = NS - 1 - p; q >= 0; --q) acc[r] = mfma_bf16(a[p][r], b[q], acc[r]);
+                            for (int q = NS - 1 - p; q >= 0; --q)
+                                acc[r][F16 ? p + q : 0] = mfma_bf16<F16>(a[p][r], b[q], acc[r][F16 ? p + q : 0]);
                 }
-                float m = acc[0][0];
+                float m = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < NB; ++r)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[r][i]);
+                    for (int i = 0; i < 16; ++i)
+                        m = fmaxf(m, F16 ? acc[r][0][i] + acc[r][F16 ? 1 : 0][i] * F16_SCALE : acc[r][0][i]);
                 m = fmaxf(m, __shfl_xor(m, 32));
                 rmax[ct] = fmaxf(rmax[ct], m);
                 // keep the weight loads of the next column tile below this point: hoisting all 64 of them spills
@@ -327,6 +388,12 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
         // (the next tile's first layer writes bufA, last read before the barrier above)
     }
     // ---- pooled output: bias (and ReLU for the STN trunks) commute with the max ----
+    if (F16) {
+        if (__ballot(range_bad) != 0ull) {
+            bad = true;                                   // poison this wave's columns of the item ...
+            if (lane == 0 && args.range_flag) atomicOr(args.range_flag, 1);      // ... and tell the host
+        }
+    }
     if (lane < 32) {
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
@@ -342,7 +409,7 @@ __global__ __launch_bounds__(256, (MT == 64 && NS == 1) ? 4 : 2) void p2s_chain_
 // fp32 packed B fragments ([N/32][K/8][2][32][4]: k = 8 kg + 4 kk + t, n = 32 nt + j) -> bf16 fragments
 // ([N/32][K/16][64 lanes][8]: k = 16 kb + 8 (lane >> 5) + t, n = 32 nt + (lane & 31)); one thread per output element
 __global__ void p2s_pack_bf16_kernel(const float *__restrict__ src, unsigned short *__restrict__ dst, int K, int N,
-                                     long long src_stride, long long dst_stride, int n_items, int piece) {
+                                     long long src_stride, long long dst_stride, int n_items, int piece, int f16) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per = (long long)K * N;
     if (e >= per * n_items) return;
@@ -358,6 +425,12 @@ __global__ void p2s_pack_bf16_kernel(const float *__restrict__ src, unsigned sho
     const int kg = k >> 3, kk = (k >> 2) & 1, ts = k & 3;
     const long long si = ((((long long)nt * (K / 8) + kg) * 2 + kk) * 32 + j) * 4 + ts;
     float x = src[(long long)item * src_stride + si];
+    if (f16) {                                        // fp16 pair: h0 = fp16(x); h1 = fp16((x - h0) * 2^11)
+        _Float16 h0 = (_Float16)x;
+        if (piece == 1) h0 = (_Float16)((x - (float)h0) * 2048.0f);
+        dst[(long long)item * dst_stride + (e % per)] = __builtin_bit_cast(unsigned short, h0);
+        return;
+    }
     unsigned short h = f2bf(x);
     for (int q = 0; q < piece; ++q) {                 // piece q = bf16 of the residual after the pieces before it
         x -= __uint_as_float((unsigned)h << 16);
@@ -373,13 +446,20 @@ int p2s_launch_chain_bf16(const ChainArgs &args, hipStream_t stream) {
     if (n <= 0) return P2S_OK;
     const int ns = args.ns < 1 ? 1 : args.ns;
     const size_t lds = (size_t)ns * MT * (HA + HB) * 2;
-    if (ns == 1) {
-        hipLaunchKernelGGL(p2s_chain_bf16_kernel<1>, dim3(n), dim3(256), lds, stream, args);
+    if (args.f16) {
+        if (ns != 2) {
+            p2s_set_error("p2s_launch_chain_bf16: the fp16 pair mode has 2 pieces, not %d", ns);
+            return P2S_EINVAL;
+        }
+        (void)hipFuncSetAttribute((const void *)p2s_chain_bf16_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((p2s_chain_bf16_kernel<2, true>), dim3(n), dim3(256), lds, stream, args);
+    } else if (ns == 1) {
+        hipLaunchKernelGGL((p2s_chain_bf16_kernel<1, false>), dim3(n), dim3(256), lds, stream, args);
     } else if (ns == 2) {
-        hipLaunchKernelGGL(p2s_chain_bf16_kernel<2>, dim3(n), dim3(256), lds, stream, args);
+        hipLaunchKernelGGL((p2s_chain_bf16_kernel<2, false>), dim3(n), dim3(256), lds, stream, args);
     } else if (ns == 3) {
-        (void)hipFuncSetAttribute((const void *)p2s_chain_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(p2s_chain_bf16_kernel<3>, dim3(n), dim3(256), lds, stream, args);
+        (void)hipFuncSetAttribute((const void *)p2s_chain_bf16_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((p2s_chain_bf16_kernel<3, false>), dim3(n), dim3(256), lds, stream, args);
     } else {
         p2s_set_error("p2s_launch_chain_bf16: %d pieces unsupported", ns);
         return P2S_EINVAL;
@@ -389,11 +469,11 @@ int p2s_launch_chain_bf16(const ChainArgs &args, hipStream_t stream) {
 }
 
 int p2s_launch_pack_bf16(const float *src, unsigned short *dst, int K, int N, long long src_stride, long long dst_stride,
-                         int n_items, int piece, hipStream_t stream) {
+                         int n_items, int piece, int f16, hipStream_t stream) {
     const long long total = (long long)K * N * n_items;
     if (total <= 0) return P2S_OK;
     hipLaunchKernelGGL(p2s_pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, K, N,
-                       src_stride, dst_stride, n_items, piece);
+                       src_stride, dst_stride, n_items, piece, f16);
     P2S_LAUNCH_CHECK("p2s_pack_bf16_kernel");
     return P2S_OK;
 }

@@ -72,13 +72,15 @@ struct ChainArgs {
     // halfs between the pieces of a weight array (shared weights / per-item W1')
     int ns;
     long long piece_stride, w1_piece_stride;
+    int f16;                 // 1: the pieces are an fp16 pair (h0, h1 * 2^11) with two accumulators (ns = 2)
+    int *range_flag;         // fp16 pair mode: device flag raised when an activation leaves the half range
 };
 int p2s_launch_chain(const ChainArgs &args, hipStream_t stream);
 // bf16 variant (p2s_chain_bf16.hip): w0b / w1 / w2 / w3 point to bf16 fragment arrays, w1_item_stride counts halfs
 int p2s_launch_chain_bf16(const ChainArgs &args, hipStream_t stream);
 // fp32 packed B fragments -> bf16 fragments, n_items matrices of K x N
 int p2s_launch_pack_bf16(const float *src, unsigned short *dst, int K, int N, long long src_stride, long long dst_stride,
-                         int n_items, int piece, hipStream_t stream);
+                         int n_items, int piece, int f16, hipStream_t stream);
 
 // W1' = (BN-folded conv1) . trans2, written in packed B-fragment order.  grid.y = encoder
 struct FoldArgs {

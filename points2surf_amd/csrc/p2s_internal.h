@@ -32,6 +32,7 @@ struct p2s_model_s {
     unsigned short *blob_h = nullptr;      // [pieces][h_total] (cfg.encoder_bf16 = number of bf16 pieces per operand)
     size_t h_total = 0;
     size_t h_w0b[2] = {}, h_s1[2] = {}, h_s2[2] = {}, h_s3[2] = {}, h_m2[2] = {}, h_m3[2] = {}, h_qc2 = 0, h_qc3 = 0;
+    int *range_flag = nullptr;             // device: raised by the fp16 pair mode when an activation leaves the half range
     float *ws = nullptr;      // per-chunk workspace, grown on demand
     int ws_chunk = 0;
     int max_chunk = 4096;     // queries per internal batch
@@ -50,6 +51,11 @@ struct p2s_model_s {
     int fault_chunk = -1;          // test hook (p2s_debug_fault_chunk): fail with P2S_EHIP before this chunk
 };
 void p2s_pipe_free(p2s_model_s *m);
+// cfg.encoder_bf16: 0 fp32, 1 bf16, 2 / 3 split bf16, 4 fp16 pair (2 pieces, two accumulators)
+inline int p2s_enc_pieces(const p2s_model_cfg &c) { return c.encoder_bf16 == 4 ? 2 : c.encoder_bf16; }
+inline int p2s_enc_f16(const p2s_model_cfg &c) { return c.encoder_bf16 == 4 ? 1 : 0; }
+// sticky range flag of the fp16 pair mode: P2S_EINVAL (and cleared) if it was raised; synchronises `s`
+int p2s_model_check_range(p2s_model_s *m, hipStream_t s);
 
 enum P2SStage { ST_CHAIN_STN = 0, ST_HEAD, ST_CHAIN_MAIN, ST_DECODER, ST_KNN, ST_SUB, ST_GRID };
 int p2s_prof_mark(p2s_model_s *m, hipStream_t s);                 // event index or -1

@@ -386,6 +386,7 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
     p2s_prof_collect(m);
     rc = p2s_rng_check(r, s);
     if (rc) return rc;
+    if ((rc = p2s_model_check_range(m, s))) return rc;
     if (n_done) *n_done = nq;
     return P2S_OK;
 }
@@ -403,6 +404,7 @@ extern "C" int p2s_infer_queries(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r_sub, 
     int rc = run_pipeline(m, c, r_sub, r_rot, q_dev, 0, n_queries, chunk, sdf_out_dev, s);
     if (rc) return rc;
     p2s_prof_collect(m);
+    if ((rc = p2s_model_check_range(m, s))) return rc;
     if ((rc = p2s_rng_check(r_sub, s))) return rc;
     if (r_rot && (rc = p2s_rng_check(r_rot, s))) return rc;
     return P2S_OK;

@@ -116,7 +116,7 @@ def _engine_cfg(train_opt, pred_dim):
         uniform_subsample=bool(getattr(train_opt, 'uniform_subsample', 0)),
         fixed_subsample=bool(getattr(train_opt, 'fixed_subsample', 0)),
         # opt-in reduced precision (BASELINE configs[3]): per-point encoder layers on bf16 MFMA, everything else fp32
-        encoder_bf16={'fp32': 0, 'bf16': 1, 'bf16x2': 2, 'bf16x3': 3}[os.environ.get('P2S_ENCODER', 'fp32')])
+        encoder_bf16={'fp32': 0, 'bf16': 1, 'bf16x2': 2, 'bf16x3': 3, 'fp16x2': 4}[os.environ.get('P2S_ENCODER', 'fp32')])
 
 
 def _load_points(indir, shape_name):

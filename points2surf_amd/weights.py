@@ -187,7 +187,7 @@ def build_blob(state_dict, cfg):
     mc.weighted_subsample = int(not bool(cfg.get('uniform_subsample', False)))
     mc.fixed_subsample = int(bool(cfg.get('fixed_subsample', False)))
     mc.single_transformer = int(single)
-    mc.encoder_bf16 = int(cfg.get('encoder_bf16', 0) or 0)      # 0 fp32, 1 bf16, 2 / 3 split bf16 (pieces per operand)
+    mc.encoder_bf16 = int(cfg.get('encoder_bf16', 0) or 0)      # 0 fp32, 1 bf16, 2 / 3 split bf16 (pieces per operand), 4 fp16 pair
     if mc.output_dim not in (1, 2):
         raise ValueError('engine supports outputs imp_surf (pred_dim 1) or imp_surf_magnitude + imp_surf_sign (pred_dim 2)')
     return blob.finish(), offs, mc

@@ -86,7 +86,7 @@ def test_bf16_deviation_from_fp32_on_reference_fixture(name, fixture_cloud, gold
 
 
 @pytest.mark.parametrize('pieces,name', [(2, 'p2s_max'), (3, 'p2s_max'), (2, 'p2s_vanilla'), (3, 'p2s_vanilla'),
-                                         (3, 'p2s_vanilla_mixed')])
+                                         (3, 'p2s_vanilla_mixed'), (4, 'p2s_max'), (4, 'p2s_vanilla'), (4, 'p2s_vanilla_mixed')])
 def test_split_bf16_against_the_reference(pieces, name, golden_dir, torch_cuda):
     """split precision (cfg encoder_bf16 = 2 / 3: every operand as 2 / 3 bf16 pieces, 3 / 6 bf16 MFMAs per product,
     fp32 accumulate): the WHOLE 128^3 grid (68,088 queries; the 2,976 of grid 32 if that golden is absent) against
@@ -111,14 +111,35 @@ def test_split_bf16_against_the_reference(pieces, name, golden_dir, torch_cuda):
     # magnitude and sign are separate logits: a flipped sign turns d into 2 |SDF| whatever the magnitude -- report the
     # magnitude deviation separately
     dm = np.abs(np.abs(sdf) - np.abs(ref))
-    print('%s bf16x%d, grid %d: max |d|SDF|| %.3g (mean %.3g), max |dSDF| %.3g, sign flips %d / %d'
+    print('%s encoder mode %d, grid %d: max |d|SDF|| %.3g (mean %.3g), max |dSDF| %.3g, sign flips %d / %d'
           % (name, pieces, res, dm.max(), dm.mean(), d.max(), int(flips.sum()), ref.size))
     assert dm.max() < 1e-4
-    if pieces == 3:
-        assert d.max() < 1e-4 and not flips.any()              # inside the contract: the fast exact mode
+    if pieces in (3, 4):     # 3 bf16 pieces (6 MFMAs per product) / the fp16 pair (3 MFMAs per product)
+        assert d.max() < 1e-4 and not flips.any()              # inside the contract: the fast exact modes
     else:
         # 16 mantissa bits move the sign logit by ~1e-4: about one query in 30,000 has a sign logit that small and
         # flips -- measured 2 / 68,088 (p2s_max) -- so two pieces are OUTSIDE the contract; bounded here, documented
         assert flips.sum() <= 8
     if name == 'p2s_vanilla_mixed':      # the weight set whose sign decision is tight: half the queries positive
         assert 0.3 < float((ref > 0).mean()) < 0.7
+
+
+def test_fp16_pair_mode_reports_activations_beyond_the_half_range(fixture_cloud, torch_cuda):
+    """encoder_bf16 = 4 carries activations as fp16 pairs (max 65504): a model whose activations leave that range must
+    not pass silently -- the affected queries come out as 1.0 (like NaN inputs) AND the call fails loudly"""
+    import torch
+    from points2surf_amd import engine, synth, _lib
+    w, cfg = synth.make_weights('p2s_max')
+    w = dict(w)
+    w['feat_local.conv0a.weight'] = (w['feat_local.conv0a.weight'] * np.float32(1e6)).astype(np.float32)
+    m = engine.Model(w, dict(cfg, encoder_bf16=4))
+    cloud = engine.Cloud(fixture_cloud)
+    with pytest.raises(_lib.P2SError) as e:
+        engine.infer_shape(m, cloud, engine.Rng(40938661), 16, 3)
+    assert e.value.code == -1 and 'half range' in str(e.value)
+    # the same weights are fine in fp32 and in the bf16 split (bf16 has the fp32 exponent range)
+    for mode in (0, 3):
+        m2 = engine.Model(w, dict(cfg, encoder_bf16=mode))
+        sdf, _ = engine.infer_shape(m2, cloud, engine.Rng(40938661), 16, 3)
+        torch.cuda.synchronize()
+        assert torch.isfinite(sdf).all()
