@@ -12,6 +12,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 # (1b) the same for the secondary workloads: p2s_vanilla pipeline, split-bf16 encoder, sign propagation + iso-surface
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_vanilla -o vanilla -- python $ROOT/tools/vanilla_bench.py > $OUT/vanilla_stdout.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bf16x3 -o bf16x3 -- python $ROOT/bench.py --steps 1 --warmup 1 --cpu-seconds 0 --bf16 3 > $OUT/bf16x3_stdout.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fp16x2 -o fp16x2 -- python $ROOT/bench.py --steps 1 --warmup 1 --cpu-seconds 0 --bf16 4 --no-secondary > $OUT/fp16x2_stdout.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_volume -o volume -- python $ROOT/tools/volume_bench.py 256 > $OUT/volume_stdout.log 2>&1
 if [ -n "$P2S_PROFILE_LIGHT" ]; then find $OUT -name "*.csv" | head -80 > $OUT/files.txt; exit 0; fi   # traces only (the PMC passes of an earlier run stay valid while the encoder kernels are unchanged)
 # (2) PMC passes on a smaller encoder-only workload, kernel-trace only (counters in their own runs)
@@ -27,6 +28,13 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU
            "FETCH_SIZE" "WRITE_SIZE"; do
   name=$(echo $grp | cut -d' ' -f1)
   timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d $OUT/pmcbf_$name -o pmc -- python $ROOT/tools/quick_bench.py --B 4096 --iters 1 --bf16 3 > $OUT/pmcbf_$name.log 2>&1
+done
+# (4) and for the fp16 pair kernel
+for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE" \
+           "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  name=$(echo $grp | cut -d' ' -f1)
+  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d $OUT/pmcf16_$name -o pmc -- python $ROOT/tools/quick_bench.py --B 4096 --iters 1 --bf16 4 > $OUT/pmcf16_$name.log 2>&1
 done
 rocprofv3 -L 2>/dev/null | grep -i -E "mfma|FETCH_SIZE|WRITE_SIZE|GRBM_GUI|LDS_BANK" | head -40 > $OUT/counters_available.txt
 find $OUT -name "*.csv" | head -80 > $OUT/files.txt

@@ -14,10 +14,11 @@ shutil.copy(os.path.join(src, 'trace', 'bench_kernel_stats.csv'), os.path.join(o
 if os.path.isfile(os.path.join(src, 'counters_available.txt')):
     shutil.copy(os.path.join(src, 'counters_available.txt'), os.path.join(out, 'counters_available.txt'))
 for sub, name in (('trace_vanilla', 'vanilla_kernel_stats.csv'), ('trace_bf16x3', 'bf16x3_kernel_stats.csv'),
-                  ('trace_volume', 'volume_kernel_stats.csv')):
+                  ('trace_fp16x2', 'fp16x2_kernel_stats.csv'), ('trace_volume', 'volume_kernel_stats.csv')):
     if os.path.isfile(os.path.join(src, sub, name)):
         shutil.copy(os.path.join(src, sub, name), os.path.join(out, name))
 for log, name in (('trace_stdout.log', 'bench_profiled.json'), ('bf16x3_stdout.log', 'bench_bf16x3_profiled.json'),
+                  ('fp16x2_stdout.log', 'bench_fp16x2_profiled.json'),
                   ('vanilla_stdout.log', 'vanilla_profiled.json'), ('volume_stdout.log', 'volume_profiled.json')):
     if os.path.isfile(os.path.join(src, log)):
         js = [l for l in open(os.path.join(src, log)).read().split('\n') if l.startswith('{')]
@@ -57,21 +58,29 @@ summ = {'workload': 'tools/quick_bench.py --B 4096 --iters 1 (p2s_max encoders+d
             'hbm_traffic_bytes_per_launch': fetch + write,
             'lds_bank_conflict_cycles': ch['SQ_LDS_BANK_CONFLICT']['avg_per_dispatch']},
         'raw': raw}
-bf = raw.get('p2s_chain_bf16_kernel<3>') or raw.get('p2s_chain_bf16_kernel')
-if bf:
-    durb = [r[-1] for r in rows if r[1].startswith('chain_bf16_kernel') and r[9] == 'GRBM_GUI_ACTIVE']
+def split_kernel(names, label, workload, mops):
+    key = next((n for n in names if n in raw), None)
+    if not key:
+        return
+    bf = raw[key]
+    short = key[len('p2s_'):]
+    durb = [r[-1] for r in rows if r[1] == short and r[9] == 'GRBM_GUI_ACTIVE']
     cycb = bf['GRBM_GUI_ACTIVE']['avg_per_dispatch'] / 8
-    summ['chain_bf16x3_kernel'] = {
-        'workload': 'tools/quick_bench.py --B 4096 --iters 1 --bf16 3',
+    summ[label] = {
+        'workload': workload, 'kernel': key,
         'queries_per_launch': 4096, 'avg_duration_ms_under_pmc': sum(durb) / len(durb) / 1e6,
         'cycles_per_launch': cycb, 'clock_GHz': cycb / (sum(durb) / len(durb)),
         'mfma_busy_frac': bf['SQ_VALU_MFMA_BUSY_CYCLES']['avg_per_dispatch'] / (1024 * cycb),
-        'executed_mfma_bf16_flop_per_launch': bf['SQ_INSTS_VALU_MFMA_MOPS_BF16']['avg_per_dispatch'] * 512
-        if 'SQ_INSTS_VALU_MFMA_MOPS_BF16' in bf else None,
+        'executed_mfma_flop_per_launch': bf[mops]['avg_per_dispatch'] * 512 if mops in bf else None,
         'fetch_bytes_per_launch_corrected_x2': bf['FETCH_SIZE']['avg_per_dispatch'] * 1024 * 2 if 'FETCH_SIZE' in bf else None,
         'write_bytes_per_launch': bf['WRITE_SIZE']['avg_per_dispatch'] * 1024 if 'WRITE_SIZE' in bf else None,
-        'lds_bank_conflict_cycles': bf['SQ_LDS_BANK_CONFLICT']['avg_per_dispatch'] if 'SQ_LDS_BANK_CONFLICT' in bf else None,
-        'wait_inst_any_frac_of_wave_cycles': None}
+        'lds_bank_conflict_cycles': bf['SQ_LDS_BANK_CONFLICT']['avg_per_dispatch'] if 'SQ_LDS_BANK_CONFLICT' in bf else None}
+
+
+split_kernel(('p2s_chain_bf16_kernel<3, false>', 'p2s_chain_bf16_kernel<3>'), 'chain_bf16x3_kernel',
+             'tools/quick_bench.py --B 4096 --iters 1 --bf16 3', 'SQ_INSTS_VALU_MFMA_MOPS_BF16')
+split_kernel(('p2s_chain_bf16_kernel<2, true>',), 'chain_fp16x2_kernel',
+             'tools/quick_bench.py --B 4096 --iters 1 --bf16 4 (fp16 pair per operand)', 'SQ_INSTS_VALU_MFMA_MOPS_F16')
 b1 = raw.get('p2s_chain_bf16_kernel<1>')
 if b1:
     dur1 = [r[-1] for r in rows if r[1] == 'chain_bf16_kernel<1>' and r[9] == 'GRBM_GUI_ACTIVE']
@@ -88,4 +97,5 @@ if b1:
 json.dump(summ, open(os.path.join(out, 'pmc_summary.json'), 'w'), indent=1)
 print(json.dumps(summ['chain_kernel'], indent=1))
 print(json.dumps(summ.get('chain_bf16x3_kernel'), indent=1))
+print(json.dumps(summ.get('chain_fp16x2_kernel'), indent=1))
 print(json.dumps(summ.get('chain_bf16_kernel'), indent=1))
