@@ -173,6 +173,12 @@ int p2s_query_grid(p2s_cloud_t c, int grid_resolution, int epsilon, float *q_out
  *   radius_out_dev [Q] (may be NULL) */
 int p2s_knn_patch(p2s_cloud_t c, const float *query_dev, int64_t n_queries, int k,
                   int32_t *ids_out_dev, float *patch_ps_out_dev, float *radius_out_dev, void *stream);
+/* the same k nearest points as a SET: patch rows in an arbitrary (deterministic) order, no ids -- what the per-shape
+ * pipeline uses: the encoders max-pool over the patch, so the order of its points changes no bit of the result, and the
+ * k smallest distances are selected by bisection on their bit patterns instead of a sort (~3x faster).  Ties at the
+ * k-th distance are broken by id exactly like p2s_knn_patch.  radius_out_dev as above. */
+int p2s_knn_patch_set(p2s_cloud_t c, const float *query_dev, int64_t n_queries, int k,
+                      float *patch_ps_out_dev, float *radius_out_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * a6: global sub-sample (reference source/base/utils.py:196-227 with the dataset-wide

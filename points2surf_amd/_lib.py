@@ -44,6 +44,7 @@ PROTOTYPES = {
                                        c_void_p]),
     'p2s_query_grid': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
     'p2s_knn_patch': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'p2s_knn_patch_set': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'p2s_rng_create': (c_int, [ctypes.c_uint32, c_int, ctypes.POINTER(c_void_p)]),
     'p2s_rng_destroy': (c_int, [c_void_p]),
     'p2s_rng_get_state': (c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_int32), c_void_p]),

@@ -208,6 +208,90 @@ __device__ void knn_prune(KnnList &L, int lane) {
     }
 }
 
+// The k smallest (distance, id) pairs of the list as a SET, moved to its front in list order -- no sort.  What the
+// pipeline needs: the encoders max-pool over the patch, so the order of its points changes no bit of the result; only
+// the API that hands out ids keeps the sorted order (knn_prune).  Bisection on the 64-bit distance patterns for a value
+// that separates the k-th from the (k+1)-th smallest: about log2(len) + 2 steps of len / 64 LDS reads each, where the
+// bitonic network costs ~45 barriers and 1440 LDS accesses for 512 entries.  A tie at the k-th distance (duplicate
+// points) falls back to the sort, whose id tie-break is the reference's.  thr2 = the separating value (an upper bound of
+// the k-th distance of everything scanned so far).
+__device__ void knn_select(KnnList &L, int lane) {
+    __syncthreads();
+    const int len = L.len, k = L.k;
+    if (len < k) return;
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+    for (int i = lane; i < len; i += 64) {
+        const unsigned long long v = L.keys[i];
+        kmin = v < kmin ? v : kmin;
+        kmax = v > kmax ? v : kmax;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long a = __shfl_xor(kmin, d), b = __shfl_xor(kmax, d);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    unsigned long long T = kmax;
+    if (len > k) {
+        // invariant: count(<= lo) < k <= count(<= hi)
+        unsigned long long lo = kmin - 1ull, hi = kmax;         // kmin >= 0 as a pattern; kmin - 1 wraps only for d2 = +0.0
+        bool found = false;
+        if (kmin == 0ull) {                                      // (a query on top of a point): count(<= 0) may already be >= k
+            int c0 = 0;
+            for (int i = lane; i < len; i += 64) c0 += L.keys[i] == 0ull ? 1 : 0;
+            for (int d = 32; d > 0; d >>= 1) c0 += __shfl_xor(c0, d);
+            if (c0 >= k) {
+                hi = 0ull;
+                lo = 0ull;
+                found = c0 == k;
+                T = 0ull;
+            } else {
+                lo = 0ull;
+            }
+        }
+        while (!found && hi - lo > 1ull) {
+            const unsigned long long mid = lo + ((hi - lo) >> 1);
+            int cnt = 0;
+            for (int i = lane; i < len; i += 64) cnt += L.keys[i] <= mid ? 1 : 0;
+            for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+            if (cnt == k) {
+                T = mid;
+                found = true;
+            } else if (cnt > k) {
+                hi = mid;
+            } else {
+                lo = mid;
+            }
+        }
+        if (!found) {                                            // several entries share the k-th distance
+            knn_prune(L, lane);
+            return;
+        }
+        // ordered in-place compaction of the entries <= T (a chunk is read before anything is written over it)
+        int out = 0;
+        for (int base = 0; base < len; base += 64) {
+            const int i = base + lane;
+            unsigned long long v = 0ull;
+            int id = 0;
+            bool keep = false;
+            if (i < len) {
+                v = L.keys[i];
+                id = L.ids[i];
+                keep = v <= T;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int o = out + __popcll(m & ((1ull << lane) - 1ull));
+                L.keys[o] = v;
+                L.ids[o] = id;
+            }
+            out += __popcll(m);
+        }
+        L.len = k;
+    }
+    L.thr2 = __longlong_as_double((long long)T);
+    __syncthreads();
+}
+
 // scan cells [lo, hi]; if has_ex, cells inside [exlo, exhi] were scanned before and are skipped.
 // The box is a set of z-contiguous cell runs, one per (x, y) column (two where the column crosses the excluded box).
 // Walking them one after the other costs two dependent L2 round trips per run for ~10 points (r02: 49 runs per query,
@@ -283,6 +367,9 @@ __device__ void knn_scan(const CloudDev &c, KnnList &L, const int lo[3], const i
     }
 }
 
+// SORTED: ids / patch rows in ascending distance (the API's contract).  !SORTED (the per-shape pipeline): the same k
+// points in list order, selected without sorting (knn_select).
+template <bool SORTED>
 __global__ __launch_bounds__(64) void p2s_knn_kernel(CloudDev c, const float *__restrict__ queries, long long nq,
                                                      int k, int *__restrict__ ids_out,
                                                      float *__restrict__ patch_out,
@@ -312,7 +399,9 @@ __global__ __launch_bounds__(64) void p2s_knn_kernel(CloudDev c, const float *__
         KnnList L{keys, lids, 0, INFINITY, k};
         __syncthreads();
         knn_scan(c, L, lo, hi, false, lo, hi, qx, qy, qz, lane, run_start, run_off);
-        knn_prune(L, lane);   // exact k-th distance among the cube's points: an upper bound of the true one
+        // exact k-th distance among the cube's points (or a value just above it): an upper bound of the true one
+        if (SORTED) knn_prune(L, lane);
+        else knn_select(L, lane);
         // every point within sqrt(thr2) of q lies in cells [lo2, hi2] (conservative: radius rounded up, and
         // cell_coord is monotone)
         const float r = (float)sqrt(L.thr2) * 1.00001f + 1e-30f;
@@ -328,7 +417,10 @@ __global__ __launch_bounds__(64) void p2s_knn_kernel(CloudDev c, const float *__
         if (grow) {
             const int before = L.len;
             knn_scan(c, L, lo2, hi2, true, lo, hi, qx, qy, qz, lane, run_start, run_off);
-            if (L.len != before) knn_prune(L, lane);
+            if (L.len != before) {
+                if (SORTED) knn_prune(L, lane);
+                else knn_select(L, lane);
+            }
         }
         __syncthreads();
         // ---- outputs: ids (ascending distance), r = max ||q - p||_2 (fp32, numpy op order), (p - q) / r ----
@@ -1194,8 +1286,31 @@ int p2s_knn_patch(p2s_cloud_t c, const float *query_dev, int64_t nq, int k, int3
     P2S_HIP_CHECK(hipSetDevice(c->device));
     p2s_cloud_note_stream(c, (hipStream_t)stream);
     const unsigned grid = (unsigned)std::min<int64_t>(nq, 256 * 64);
-    hipLaunchKernelGGL(p2s_knn_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, c->d, query_dev, (long long)nq, k,
+    hipLaunchKernelGGL(p2s_knn_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, c->d, query_dev, (long long)nq, k,
                        ids_out_dev, patch_ps_out_dev, radius_out_dev);
+    P2S_LAUNCH_CHECK("p2s_knn_kernel");
+    return P2S_OK;
+}
+
+// the pipeline's variant: the same k nearest points, patch rows in arbitrary (deterministic) order, no ids
+int p2s_knn_patch_set(p2s_cloud_t c, const float *query_dev, int64_t nq, int k, float *patch_ps_out_dev,
+                      float *radius_out_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!c || !query_dev || nq < 0 || k < 1 || k > c->d.n || k > KNN_CAP - 128) {
+        p2s_set_error("p2s_knn_patch_set: bad argument (k=%d)", k);
+        return P2S_EINVAL;
+    }
+    if (nq == 0) return P2S_OK;
+    P2S_HIP_CHECK(hipSetDevice(c->device));
+    p2s_cloud_note_stream(c, stream);
+    const unsigned grid = (unsigned)std::min<int64_t>(nq, 256 * 64);
+    static const bool sorted = getenv("P2S_KNN_SORTED") != nullptr;          // development: A/B against the sorting kernel
+    if (sorted)
+        hipLaunchKernelGGL(p2s_knn_kernel<true>, dim3(grid), dim3(64), 0, stream, c->d, query_dev, (long long)nq, k,
+                           (int *)nullptr, patch_ps_out_dev, radius_out_dev);
+    else
+        hipLaunchKernelGGL(p2s_knn_kernel<false>, dim3(grid), dim3(64), 0, stream, c->d, query_dev, (long long)nq, k,
+                           (int *)nullptr, patch_ps_out_dev, radius_out_dev);
     P2S_LAUNCH_CHECK("p2s_knn_kernel");
     return P2S_OK;
 }

@@ -145,6 +145,7 @@ void *p2s_pool_alloc(int device, size_t bytes);
 void p2s_pool_free(int device, void *p);
 void p2s_cloud_note_stream(p2s_cloud_s *c, hipStream_t s);
 
+
 // query grid of (res, eps), computed once per cloud handle and kept on the device (p2s_cloud.hip); *q is owned by
 // the handle and valid until the next call with other parameters; stream-ordered on `s` (synchronises it once to
 // learn the count)

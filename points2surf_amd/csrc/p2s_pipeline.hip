@@ -296,7 +296,7 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         if (sp != s && ci >= nbuf) PIPE_HIP(hipStreamWaitEvent(sp, b.done[bi], 0));
         const int ek0 = p2s_prof_mark(m, sp);
         int rc2 = small ? p2s_knn_patch(c, qc, cur, k, b.knn_ids[bi], nullptr, nullptr, sp)
-                        : p2s_knn_patch(c, qc, cur, k, nullptr, b.patch[bi], b.radius[bi], sp);
+                        : p2s_knn_patch_set(c, qc, cur, k, b.patch[bi], b.radius[bi], sp);
         if (rc2) return fail(rc2);
         p2s_prof_span(m, ST_KNN, ek0, p2s_prof_mark(m, sp));
         if (sa != sp) PIPE_HIP(hipStreamWaitEvent(sp, b.ready[bi], 0));

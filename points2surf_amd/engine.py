@@ -214,6 +214,18 @@ class Cloud:
                                               _stream_ptr(self.device)))
         return ids, patch, rad
 
+    def knn_patch_set(self, queries, k):
+        """a4+a5 as the pipeline runs them: the k nearest points as a set -> (patch_ps [Q,k,3] rows in arbitrary order,
+        radius [Q]); no sort (p2s_knn_patch_set)"""
+        q = _f32c(queries, self.device)
+        Q = q.shape[0]
+        patch = torch.empty((Q, k, 3), dtype=torch.float32, device=self.device)
+        rad = torch.empty((Q,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.p2s_knn_patch_set(self.handle, _ptr(q), Q, int(k), _ptr(patch), _ptr(rad),
+                                                  _stream_ptr(self.device)))
+        return patch, rad
+
     def gather(self, ids):
         ids = ids.to(self.device, torch.int32).contiguous()
         out = torch.empty(tuple(ids.shape) + (3,), dtype=torch.float32, device=self.device)

@@ -1,4 +1,6 @@
 """Stress / randomized checks of the data-path kernels against the oracle (GPU)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -35,6 +37,36 @@ def test_knn_large_clustered_cloud_with_duplicates():
     assert np.array_equal(ids[no_tie], ref[no_tie])                             # without ties: identical ids
     r_ref, _ = O.patch_radius_and_ps(pts, ids, q)
     assert np.array_equal(rad.cpu().numpy(), r_ref)
+
+
+@pytest.mark.parametrize('k', [1, 64, 300, 1200])
+def test_knn_selection_kernel_returns_the_same_set_as_the_sorting_kernel(k):
+    """the pipeline's kNN selects the k smallest distances by bisection instead of sorting: same points (rows of the patch
+    as a set), bit-identical radius -- on the fixture, on a clustered cloud with duplicate stacks (ties at the k-th
+    distance fall back to the sort) and with queries sitting exactly on points"""
+    import torch
+    from points2surf_amd import engine
+    rng = np.random.default_rng(7)
+    fixture = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cloud_abc_00994122.npy')).astype(np.float32)
+    clustered = np.concatenate([rng.uniform(-0.5, 0.5, (40000, 3)),
+                                0.002 * rng.standard_normal((20000, 3)) + rng.uniform(-0.4, 0.4, (20, 1, 3)).repeat(1000, 1).reshape(-1, 3),
+                                np.repeat(rng.uniform(-0.3, 0.3, (30, 3)), 400, axis=0)]).astype(np.float32)
+    for pts in (fixture, clustered):
+        cloud = engine.Cloud(pts)
+        q = np.concatenate([pts[rng.integers(0, pts.shape[0], 300)] + rng.normal(0, 0.004, (300, 3)),
+                            pts[rng.integers(0, pts.shape[0], 40)],                  # distance 0 to a point / a stack
+                            rng.uniform(-0.9, 0.9, (60, 3))]).astype(np.float32)
+        qd = torch.from_numpy(q).cuda()
+        _, patch_sorted, rad_sorted = cloud.knn_patch(qd, k)
+        patch_set, rad_set = cloud.knn_patch_set(qd, k)
+        torch.cuda.synchronize()
+        a, b = patch_sorted.cpu().numpy(), patch_set.cpu().numpy()
+        assert np.array_equal(rad_sorted.cpu().numpy(), rad_set.cpu().numpy())
+        for i in range(q.shape[0]):
+            ra = a[i][np.lexsort(a[i].T[::-1])]
+            rb = b[i][np.lexsort(b[i].T[::-1])]
+            assert np.array_equal(ra, rb, equal_nan=True), (i, k)
+        cloud.close()
 
 
 def test_query_grid_random_clouds_match_oracle():
