@@ -426,7 +426,8 @@ __global__ __launch_bounds__(64) void p2s_knn_kernel(CloudDev c, const float *__
         // ---- outputs: ids (ascending distance), r = max ||q - p||_2 (fp32, numpy op order), (p - q) / r ----
         float smax = 0.0f;
         for (int j = lane; j < k; j += 64) {
-            const int id = lids[j];
+            int id = lids[j];
+            if ((unsigned)id >= (unsigned)c.n) id = 0;      // a non-finite query finds no candidates: stay inside the cloud
             if (ids_out) ids_out[qi * k + j] = id;
             const float dx = qxf - c.pts[3 * id + 0];
             const float dy = qyf - c.pts[3 * id + 1];
@@ -439,7 +440,8 @@ __global__ __launch_bounds__(64) void p2s_knn_kernel(CloudDev c, const float *__
         if (radius_out && lane == 0) radius_out[qi] = rad;
         if (patch_out) {
             for (int j = lane; j < k; j += 64) {
-                const int id = lids[j];
+                int id = lids[j];
+                if ((unsigned)id >= (unsigned)c.n) id = 0;
                 float *dst = patch_out + (qi * k + j) * 3;
                 dst[0] = (c.pts[3 * id + 0] - qxf) / rad;
                 dst[1] = (c.pts[3 * id + 1] - qyf) / rad;
