@@ -137,6 +137,7 @@ struct p2s_rng_s {
     double *wc_S = nullptr;        // [C][n]   exact prefix sums of the probabilities
     void *wc_T = nullptr;          // [C][K]   guide records of the cdf (32 B each)
     double *wc_stot = nullptr;     // [C]
+    unsigned short *wc_J = nullptr; // [11][SP_B][SP_W] jump tables of the offsets chain (p2s_wchoice.hip)
     size_t wc_cap_q = 0, wc_cap_n = 0, wc_cap_k = 0;
 };
 

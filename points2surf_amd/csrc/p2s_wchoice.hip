@@ -1181,7 +1181,58 @@ struct WcSpec {
     const float *mu;          // [nq] expected first-round collisions
     int *win_bin;             // [SP_B][SP_NB] first-round bin of every draw of the window (-1: past the request)
     double2 *win_s;           // [SP_B][SP_NB] (S_bin, S_{bin-1}) of it: what the complete algorithm needs of round 1
+    unsigned short *jump;     // [SP_LEV][SP_B][SP_W] jump tables (below); nullptr = walk query by query
 };
+
+// ---- the walk s -> s + 2 (nsel + R_q(s)) without walking --------------------------------------------------------------
+// In window coordinates (d = (s - klo[q]) / 2, candidate d of query q) one step is
+//     next(q, d) = d + R_q(d) + nsel + (klo[q] - klo[q + 1]) / 2        if R_q(d) is decided and the result is a candidate of q + 1
+// -- a table look-up.  2^k steps at once are the look-up J_k[q][d] with J_k = J_{k-1} o J_{k-1} (all CUs, 2 M entries
+// per level, 11 levels for a block of 2048 queries), so the one workgroup that owns the serial dependence no longer pays
+// one dependent L2 round trip per QUERY (1.4 us each, 2.9 ms per block) but ~11 per SEGMENT between two queries it has
+// to resolve itself (undecided candidates: ~5 % of the queries), and the word offsets of the queries inside a segment
+// are filled in by all its lanes afterwards (binary lifting from the segment start).
+constexpr int SP_LEV = 11;
+static_assert((1 << SP_LEV) >= SP_B, "jump levels cover a block");
+constexpr unsigned short SP_INV = 0xffffu;
+
+__global__ __launch_bounds__(256) void wc_jump0_kernel(WcArgs a, WcSpec sp) {
+    if (a.meta[1] != 0) return;
+    const long long qb = sp.ctl[0];
+    if (qb >= a.nq) return;
+    const int lim = (int)(a.nq - qb < SP_B ? a.nq - qb : SP_B);
+    const int i = blockIdx.x;
+    unsigned short *J0 = sp.jump + (size_t)i * SP_W;
+    if (i >= lim) return;
+    const bool last = i + 1 >= lim;                      // the step of the block's last query leaves the block: not a jump
+    const int delta = last ? 0 : a.nsel + (int)((sp.klo[i] - sp.klo[i + 1]) >> 1);
+    for (int d = threadIdx.x; d < SP_W; d += 256) {
+        const unsigned r = sp.rtab[(size_t)i * SP_W + d];
+        const int nd = d + (int)r + delta;
+        J0[d] = (last || r == 255u || nd < 0 || nd >= SP_W) ? SP_INV : (unsigned short)nd;
+    }
+}
+
+// level k from level k - 1: 2^k steps = 2^(k-1) steps twice
+__global__ __launch_bounds__(256) void wc_jumpk_kernel(WcArgs a, WcSpec sp, int k) {
+    if (a.meta[1] != 0) return;
+    const long long qb = sp.ctl[0];
+    if (qb >= a.nq) return;
+    const int lim = (int)(a.nq - qb < SP_B ? a.nq - qb : SP_B);
+    const int i = blockIdx.x, half = 1 << (k - 1);
+    if (i >= lim) return;
+    const unsigned short *Jp = sp.jump + (size_t)(k - 1) * SP_B * SP_W;
+    unsigned short *Jk = sp.jump + (size_t)k * SP_B * SP_W + (size_t)i * SP_W;
+    const bool reach = i + 2 * half <= lim - 1;          // lands on a query of the block
+    for (int d = threadIdx.x; d < SP_W; d += 256) {
+        unsigned short v = SP_INV;
+        if (reach) {
+            const unsigned short m = Jp[(size_t)i * SP_W + d];
+            if (m != SP_INV) v = Jp[(size_t)(i + half) * SP_W + m];
+        }
+        Jk[d] = v;
+    }
+}
 
 __global__ void wc_ctl_init_kernel(long long *ctl, const long long *meta) {
     ctl[0] = 0;
@@ -1389,6 +1440,12 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp) {
     int i = 0;
     long long t_fb = 0, n_fb = 0;
     const long long t_start = a.stats ? wall_clock64() : 0;
+    // jump mode: s_mark[j] = window coordinate of query j where the walk KNEW it (block start, after a query it resolved
+    // itself); the queries in between are filled in at the end
+    __shared__ unsigned short s_mark[SP_B];
+    const bool jumping = sp.jump != nullptr;
+    if (jumping)
+        for (int j = tid; j < SP_B; j += 256) s_mark[j] = SP_INV;
     __syncthreads();
     for (;;) {
         if (tid == 0) {
@@ -1398,8 +1455,26 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp) {
                     ev = 3;
                     break;
                 }
-                const long long d = (s - s_klo[i]) >> 1;
+                long long d = (s - s_klo[i]) >> 1;
                 if (d < 0 || d >= SP_W) break;
+                if (jumping) {
+                    // as far as whole jumps go (validity of a jump = validity of every step in it, so the greedy
+                    // descent through the levels ends on the last query before an undecided / outside step)
+                    s_mark[i] = (unsigned short)d;
+                    for (int k = SP_LEV - 1; k >= 0; --k) {
+                        if (i + (1 << k) > lim - 1) continue;
+                        const unsigned short v = sp.jump[((size_t)k * SP_B + i) * SP_W + d];
+                        if (v != SP_INV) {
+                            i += 1 << k;
+                            d = v;
+                        }
+                    }
+                    s = s_klo[i] + 2 * d;
+                    if (s + 2LL * a.nsel > a.cap_words) {
+                        ev = 3;
+                        break;
+                    }
+                }
                 const unsigned r = sp.rtab[(size_t)i * SP_W + d];
                 if (r == 255u) {
                     ev = 1;
@@ -1457,6 +1532,47 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp) {
             ++n_fb;
         }
         __syncthreads();
+    }
+    if (jumping) {
+        // word offsets of the queries the walk jumped over: nearest known start at or below j (prefix maximum over the
+        // marks), then j - start steps by binary lifting.  Queries >= i were not reached.
+        __shared__ short s_from[SP_B];
+        __syncthreads();
+        for (int j0 = tid * (SP_B / 256); j0 < (tid + 1) * (SP_B / 256); ++j0) s_from[j0] = s_mark[j0] != SP_INV ? (short)j0 : (short)-1;
+        __syncthreads();
+        {   // prefix maximum: 8 consecutive entries per lane, then across lanes
+            __shared__ short s_lane[256];
+            const int b0 = tid * (SP_B / 256);
+            short run = -1;
+            for (int j0 = b0; j0 < b0 + SP_B / 256; ++j0) {
+                run = s_from[j0] > run ? s_from[j0] : run;
+                s_from[j0] = run;
+            }
+            s_lane[tid] = run;
+            __syncthreads();
+            short before = -1;
+            for (int t = 0; t < tid; ++t) before = s_lane[t] > before ? s_lane[t] : before;
+            for (int j0 = b0; j0 < b0 + SP_B / 256; ++j0)
+                if (s_from[j0] < before) s_from[j0] = before;
+            __syncthreads();
+        }
+        for (int j = tid; j < i; j += 256) {
+            int ii = s_from[j];
+            if (ii < 0) continue;                         // (cannot happen: query 0 of the block is always a start)
+            int dd = s_mark[ii];
+            int m = j - ii;
+            for (int k = SP_LEV - 1; k >= 0 && m > 0 && dd != SP_INV; --k) {
+                if (m >= (1 << k)) {
+                    dd = sp.jump[((size_t)k * SP_B + ii) * SP_W + dd];
+                    ii += 1 << k;
+                    m -= 1 << k;
+                }
+            }
+            // (a start itself: m = 0 from the beginning.  The ids kernel re-derives every query's consumption and flags
+            //  any disagreement, so a wrong offset cannot pass silently.)
+            if (m == 0 && dd != SP_INV) a.base[qb + j] = s_klo[j] + 2LL * dd;
+            else if (j < i) a.meta[1] = 4;
+        }
     }
     if (tid == 0) {
         if (a.stats) {
@@ -1607,11 +1723,13 @@ int wc_reserve(p2s_rng_s *r, size_t nq, size_t n, size_t K) {
     if (r->wc_S) (void)hipFree(r->wc_S);
     if (r->wc_T) (void)hipFree(r->wc_T);
     if (r->wc_stot) (void)hipFree(r->wc_stot);
-    r->wc_S = nullptr; r->wc_T = nullptr; r->wc_stot = nullptr;
+    if (r->wc_J) (void)hipFree(r->wc_J);
+    r->wc_S = nullptr; r->wc_T = nullptr; r->wc_stot = nullptr; r->wc_J = nullptr;
     r->wc_cap_q = r->wc_cap_n = r->wc_cap_k = 0;
     nq = std::max(nq, r->wc_cap_q);
     if (hipMalloc(&r->wc_S, nq * n * 8) != hipSuccess ||
         hipMalloc(&r->wc_T, nq * K * sizeof(WcRec)) != hipSuccess ||
+        hipMalloc(&r->wc_J, (size_t)SP_LEV * SP_B * SP_W * 2) != hipSuccess ||
         hipMalloc(&r->wc_stot, nq * 32 + (size_t)SP_B * SP_W + (size_t)SP_B * 8 + 64 + (size_t)SP_B * SP_NB * 20 + 64) != hipSuccess) {
         (void)hipGetLastError();
         p2s_set_error("weighted sub-sample: hipMalloc of the per-query tables failed (%zu queries x %zu points)", nq, n);
@@ -1629,6 +1747,7 @@ void p2s_wc_free_rng(p2s_rng_s *r) {
     if (r->wc_S) (void)hipFree(r->wc_S);
     if (r->wc_T) (void)hipFree(r->wc_T);
     if (r->wc_stot) (void)hipFree(r->wc_stot);
+    if (r->wc_J) (void)hipFree(r->wc_J);
 }
 
 static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_t nq, int n_sel, int32_t *ids_out_dev,
@@ -1708,6 +1827,7 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     sp.mu = mu;
     sp.win_s = (double2 *)(((uintptr_t)(sp.rtab + (size_t)SP_B * SP_W) + 15) & ~(uintptr_t)15);
     sp.win_bin = (int *)(sp.win_s + (size_t)SP_B * SP_NB);
+    sp.jump = getenv("P2S_WC_NO_JUMP") ? nullptr : r->wc_J;                 // development / A-B: walk query by query
     const bool serial_only = getenv("P2S_WC_SERIAL") != nullptr;            // development / A-B: the serial kernel alone
     const size_t lds_ids = wc_lds_bytes(n);
     size_t lds_off = wc_offsets_lds_bytes(n);
@@ -1727,7 +1847,7 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     {   // per device (a process may drive several); the call is cheap
         (void)hipFuncSetAttribute((const void *)wc_offsets_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         (void)hipFuncSetAttribute((const void *)wc_ids_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)wc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096 - SP_B * 8);
+        (void)hipFuncSetAttribute((const void *)wc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096 - SP_B * 8 - SP_B * 4 - 1024);
         (void)hipFuncSetAttribute((const void *)wc_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NP_BUFSIZE + WC_MAX_NODES) * 4);
     }
     long long *meta = p2s_rng_raw_meta(r);
@@ -1779,6 +1899,11 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
             const int pairs = (cur + SP_B - 1) / SP_B + (cur > SP_B / 2 ? 2 : 0);
             for (int pr = 0; pr < pairs; ++pr) {
                 hipLaunchKernelGGL(wc_spec_kernel, dim3(std::min(cur, SP_B)), dim3(256), 0, s, a, sp);
+                if (sp.jump) {
+                    hipLaunchKernelGGL(wc_jump0_kernel, dim3(std::min(cur, SP_B)), dim3(256), 0, s, a, sp);
+                    for (int k = 1; k < SP_LEV && (1 << k) < std::min(cur, SP_B); ++k)
+                        hipLaunchKernelGGL(wc_jumpk_kernel, dim3(std::min(cur, SP_B)), dim3(256), 0, s, a, sp, k);
+                }
                 hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), pr < (cur + SP_B - 1) / SP_B ? lds_chain : lds_ids, s, a, sp);
             }
             a.ctl = sp.ctl;
