@@ -50,3 +50,34 @@ def test_eight_ranks_three_clouds_at_the_real_world_size():
     g = d['self_check']['vs_reference_golden']
     assert g['file'].endswith('ref_rec_p2s_max_abc3_grid64.npz') and len(g['shapes']) == 3
     assert g['sign_flips'] == 0 and g['max_abs_dsdf'] < 1e-4 and g['queries'] == sum(d['config']['queries_per_shape'].values())
+
+
+def test_golden_check_classifies_a_flipped_sign_with_device_and_cpu_logits(fixture_cloud):
+    """the self-check's flip analysis: a doctored golden with ONE sign reversed must come back as one flip
+    that is NOT an fp32 tie (both the device's and the CPU port's sign logit are far from zero), with the unmasked
+    difference = 2 |sdf| -- and the same machinery positions the stream at a query of the SECOND shape of a dataset"""
+    import importlib.util
+    import numpy as np
+    import torch
+    spec = importlib.util.spec_from_file_location('p2s_bench', os.path.join(REPO, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from points2surf_amd import engine, parity, synth
+    w, cfg = synth.make_weights('p2s_max')
+    model = engine.Model(w, cfg)
+    a = np.ascontiguousarray(fixture_cloud[:20000], dtype=np.float32)
+    b = np.ascontiguousarray(fixture_cloud[5000:30000], dtype=np.float32)
+    rng = engine.Rng(bench.SEED_DATA)
+    sdfs = [bench.complete_shape(engine, model, p, rng, 24, 0)[0].numpy() for p in (a, b)]
+    refs = [s.copy() for s in sdfs]
+    j = int(np.argmax(np.abs(refs[1])))                      # a query whose sign logit is certainly not a tie
+    refs[1][j] = -refs[1][j]
+    shapes = [('shape_a', a, refs[0]), ('shape_b', b, refs[1])]
+    rec, ok = bench.golden_check(engine, parity, model, w, cfg, shapes, 24, sdfs, 1e-4, 0)
+    assert not ok and rec['sign_flips'] == 1 and rec['sign_flips_not_ties'] == 1
+    f = rec['flipped'][0]
+    assert f['shape'] == 'shape_b' and f['query'] == j and not f['fp32_tie']
+    assert abs(f['sign_logit_device'] - f['sign_logit_cpu_port']) < 1e-3 and abs(f['sign_logit_device']) > 1e-3
+    assert abs(rec['max_abs_diff_unmasked'] - 2 * abs(sdfs[1][j])) < 1e-6 and rec['max_abs_dsdf'] < 1e-6
+    # the logit the analysis computed belongs to THAT query: its sign is the sign of the device's SDF there
+    assert (f['sign_logit_device'] >= 0) == (sdfs[1][j] > 0)
