@@ -35,7 +35,8 @@ struct p2s_model_s {
     int *range_flag = nullptr;             // device: raised by the fp16 pair mode when an activation leaves the half range
     float *ws = nullptr;      // per-chunk workspace, grown on demand
     int ws_chunk = 0;
-    int max_chunk = 4096;     // queries per internal batch
+    int max_chunk = 8192;     // queries per internal batch (r03: 4096 -> 8192: 180.4 -> 182.0 k queries/s, the launch boundaries
+                              // of a chunk -- four drains of the chip -- weigh half as much; 12288: 182.1 k)
     // profiling: HIP events recorded on the launch stream, no host synchronisation until collect
     bool profiling = false;
     std::vector<hipEvent_t> evpool;
