@@ -1794,7 +1794,7 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     // queries per batch (table memory: ~1.4 MB per query at 50k points); random words come from the raw session
     long long per_req = 4096;
     const long long req_env = getenv("P2S_WCHOICE_QUERIES") ? atoll(getenv("P2S_WCHOICE_QUERIES")) : 0;   // tests
-    if (req_env > 0) per_req = std::min(per_req, req_env);
+    if (req_env > 0) per_req = std::min<long long>(req_env, 16384);
     per_req = std::min<long long>(per_req, nq);
     const long long cap = p2s_rng_session_words(r);
     // numpy draws 2 words per double, n_sel doubles + a few % redraws per query; the serial kernel stages words
