@@ -143,3 +143,29 @@ def test_fp16_pair_mode_reports_activations_beyond_the_half_range(fixture_cloud,
         sdf, _ = engine.infer_shape(m2, cloud, engine.Rng(40938661), 16, 3)
         torch.cuda.synchronize()
         assert torch.isfinite(sdf).all()
+
+
+@pytest.mark.parametrize('name', ['p2s_max', 'p2s_vanilla'])
+def test_fp16_pair_full_512_grid(name, golden_dir, torch_cuda):
+    """BASELINE configs[3] / [4] together: the fp16-pair encoder over every one of the 757,499 queries of the 512^3 grid
+    against the unmodified reference -- magnitudes within the 1e-4 contract, signs identical except fp32 TIES of the sign
+    decision (|sign logit| < 5e-5 on the device; p2s_max has two such queries in fp32 as well)"""
+    import torch
+    from points2surf_amd import engine, synth, parity
+    path = os.path.join(golden_dir, 'ref_rec_%s_testset_grid512.npz' % name)
+    if not os.path.isfile(path):
+        pytest.skip('512^3 golden not generated')
+    ref = np.load(path)['rec_0']
+    w, cfg = synth.make_weights(name)
+    m = engine.Model(w, dict(cfg, encoder_bf16=4))
+    fix = os.path.join(golden_dir, 'abc_minimal', '04_pts', '00994122_57d9d4755722f9d2d7436f0a_trimesh_000.xyz.npy')
+    cloud = engine.Cloud(np.load(fix))
+    sdf, q = engine.infer_shape(m, cloud, engine.Rng(40938661), 512, 3)
+    torch.cuda.synchronize()
+    c = parity.compare_sdf(sdf.cpu().numpy(), ref)
+    print('%s fp16 pair, grid 512: max |dSDF| %.3g (magnitudes at flipped signs), sign flips %d / %d'
+          % (name, c['max_abs_dsdf'], c['flipped'].size, ref.size))
+    assert c['max_abs_dsdf'] < 1e-4 and c['flipped'].size <= 8
+    for j in c['flipped']:
+        lg = engine.query_logits(m, cloud, engine.Rng(40938661), q, int(j)).cpu().numpy()
+        assert parity.not_ties([lg[1]]) == 0, (int(j), lg)
