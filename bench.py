@@ -197,7 +197,7 @@ def golden_check(engine, parity, model, w, cfg, shapes, res, sdfs, tol, bf16):
         rec['max_abs_diff_unmasked'] = max(rec['max_abs_diff_unmasked'], unmasked)
         rec['sign_flips'] += int(fl.size)
         not_ties = int(fl.size)
-        if 0 < fl.size <= 8 and not bf16:
+        if 0 < fl.size <= 32 and not bf16:       # ~1 query in 400,000 has a sign logit within fp32 noise of zero
             not_ties = 0
             # position a stream at this shape's first draw: skip the shapes before it
             for j in fl:
