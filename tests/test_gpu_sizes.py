@@ -95,9 +95,31 @@ def test_full_grid128_sign_decision_with_power():
 @pytest.mark.parametrize('res', [256])
 def test_three_clouds_one_stream_256_matches_reference(res):
     """the benchmarked dataset -- all three abc_minimal clouds as ONE dataset at 256^3, 1,378,242
-    queries from one continuous stream -- against the golden the unmodified reference wrote (~6 h of CPU)"""
+    queries from one continuous stream -- against the golden the unmodified reference wrote (~6 h of CPU).  All
+    magnitudes within 1e-4; signs identical except fp32 TIES of the sign decision (about one query in 400,000 has a sign
+    logit within the logit accuracy of zero, see test_full_grid512_matches_reference): each flipped query is re-run at
+    its exact stream position and must have |sign logit| < 5e-5."""
+    import torch
+    from points2surf_amd import engine, synth, sharding
     g, meta = _golden('rec', 'p2s_max', 'abc3', res)
-    _compare(_run_dataset('p2s_max', 'abc3', res), g, meta)
+    out = _run_dataset('p2s_max', 'abc3', res)
+    flipped = _compare(out, g, meta, ties_ok=True)
+    assert len(flipped) <= 16, flipped
+    if flipped:
+        w, cfg = synth.make_weights('p2s_max')
+        model = engine.Model(w, cfg)
+        names = _names('abc3')
+        for si, j in flipped:
+            rng = engine.Rng(SEED)
+            for n in names[:si]:                               # the draws of the shapes before this one
+                c = engine.Cloud(np.load(os.path.join(FIX, '04_pts', n + '.xyz.npy')))
+                sharding.skip_shape_stream(c, rng, cfg, res, 3, model.sub_sample_size)
+                c.close()
+            cloud = engine.Cloud(np.load(os.path.join(FIX, '04_pts', names[si] + '.xyz.npy')))
+            lg = engine.query_logits(model, cloud, rng, torch.from_numpy(out[si][1]).cuda(), j).cpu().numpy()
+            print('shape %d query %d: logits %s, device sdf %.6g, reference %.6g' % (si, j, lg, out[si][0][j], g['rec_%d' % si][j]))
+            assert parity.not_ties([lg[1]]) == 0, (si, j, lg)
+            cloud.close()
 
 
 @pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
