@@ -120,3 +120,37 @@ def make_cloud(n_points=50000, seed=0, noise=0.004, kind='blob'):
     lo, hi = p.min(0), p.max(0)
     p = (p - (lo + hi) / 2) / (hi - lo).max()
     return np.ascontiguousarray(p.astype(np.float32))
+
+
+def standin_cloud(base, seed):
+    """One cloud of the stand-in data sets of SURVEY 8d configs 3-5 (the Famous / ABC / Thingi10k test sets cannot be
+    downloaded offline): a base cloud under a seeded random rotation, re-normalised to the unit cube the way
+    make_pc_dataset._to_unit_cube does (reference make_pc_dataset.py:20-36: translate the bounding-box centre to the
+    origin, scale the largest extent to 1).  float64 arithmetic, one rounding to float32; numpy only."""
+    rs = np.random.RandomState(int(seed))
+    a = rs.standard_normal((3, 3))
+    q, r = np.linalg.qr(a)
+    q = q * np.sign(np.diag(r))                      # a proper distribution over O(3) ...
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]                           # ... restricted to rotations
+    p = np.asarray(base, dtype=np.float64)[:, :3] @ q.T
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    ext = (hi - lo).max()
+    if ext == 0.0:
+        return np.ascontiguousarray(p.astype(np.float32))
+    return np.ascontiguousarray(((p - (lo + hi) * 0.5) / ext).astype(np.float32))
+
+
+def make_standin_dataset(root, base_clouds, n_shapes, list_name='testset.txt'):
+    """write ``n_shapes`` stand-in clouds (base cloud i mod len(base), rotation seed i) as <root>/04_pts/*.xyz.npy plus the
+    shape list; returns the shape names"""
+    import os
+    os.makedirs(os.path.join(root, '04_pts'), exist_ok=True)
+    names = []
+    for i in range(int(n_shapes)):
+        name = 'standin_%03d' % i
+        np.save(os.path.join(root, '04_pts', name + '.xyz.npy'), standin_cloud(base_clouds[i % len(base_clouds)], i))
+        names.append(name)
+    with open(os.path.join(root, list_name), 'w') as f:
+        f.write('\n'.join(names) + '\n')
+    return names

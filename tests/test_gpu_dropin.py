@@ -266,3 +266,40 @@ def test_dropin_under_the_real_launcher_two_ranks(shard, dropin_source, tmp_path
         assert a.shape == b.shape and a.size > 500 and np.array_equal(a, b), n
         assert np.array_equal(np.load(os.path.join(single, 'rec', 'query_pts_ms', n + '.xyz.npy')),
                               np.load(os.path.join(sharded, 'rec', 'query_pts_ms', n + '.xyz.npy')))
+
+
+def test_standin_dataset_of_22_clouds_sharded_like_single_process(dropin_source, tmp_path, monkeypatch):
+    """SURVEY 8d config 3's stand-in for the Famous test set: 22 clouds = the three abc_minimal clouds under seeded random
+    rotations, re-normalised to the unit cube (points2surf_amd/synth.py:make_standin_dataset).  The drop-in over the whole
+    set, single process vs four 'ranks' (LPT shape assignment, every rank consuming the draws of the shapes it does not
+    own): identical files for all 22 shapes; every SDF finite; queries per shape differ (different voxelisations)."""
+    from points2surf_amd import synth
+    ev, _ = dropin_source
+    golden = os.path.join(REPO, 'tests', 'golden', 'abc_minimal', '04_pts')
+    bases = [np.load(os.path.join(golden, f)) for f in sorted(os.listdir(golden)) if f.endswith('.xyz.npy')]
+    assert len(bases) == 3
+    root = str(tmp_path / 'ds')
+    names = synth.make_standin_dataset(root, bases, 22)
+    modeldir = str(tmp_path / 'models')
+    _write_model_files(modeldir, 'p2s_max')
+
+    def run(outdir, world, rank):
+        monkeypatch.setenv('WORLD_SIZE', str(world))
+        monkeypatch.setenv('RANK', str(rank))
+        monkeypatch.setenv('LOCAL_RANK', '0')
+        opt = ev.parse_arguments(['--indir', root, '--outdir', outdir, '--dataset', 'testset.txt', '--modeldir', modeldir,
+                                  '--models', 'p2s_max', '--query_grid_resolution', '48', '--epsilon', '3'])
+        opt.reconstruction = True
+        ev.points_to_surf_eval(opt)
+
+    single, sharded = str(tmp_path / 'single'), str(tmp_path / 'sharded')
+    run(single, 1, 0)
+    for r in range(4):
+        run(sharded, 4, r)
+    counts = set()
+    for n in names:
+        a = np.load(os.path.join(single, 'rec', 'dist_ms', n + '.xyz.npy'))
+        b = np.load(os.path.join(sharded, 'rec', 'dist_ms', n + '.xyz.npy'))
+        assert a.shape == b.shape and a.size > 3000 and np.isfinite(a).all() and np.array_equal(a, b), n
+        counts.add(a.size)
+    assert len(counts) > 10
