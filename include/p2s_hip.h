@@ -76,7 +76,12 @@ typedef struct {
     int32_t single_transformer;  /* train --single_transformer 1 (p2s_shared_encoder): ONE encoder over cat(patch,
                                     sub-sample); enc[0] = enc[1] = feat_local_global.*, the QSTN is its stn1 and sees
                                     all points, d1l / d1g = the two halves of fc1_local_global (1024 -> 1024)  */
-    int32_t reserved[6];
+    double  patch_radius;        /* train --patch_radius: 0 = the points_per_patch nearest neighbours, radius = their largest
+                                    distance; > 0 (p2s_{small,medium,large}_radius: 0.05 / 0.1 / 0.2) = all points within
+                                    this distance, a random points_per_patch of them if there are more, padded with the
+                                    query point if fewer (reference source/base/point_cloud.py:177-191).  The float64
+                                    value of the reference's Python float: the ball test is r * r in float64          */
+    int32_t reserved[4];
 } p2s_model_cfg;
 
 /* Offsets (in floats) into the weight blob.  The blob holds BatchNorm-folded fp32 weights,
@@ -231,6 +236,24 @@ int p2s_subsample_shuffle_pad(p2s_rng_t r, p2s_cloud_t c, int64_t n_queries, int
 /* a5 from explicit kNN ids (rows looked up through perm_before_dev, NULL = identity): radius + patch space */
 int p2s_patch_from_ids(p2s_cloud_t c, const int32_t *ids_dev, const int32_t *perm_before_dev, const float *query_dev,
                        int64_t n_queries, int k, float *patch_ps_out_dev, float *radius_out_dev, void *stream);
+/* a4, fixed-radius branch: get_patch_kdtree with patch_radius > 0 (reference source/base/point_cloud.py:177-191,
+ * source/data_loader.py:335-350) -- see points2surf_amd/csrc/p2s_ball.hip.
+ * p2s_kd_order_host: HOST function (no device needed): the index array of scipy.spatial.cKDTree(pts, leafsize) --
+ * query_ball_point returns its hits in this order.  order_out [n]; leaf_start_out [n_leaves + 1] (may be NULL).
+ * p2s_ball_count: number of points within `radius` of every query (= len(query_ball_point)).
+ * p2s_ball_patch: for queries in order, the patch ids (ids_out_dev [Q][k], may be NULL; padding = 0), the patch in patch
+ * space (patch_out_dev [Q][k][3]; NULL = only advance the generator) and radius_out_dev [Q] (may be NULL) = 1: the scale
+ * of the distance output, which fixed-radius models do not rescale (source/points_to_surf_eval.py:180,188).  r = the
+ * data set's FIRST RandomState (self.rng): a query with more than k points in its ball consumes the words of
+ * permutation(count).  with_rotation: every query then also draws the rand(3) of the GT-query pass
+ * (data_loader.py:384) and rot_out_dev [Q][9] receives its rotation matrix.  Synchronises `stream` once (hit counts). */
+int p2s_kd_order_host(const float *pts_host, int64_t n, int leafsize, int32_t *order_out, int32_t *leaf_start_out,
+                      int64_t leaf_cap, int32_t *n_leaves_out);
+int p2s_ball_count(p2s_cloud_t c, const float *query_dev, int64_t n_queries, double radius, int32_t *count_out_dev,
+                   void *stream);
+int p2s_ball_patch(p2s_rng_t r, p2s_cloud_t c, const float *query_dev, int64_t n_queries, double radius,
+                   int points_per_patch, int with_rotation, int32_t *ids_out_dev, float *patch_out_dev,
+                   float *radius_out_dev, double *rot_out_dev, void *stream);
 /* given-ids mode (ids produced elsewhere; id < 0 = zero point) */
 int p2s_gather_points(p2s_cloud_t c, const int32_t *ids_dev, int64_t n_ids, float *pts_out_dev,
                       void *stream);
@@ -245,6 +268,12 @@ int p2s_gather_points(p2s_cloud_t c, const int32_t *ids_dev, int64_t n_ids, floa
 int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int grid_resolution, int epsilon,
                     int64_t q_begin, int64_t q_end, int chunk, float *sdf_out_dev, float *q_out_dev,
                     int64_t *n_done, void *stream);
+/* the same for a fixed-radius model (cfg.patch_radius > 0): r_patch = the data set's FIRST RandomState (self.rng), which
+ * the patch choice draws from (reference source/data_loader.py:335-338); p2s_infer_shape refuses such a model.  With
+ * cfg.patch_radius == 0, r_patch is ignored (may be NULL). */
+int p2s_infer_shape_ball(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, p2s_rng_t r_patch, int grid_resolution, int epsilon,
+                         int64_t q_begin, int64_t q_end, int chunk, float *sdf_out_dev, float *q_out_dev,
+                         int64_t *n_done, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * GT-query evaluation pass: the batch loop of points_to_surf_eval with reconstruction=False, the pass
@@ -254,7 +283,8 @@ int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int grid_resoluti
  * from the dataset's FIRST RandomState (self.rng, :272; the sub-sample uses the second one, :277), applied in
  * float64 to the sub-sample (model space), the patch (patch space) and the query point, each cast back to float32
  * (:385-393).  r_rot = NULL: no rotation (plain inference at given query points).  sdf_out_dev [n_queries].
- * Synchronises `stream`.
+ * Fixed-radius models (cfg.patch_radius > 0) need r_rot: the same generator makes every query's patch choice, right
+ * before its rotation.  Synchronises `stream`.
  * ------------------------------------------------------------------------------------------ */
 int p2s_infer_queries(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r_sub, p2s_rng_t r_rot, const float *q_dev,
                       int64_t n_queries, int chunk, float *sdf_out_dev, void *stream);

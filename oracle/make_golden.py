@@ -45,7 +45,8 @@ def train_namespace(cfg, batch=500):
         ['imp_surf_magnitude', 'imp_surf_sign', 'patch_pts_ids', 'p_index']
     return argparse.Namespace(
         outputs=outputs,
-        points_per_patch=int(cfg.get('points_per_patch', 300)), patch_center='mean', sub_sample_size=1000, patch_radius=0.0,
+        points_per_patch=int(cfg.get('points_per_patch', 300)), patch_center='mean', sub_sample_size=1000,
+        patch_radius=float(cfg.get('patch_radius', 0.0)),
         uniform_subsample=int(cfg['uniform_subsample']), fixed_subsample=0, net_size=1024,
         use_point_stn=int(cfg['use_point_stn']), use_feat_stn=1, sym_op='max',
         single_transformer=int(cfg.get('single_transformer', False)), shared_transformer=int(cfg['shared_transformer']),

@@ -148,6 +148,23 @@ class LegacyMT19937:
                 x[[i, v]] = x[[v, i]]
         return x
 
+    # -- legacy RandomState.permutation(n) ------------------------------------------------
+    def permutation(self, n):
+        """``RandomState.permutation(n)`` = shuffle(arange(n)) (numpy mtrand: 1-D branch of ``shuffle``, the same
+        i = n-1 .. 1, j = rk_interval(i) swaps as above) -- what ``rng.choice(np.arange(n), k, replace=False)`` takes its
+        first k entries of.  Call site: source/base/point_cloud.py:183 (fixed-radius patches)."""
+        a = np.arange(n, dtype=np.int64)
+        for i in reversed(range(1, n)):
+            mask = i
+            for sft in (1, 2, 4, 8, 16):
+                mask |= mask >> sft
+            while True:
+                v = int(self.raw(1)[0]) & mask
+                if v <= i:
+                    break
+            a[i], a[v] = a[v], a[i]
+        return a
+
     # -- legacy RandomState.rand / random_sample ---------------------------------------
     def rand(self, size):
         w = self.raw(2 * size).astype(np.uint64)
@@ -271,6 +288,27 @@ def patch_radius_and_ps(pts, ids, query):
 # --------------------------------------------------------------------------------------
 # a6: global sub-sample
 # --------------------------------------------------------------------------------------
+
+def ball_patch(rng_patch, pts, tree, query, radius, points_per_patch):
+    """The fixed-radius patch of ONE query: get_patch_kdtree with patch_radius > 0 (reference
+    source/base/point_cloud.py:177-191) + the padding / patch-space steps of source/data_loader.py:340-350.
+    ``tree`` = scipy.spatial.cKDTree(pts, 1000) (source/data_loader.py:40-42): scipy is the reference's own dependency
+    and present in this image, so the ball -- and the ORDER of its points, which decides what a random choice of
+    positions selects -- comes from the call the reference makes.  ``rng_patch`` = dataset.rng (LegacyMT19937).
+    Returns (ids [k] int32 with 0 for padding, patch_ps [k,3] float32, number of points in the ball)."""
+    ids = np.array(tree.query_ball_point(x=query, r=radius), dtype=np.int32)
+    count = ids.shape[0]
+    if count > points_per_patch:
+        ids = ids[rng_patch.permutation(count)[:points_per_patch]]      # rng.choice(np.arange(count), k, replace=False)
+    pad = np.zeros(points_per_patch, dtype=bool)
+    if count < points_per_patch:
+        pad[count:] = True
+        ids = np.concatenate((ids, np.zeros(points_per_patch - count, np.int32)))
+    patch_ms = pts[ids, :]
+    patch_ms[pad, :] = query
+    patch_ps = (patch_ms - np.repeat(np.expand_dims(query, 0), points_per_patch, axis=0)) / np.float32(radius)
+    return ids, patch_ps.astype(np.float32), count
+
 
 def dist_prob(pts, query):
     """source/base/utils.py:200-208 (float32 throughout; np.sum pairwise)."""
@@ -479,7 +517,7 @@ def post_process(logits, patch_radius):
 # --------------------------------------------------------------------------------------
 
 def infer_shape(w, cfg, pts, grid_resolution, epsilon, rng, points_per_patch=300,
-                sub_sample_size=1000, query_range=None, chunk=32, return_all=False):
+                sub_sample_size=1000, query_range=None, chunk=32, return_all=False, rng_patch=None):
     """What source/points_to_surf_eval.py:358-404 computes for one shape in
     reconstruction mode with --workers 0.  ``rng`` = LegacyMT19937 carried across shapes.
     ``query_range`` = (q0, q1) restricts to a prefix/sub-range of the query list (the RNG
@@ -488,9 +526,30 @@ def infer_shape(w, cfg, pts, grid_resolution, epsilon, rng, points_per_patch=300
     q_all, _ = query_grid(pts, grid_resolution, epsilon)
     q0, q1 = (0, q_all.shape[0]) if query_range is None else query_range
     q = q_all[q0:q1]
-    ids = knn_ids(pts, q, points_per_patch)
     uniform = bool(cfg.get('uniform_subsample', False))
     fixed = bool(cfg.get('fixed_subsample', False))
+    radius = float(cfg.get('patch_radius', 0.0) or 0.0)
+    if radius > 0.0:
+        # fixed-radius models: the patch choice draws from dataset.rng (``rng_patch``), the sub-sample from
+        # dataset.rng_global_sample (``rng``) -- source/data_loader.py:272-277,336,376
+        from scipy import spatial
+        tree = spatial.cKDTree(pts, 1000)
+        ids = np.zeros((q.shape[0], points_per_patch), np.int32)
+        patch_ps = np.zeros((q.shape[0], points_per_patch, 3), np.float32)
+        counts = np.zeros(q.shape[0], np.int64)
+        sub_ids = np.zeros((q.shape[0], sub_sample_size), np.int64)
+        for i in range(q.shape[0]):
+            ids[i], patch_ps[i], counts[i] = ball_patch(rng_patch, pts, tree, q[i], radius, points_per_patch)
+            sub_ids[i] = subsample_ids(rng, pts, q[i], sub_sample_size, uniform, fixed)
+        # fixed radius: the prediction is not rescaled (source/points_to_surf_eval.py:180,188 `if not fixed_radius`)
+        r = np.ones(q.shape[0], np.float32)
+        logits = model_forward(w, cfg, patch_ps, pts[sub_ids], q, chunk=chunk)
+        sdf = post_process(logits, r)
+        if return_all:
+            return dict(q=q, knn_ids=ids, radius=r, patch_ps=patch_ps, sub_ids=sub_ids, logits=logits, sdf=sdf,
+                        q_total=q_all.shape[0], ball_counts=counts)
+        return q, sdf
+    ids = knn_ids(pts, q, points_per_patch)
     if pts.shape[0] < sub_sample_size:
         # data_loader.py:322-421 query by query: the kd-tree holds a float64 COPY of the original order (cKDTree of a
         # float32 array), the patch is gathered from shape.pts -- which every previous query's sub-sample shuffled

@@ -59,6 +59,12 @@ PROTOTYPES = {
     'p2s_gather_points': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'p2s_infer_shape': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_void_p,
                                 c_void_p, ctypes.POINTER(c_int64), c_void_p]),
+    'p2s_infer_shape_ball': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_void_p,
+                                     c_void_p, ctypes.POINTER(c_int64), c_void_p]),
+    'p2s_kd_order_host': (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, ctypes.POINTER(ctypes.c_int32)]),
+    'p2s_ball_count': (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_double, c_void_p, c_void_p]),
+    'p2s_ball_patch': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, ctypes.c_double, c_int, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p]),
     'p2s_infer_queries': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     'p2s_random_rotations': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     'p2s_rotate_points': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),

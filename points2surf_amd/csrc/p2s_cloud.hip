@@ -1105,6 +1105,7 @@ int p2s_cloud_destroy(p2s_cloud_t c) {
     p2s_pool_free(c->device, c->qcache);
     p2s_pool_free(c->device, c->shuffle_perm);
     p2s_pool_free(c->device, c->wc_plan);
+    p2s_pool_free(c->device, c->kd_blob);
     delete c;
     return P2S_OK;
 }
@@ -1411,6 +1412,7 @@ int p2s_rng_destroy(p2s_rng_t r) {
     if (r->blk_cum) (void)hipFree(r->blk_cum);
     if (r->meta) (void)hipFree(r->meta);
     p2s_wc_free_rng(r);
+    p2s_ball_free_rng(r);
     delete r;
     return P2S_OK;
 }

@@ -112,6 +112,12 @@ struct p2s_cloud_s {
     // summation plan of np.sum(float32[n]) for the weighted sub-sample (p2s_wchoice.hip), built on first use
     int *wc_plan = nullptr;        // device: leaves [L][3], ops [O][3], level offsets [levels+1]
     int wc_leaves = 0, wc_ops_at = 0, wc_lvl_at = 0, wc_levels = 0, wc_root = 0, wc_nodes = 0;
+    // fixed-radius patches (p2s_ball.hip), built on first use: the cloud in scipy's cKDTree(pts, 1000).indices order
+    char *kd_blob = nullptr;
+    float4 *kd_pts = nullptr;      // [n] xyz + original id
+    int *kd_leaf = nullptr;        // [kd_leaves + 1] leaf ranges
+    float *kd_box = nullptr;       // [kd_leaves][6] lo, hi of each leaf's points
+    int kd_leaves = 0;
 };
 
 struct p2s_rng_s {
@@ -140,6 +146,11 @@ struct p2s_rng_s {
     double *wc_stot = nullptr;     // [C]
     unsigned short *wc_J = nullptr; // [11][SP_B][SP_W] jump tables of the offsets chain (p2s_wchoice.hip)
     size_t wc_cap_q = 0, wc_cap_n = 0, wc_cap_k = 0;
+    // fixed-radius patches (p2s_ball.hip): hit counts of a shape's queries (device + pinned host), batch work space
+    int32_t *ball_counts_dev = nullptr, *ball_counts_host = nullptr;
+    size_t ball_counts_cap = 0;
+    void *ball_ws = nullptr;
+    size_t ball_ws_bytes = 0;
 };
 
 // per-device cache of device-memory blocks for the cloud handles (p2s_cloud.hip)
@@ -163,6 +174,17 @@ int p2s_rng_session_close(p2s_rng_s *r, hipStream_t s);        // advance the ge
 int p2s_rng_session_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s);
 int p2s_rng_session_raw(p2s_rng_s *r, long long need_words, hipStream_t s);
 void p2s_wc_free_rng(p2s_rng_s *r);               // p2s_wchoice.hip workspace
+// fixed-radius patches (p2s_ball.hip)
+void p2s_ball_free_rng(p2s_rng_s *r);
+int p2s_cloud_kd_prepare(p2s_cloud_s *c);
+int p2s_ball_counts_to_host(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_t nq, double radius, int32_t **count_dev,
+                            const int32_t **count_host, hipStream_t s);
+// patch_out_dev == NULL: advance the generator only
+int p2s_ball_patch_counted(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, const int32_t *count_dev, const int32_t *count_host,
+                           int64_t nq, double radius, int k, int tail_words, int32_t *ids_out_dev, float *patch_out_dev,
+                           float *radius_out_dev, double *rot_out_dev, hipStream_t s);
+// rand(3) -> rotation matrix for n queries whose 6 words lie contiguously at six_dev[6 * i] (p2s_pipeline.hip)
+int p2s_rotations_from_words(const uint32_t *six_dev, long long n, double *rot_out_dev, hipStream_t s);
 void p2s_mt_seed_host(uint32_t seed, uint32_t st[625]);                 // init_genrand
 int p2s_rng_reseed(p2s_rng_s *r, uint32_t seed, hipStream_t s);         // rng.seed(seed): closes any session
 int p2s_wc_subsample_fixed(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_t nq, int n_sel, uint32_t seed,

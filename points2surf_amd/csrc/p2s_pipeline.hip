@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void p2s_rand_rot_kernel(const uint32_t *__res
                                                            long long *__restrict__ err) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const long long c0 = meta[0];
-    if (c0 + 6 * n > cap_words) {
+    const long long c0 = meta ? meta[0] : 0;   // meta == NULL: the words of query i lie at words[6 i]
+    if (meta && c0 + 6 * n > cap_words) {
         if (i == 0) err[0] = 2;          // random words exhausted (host-side accounting makes this unreachable)
         return;
     }
@@ -145,6 +145,14 @@ __global__ __launch_bounds__(256) void p2s_rotate_points_kernel(const double *__
 
 }  // namespace
 
+int p2s_rotations_from_words(const uint32_t *six_dev, long long n, double *rot_out_dev, hipStream_t s) {
+    if (n <= 0) return P2S_OK;
+    hipLaunchKernelGGL(p2s_rand_rot_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, six_dev, (const long long *)nullptr,
+                       6 * n, n, rot_out_dev, (long long *)nullptr);
+    P2S_LAUNCH_CHECK("p2s_rand_rot_kernel");
+    return P2S_OK;
+}
+
 extern "C" int p2s_random_rotations(p2s_rng_t r, int64_t n, double *rot_out_dev, void *stream) {
     if (!r || n < 0 || (n > 0 && !rot_out_dev)) {
         p2s_set_error("p2s_random_rotations: bad argument");
@@ -194,9 +202,12 @@ extern "C" int p2s_debug_fault_chunk(p2s_model_t m, int chunk_index) {
 }
 
 // queries q_all[q_begin, q_end) through the double-buffered pipeline.  r_rot != NULL: GT-query pass (rotation).
-static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s *r_rot, const float *q_all, int64_t q_begin,
-                        int64_t q_end, int chunk, float *sdf_out_dev, hipStream_t s) {
+// r_patch: fixed-radius models only (the generator of the patch choice; in the GT-query pass the same handle as r_rot).
+static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s *r_rot, p2s_rng_s *r_patch, const float *q_all,
+                        int64_t q_begin, int64_t q_end, int chunk, float *sdf_out_dev, hipStream_t s) {
     const bool weighted = m->cfg.weighted_subsample != 0;   // p2s_vanilla: choice(p, replace=False) per query
+    const double ball_r = m->cfg.patch_radius;
+    const bool ball = ball_r > 0.0;                         // patch = points within a fixed radius (p2s_ball.hip)
     const int k = m->cfg.points_per_patch, n = m->cfg.sub_sample_size;
     // default chunk: 8192 queries for the uniform sub-sample; 4096 for the distance-weighted one, whose generator works in
     // batches of 4096 queries (two batches per chunk of 8192 measured 6 % SLOWER: 102.7 vs 109.8 k queries/s)
@@ -234,6 +245,11 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
     // clouds with fewer points than the sub-sample: shuffle + pad, and shape.pts permuted under the kd-tree
     // (reference source/base/utils.py:221-226; p2s_subsample_shuffle_pad)
     const bool small = c->d.n < n;
+    if (ball && (small || !r_patch || (r_rot && r_rot != r_patch))) {
+        p2s_set_error("p2s pipeline: a fixed-radius model needs the generator of the patch choice (the rotation generator of the "
+                      "GT-query pass) and a cloud with at least sub_sample_size points");
+        return P2S_EINVAL;
+    }
     int rc = pipe_reserve(m, C, k, n, small);
     if (rc) return rc;
     rc = p2s_model_reserve(m, C);
@@ -267,6 +283,17 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         if (sp != s) PIPE_HIP(hipStreamWaitEvent(sp, b.grid, 0));
     }
 
+    // fixed radius: the number of points in every query's ball, on the host too (batch sizes and the random words each
+    // batch may need follow from it) -- the one blocking call of this mode, before the pipeline starts
+    int32_t *ball_cd = nullptr;
+    const int32_t *ball_ch = nullptr;
+    if (ball) {
+        const int eb0 = p2s_prof_mark(m, s);
+        if ((rc = p2s_ball_counts_to_host(r_patch, c, q_all + (size_t)q_begin * 3, nq, ball_r, &ball_cd, &ball_ch, s))) return fail(rc);
+        p2s_prof_span(m, ST_KNN, eb0, p2s_prof_mark(m, s));
+    }
+    const bool use_done = sp != s || (ball && sa != s);
+
     const int64_t nchunks = (nq + C - 1) / C;
     auto produce = [&](int64_t ci) -> int {       // sub-sample ids of chunk ci on the aux stream
         const int bi = (int)(ci % nbuf);
@@ -284,6 +311,16 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
                            : p2s_subsample_uniform(r, c, cur, n, b.sub_ids[bi], nullptr, sa);
         if (rc2) return fail(rc2);
         p2s_prof_span(m, ST_SUB, e0, p2s_prof_mark(m, sa));
+        if (ball) {
+            // patch choice (+ the rotation of the GT-query pass): a serial walk along the first generator's stream, under
+            // the encoders of the chunks before; the encoders of chunk ci - nbuf read the patch buffer it fills
+            if (ci >= nbuf && sa != s) PIPE_HIP(hipStreamWaitEvent(sa, b.done[bi], 0));
+            const int eb0 = p2s_prof_mark(m, sa);
+            rc2 = p2s_ball_patch_counted(r_patch, c, q_all + (size_t)q0 * 3, ball_cd + (q0 - q_begin), ball_ch + (q0 - q_begin), cur,
+                                         ball_r, k, r_rot ? 6 : 0, nullptr, b.patch[bi], b.radius[bi], r_rot ? b.rot[bi] : nullptr, sa);
+            if (rc2) return fail(rc2);
+            p2s_prof_span(m, ST_KNN, eb0, p2s_prof_mark(m, sa));
+        }
         if (sa != s) PIPE_HIP(hipEventRecord(b.ready[bi], sa));
         return P2S_OK;
     };
@@ -297,10 +334,13 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         // the encoders of chunk ci - nbuf read this buffer
         if (sp != s && ci >= nbuf) PIPE_HIP(hipStreamWaitEvent(sp, b.done[bi], 0));
         const int ek0 = p2s_prof_mark(m, sp);
-        int rc2 = small ? p2s_knn_patch(c, qc, cur, k, b.knn_ids[bi], nullptr, nullptr, sp)
+        int rc2 = P2S_OK;
+        if (!ball) {
+            rc2 = small ? p2s_knn_patch(c, qc, cur, k, b.knn_ids[bi], nullptr, nullptr, sp)
                         : p2s_knn_patch_set(c, qc, cur, k, b.patch[bi], b.radius[bi], sp);
-        if (rc2) return fail(rc2);
-        p2s_prof_span(m, ST_KNN, ek0, p2s_prof_mark(m, sp));
+            if (rc2) return fail(rc2);
+            p2s_prof_span(m, ST_KNN, ek0, p2s_prof_mark(m, sp));
+        }
         if (sa != sp) PIPE_HIP(hipStreamWaitEvent(sp, b.ready[bi], 0));
         if (small) {       // the patch is gathered from the array as the queries before this one left it
             rc2 = p2s_patch_from_ids(c, b.knn_ids[bi], b.perm[bi], qc, cur, k, b.patch[bi], b.radius[bi], sp);
@@ -334,7 +374,7 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         else if ((rc = prepare(ci))) return rc;
         if (r_rot) {
             // data_loader.py:381-393: rotate sub-sample (model space), patch (patch space) and the query point
-            if ((rc = p2s_random_rotations(r_rot, cur, b.rot[bi], s))) return fail(rc);
+            if (!ball && (rc = p2s_random_rotations(r_rot, cur, b.rot[bi], s))) return fail(rc);
             if ((rc = p2s_rotate_points(b.rot[bi], b.sub[bi], n, cur, b.sub[bi], s))) return fail(rc);
             if ((rc = p2s_rotate_points(b.rot[bi], b.patch[bi], k, cur, b.patch[bi], s))) return fail(rc);
             if ((rc = p2s_rotate_points(b.rot[bi], qc, 1, cur, b.qrot[bi], s))) return fail(rc);
@@ -343,7 +383,7 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         rc = p2s_run_chunk(m, b.patch[bi], b.sub[bi], qc, b.radius[bi], cur, nullptr, sdf_out_dev + (q0 - q_begin),
                            nullptr, nullptr, s);
         if (rc) return fail(rc);
-        if (sp != s) PIPE_HIP(hipEventRecord(b.done[bi], s));
+        if (use_done) PIPE_HIP(hipEventRecord(b.done[bi], s));
         if (ci + nbuf < nchunks) {
             if ((rc = produce(ci + nbuf))) return rc;
             if (sp != s && (rc = prepare(ci + nbuf))) return rc;
@@ -357,10 +397,22 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
 extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int res, int eps, int64_t q_begin,
                                int64_t q_end, int chunk, float *sdf_out_dev, float *q_out_dev, int64_t *n_done,
                                void *stream) {
-    if (!m || !c || !r || !sdf_out_dev) {
-        p2s_set_error("p2s_infer_shape: null argument");
+    if (m && m->cfg.patch_radius > 0.0) {
+        p2s_set_error("p2s_infer_shape: fixed-radius model (patch_radius %g): use p2s_infer_shape_ball with the generator of "
+                      "the patch choice", m->cfg.patch_radius);
         return P2S_EINVAL;
     }
+    return p2s_infer_shape_ball(m, c, r, nullptr, res, eps, q_begin, q_end, chunk, sdf_out_dev, q_out_dev, n_done, stream);
+}
+
+extern "C" int p2s_infer_shape_ball(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, p2s_rng_t r_patch, int res, int eps,
+                                    int64_t q_begin, int64_t q_end, int chunk, float *sdf_out_dev, float *q_out_dev,
+                                    int64_t *n_done, void *stream) {
+    if (!m || !c || !r || !sdf_out_dev || r_patch == r) {
+        p2s_set_error("p2s_infer_shape: null argument (or one generator handle passed twice)");
+        return P2S_EINVAL;
+    }
+    if (m->cfg.patch_radius <= 0.0) r_patch = nullptr;
     P2S_HIP_CHECK(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     p2s_prof_reset(m);
@@ -379,7 +431,7 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
     if (n_done) *n_done = 0;
     const int64_t nq = q_end - q_begin;
     if (nq == 0) return P2S_OK;
-    rc = run_pipeline(m, c, r, nullptr, q_all, q_begin, q_end, chunk, sdf_out_dev, s);
+    rc = run_pipeline(m, c, r, nullptr, r_patch, q_all, q_begin, q_end, chunk, sdf_out_dev, s);
     if (rc) return rc;
     if (q_out_dev) {
         P2S_HIP_CHECK(hipMemcpyAsync(q_out_dev, q_all + (size_t)q_begin * 3, (size_t)nq * 12, hipMemcpyDeviceToDevice, s));
@@ -388,6 +440,7 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
     p2s_prof_collect(m);
     rc = p2s_rng_check(r, s);
     if (rc) return rc;
+    if (r_patch && (rc = p2s_rng_check(r_patch, s))) return rc;
     if ((rc = p2s_model_check_range(m, s))) return rc;
     if (n_done) *n_done = nq;
     return P2S_OK;
@@ -403,7 +456,7 @@ extern "C" int p2s_infer_queries(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r_sub, 
     hipStream_t s = (hipStream_t)stream;
     p2s_prof_reset(m);
     if (n_queries == 0) return P2S_OK;
-    int rc = run_pipeline(m, c, r_sub, r_rot, q_dev, 0, n_queries, chunk, sdf_out_dev, s);
+    int rc = run_pipeline(m, c, r_sub, r_rot, m->cfg.patch_radius > 0.0 ? r_rot : nullptr, q_dev, 0, n_queries, chunk, sdf_out_dev, s);
     if (rc) return rc;
     p2s_prof_collect(m);
     if ((rc = p2s_model_check_range(m, s))) return rc;

@@ -105,9 +105,9 @@ def _engine_cfg(train_opt, pred_dim):
         # of the regression model (experiments/train_p2s_regression.sh)
         raise ValueError('the HIP engine supports outputs imp_surf_magnitude, imp_surf_sign (in this order) or imp_surf '
                          '(got %s)' % outputs)
-    if getattr(train_opt, 'patch_radius', 0.0) > 0.0:
-        raise ValueError('fixed patch_radius (radius query) models are not supported by the HIP engine')
     return dict(
+        # > 0: experiments/train_p2s_{small,medium,large}_radius.sh (points2surf_amd/csrc/p2s_ball.hip)
+        patch_radius=max(float(getattr(train_opt, 'patch_radius', 0.0) or 0.0), 0.0),
         net_size=getattr(train_opt, 'net_size', 1024), points_per_patch=train_opt.points_per_patch,
         sub_sample_size=train_opt.sub_sample_size, output_dim=pred_dim,
         use_point_stn=bool(train_opt.use_point_stn), use_feat_stn=bool(train_opt.use_feat_stn),
@@ -135,10 +135,11 @@ def _load_points(indir, shape_name):
     return np.ascontiguousarray(pts)
 
 
-def _infer_one_shape(model, cloud, rng_dev, res, eps, chunk):
+def _infer_one_shape(model, cloud, rng_dev, res, eps, chunk, rng_patch=None):
     """the reference's batch loop for one shape (:358-404).  Both sub-sample modes run on the device:
-    randint (p2s_max) and the distance-weighted choice without replacement (p2s_vanilla)."""
-    return _engine.infer_shape(model, cloud, rng_dev, res, eps, chunk=chunk)
+    randint (p2s_max) and the distance-weighted choice without replacement (p2s_vanilla); fixed-radius models draw
+    their patch choice from ``rng_patch``, the data set's first generator."""
+    return _engine.infer_shape(model, cloud, rng_dev, res, eps, chunk=chunk, rng_patch=rng_patch)
 
 
 def _visualize_query_points(query_pts_ms, query_dist_ms, file_out):
@@ -252,7 +253,9 @@ def points_to_surf_eval(eval_opt):
         # one RNG stream over all shapes in dataset order (--workers 0 semantics of the reference)
         rng_dev = _engine.Rng(eval_opt.seed, device=device)
         # the dataset's FIRST RandomState (data_loader.py:272): rand(3) per query -> rotation, GT-query pass only
-        rng_rot = None if reconstruction else _engine.Rng(eval_opt.seed, device=device)
+        # -- and, for fixed-radius models, the patch choice of every query in both passes (:336)
+        ball = cfg['patch_radius'] > 0.0
+        rng_rot = None if (reconstruction and not ball) else _engine.Rng(eval_opt.seed, device=device)
         mine = set(range(len(shape_names)))
         if world > 1:
             sizes = [os.path.getsize(os.path.join(eval_opt.indir, '04_pts', n + '.xyz.npy'))
@@ -294,10 +297,10 @@ def points_to_surf_eval(eval_opt):
                 cloud = _engine.Cloud(_load_points(eval_opt.indir, shape_name), device=device)
                 q_all = cloud.query_grid(eval_opt.query_grid_resolution, eval_opt.epsilon)
                 q0, q1 = _sharding.query_range(int(q_all.shape[0]), world, rank)
-                _sharding.skip_queries(cloud, rng_dev, cfg, q_all[:q0], model.sub_sample_size)
+                _sharding.skip_queries(cloud, rng_dev, cfg, q_all[:q0], model.sub_sample_size, rng_patch=rng_rot)
                 sdf, q = _engine.infer_shape(model, cloud, rng_dev, eval_opt.query_grid_resolution, eval_opt.epsilon,
-                                             q_begin=q0, q_end=q1, chunk=chunk)
-                _sharding.skip_queries(cloud, rng_dev, cfg, q_all[q1:], model.sub_sample_size)
+                                             q_begin=q0, q_end=q1, chunk=chunk, rng_patch=rng_rot)
+                _sharding.skip_queries(cloud, rng_dev, cfg, q_all[q1:], model.sub_sample_size, rng_patch=rng_rot)
                 total_q += int(sdf.shape[0])
                 _write_part(model_out_dir, shape_name, rank, sdf.cpu().numpy(), q.cpu().numpy())
                 cloud.close()
@@ -306,15 +309,18 @@ def points_to_surf_eval(eval_opt):
                 if shape_ind not in mine:
                     continue
                 rng_dev = _engine.Rng((eval_opt.seed + shape_ind) & 0xffffffff, device=device)
+                if ball:
+                    rng_rot = _engine.Rng((eval_opt.seed + shape_ind) & 0xffffffff, device=device)
             pts_np = _load_points(eval_opt.indir, shape_name)
             if shape_ind not in mine:
                 # keep the dataset-wide stream exact on every rank: consume this shape's draws without inference
                 cloud = _engine.Cloud(pts_np, device=device)
                 _sharding.skip_shape_stream(cloud, rng_dev, cfg, eval_opt.query_grid_resolution,
-                                            eval_opt.epsilon, model.sub_sample_size)
+                                            eval_opt.epsilon, model.sub_sample_size, rng_patch=rng_rot)
                 continue
             cloud = _engine.Cloud(pts_np, device=device)
-            sdf, q = _infer_one_shape(model, cloud, rng_dev, eval_opt.query_grid_resolution, eval_opt.epsilon, chunk)
+            sdf, q = _infer_one_shape(model, cloud, rng_dev, eval_opt.query_grid_resolution, eval_opt.epsilon, chunk,
+                                      rng_patch=rng_rot)
             sdf_np = sdf.cpu().numpy()
             q_np = q.cpu().numpy()
             total_q += sdf_np.shape[0]

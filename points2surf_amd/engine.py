@@ -382,10 +382,62 @@ def query_logits(model, cloud, rng, queries, index):
     return logits[0]
 
 
+def kd_order(pts, leafsize=1000):
+    """HOST: the index array of ``scipy.spatial.cKDTree(pts, leafsize)`` (p2s_kd_order_host) -- the order in which
+    ``query_ball_point`` reports its hits.  Returns (order [n] int32, leaf_start [n_leaves + 1] int32)."""
+    lib = _lib.load()
+    p = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 3)
+    n = p.shape[0]
+    order = np.empty(n, np.int32)
+    leaf = np.empty(n + 2, np.int32)
+    nl = ctypes.c_int32(0)
+    _lib.check(lib.p2s_kd_order_host(p.ctypes.data_as(ctypes.c_void_p), n, int(leafsize), order.ctypes.data_as(ctypes.c_void_p),
+                                     leaf.ctypes.data_as(ctypes.c_void_p), n + 2, ctypes.byref(nl)))
+    return order, leaf[:nl.value + 1].copy()
+
+
+def ball_count(cloud, queries, radius):
+    """len(kdtree.query_ball_point(q, radius)) per query (p2s_ball_count) -> int32 device tensor"""
+    dev = cloud.device
+    q = _f32c(queries, dev).reshape(-1, 3)
+    out = torch.empty((max(int(q.shape[0]), 1),), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(cloud.lib.p2s_ball_count(cloud.handle, _ptr(q), int(q.shape[0]), float(radius), _ptr(out), _stream_ptr(dev)))
+    return out[:q.shape[0]]
+
+
+def ball_patch(cloud, rng, queries, radius, points_per_patch, with_rotation=False, want_ids=True):
+    """the fixed-radius patch of every query, in order (p2s_ball_patch; reference source/base/point_cloud.py:177-191,
+    source/data_loader.py:335-350): (ids [n,k] int32 or None, patch_ps [n,k,3], radius [n], rot [n,3,3] float64 or None).
+    ``rng`` = the data set's first generator."""
+    dev = cloud.device
+    q = _f32c(queries, dev).reshape(-1, 3)
+    n, k = int(q.shape[0]), int(points_per_patch)
+    ids = torch.empty((max(n, 1), k), dtype=torch.int32, device=dev) if want_ids else None
+    patch = torch.empty((max(n, 1), k, 3), dtype=torch.float32, device=dev)
+    rad = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
+    rot = torch.empty((max(n, 1), 3, 3), dtype=torch.float64, device=dev) if with_rotation else None
+    with torch.cuda.device(dev):
+        _lib.check(cloud.lib.p2s_ball_patch(rng.handle, cloud.handle, _ptr(q), n, float(radius), k, int(bool(with_rotation)),
+                                            _ptr(ids), _ptr(patch), _ptr(rad), _ptr(rot), _stream_ptr(dev)))
+    return (ids[:n] if ids is not None else None), patch[:n], rad[:n], (rot[:n] if rot is not None else None)
+
+
+def ball_skip(cloud, rng, queries, radius, points_per_patch, with_rotation=False):
+    """advance the first generator past the patch choices (and rotations) of ``queries`` without producing them"""
+    dev = cloud.device
+    q = _f32c(queries, dev).reshape(-1, 3)
+    rot = torch.empty((max(int(q.shape[0]), 1), 9), dtype=torch.float64, device=dev) if with_rotation else None
+    with torch.cuda.device(dev):
+        _lib.check(cloud.lib.p2s_ball_patch(rng.handle, cloud.handle, _ptr(q), int(q.shape[0]), float(radius), int(points_per_patch),
+                                            int(bool(with_rotation)), None, None, None, _ptr(rot), _stream_ptr(dev)))
+
+
 def infer_shape(model, cloud, rng, grid_resolution, epsilon, q_begin=0, q_end=-1, chunk=0, want_queries=True,
-                n_queries=None):
+                n_queries=None, rng_patch=None):
     """Fused per-shape pipeline (p2s_infer_shape).  Returns (sdf [n] device tensor, q [n,3] or None).
-    ``n_queries``: the size of the query grid if the caller already asked for it (Cloud.count_queries)."""
+    ``n_queries``: the size of the query grid if the caller already asked for it (Cloud.count_queries).
+    ``rng_patch``: fixed-radius models -- the data set's first generator (patch choice)."""
     dev = model.device
     lib = model.lib
     with torch.cuda.device(dev):
@@ -395,9 +447,10 @@ def infer_shape(model, cloud, rng, grid_resolution, epsilon, q_begin=0, q_end=-1
         sdf = torch.empty((max(nq, 1),), dtype=torch.float32, device=dev)
         q = torch.empty((max(nq, 1), 3), dtype=torch.float32, device=dev) if want_queries else None
         done = ctypes.c_int64(0)
-        _lib.check(lib.p2s_infer_shape(model.handle, cloud.handle, rng.handle, int(grid_resolution), int(epsilon),
-                                       int(q_begin), int(qe), int(chunk), _ptr(sdf), _ptr(q), ctypes.byref(done),
-                                       _stream_ptr(dev)))
+        _lib.check(lib.p2s_infer_shape_ball(model.handle, cloud.handle, rng.handle,
+                                            rng_patch.handle if rng_patch is not None else None, int(grid_resolution),
+                                            int(epsilon), int(q_begin), int(qe), int(chunk), _ptr(sdf), _ptr(q),
+                                            ctypes.byref(done), _stream_ptr(dev)))
     return sdf[:nq], (q[:nq] if q is not None else None)
 
 

@@ -31,6 +31,12 @@ NAMED_MODELS = {
     # experiments/train_p2s_shared_encoder.sh (--single_transformer 1): one PointNetfeat over cat(patch, sub-sample)
     # with its own QSTN + STN, then fc1_local_global 1024 -> 1024 (source/points_to_surf_model.py:253-263, :320-323)
     'p2s_shared_encoder': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, single_transformer=True),
+    # experiments/train_p2s_{small,medium,large}_radius.sh (--patch_radius 0.05 / 0.1 / 0.2): the patch is every point within
+    # that distance of the query -- a random 300 of them if there are more, padded with the query point if fewer
+    # (source/base/point_cloud.py:177-191)
+    'p2s_small_radius': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, patch_radius=0.05),
+    'p2s_medium_radius': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, patch_radius=0.1),
+    'p2s_large_radius': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, patch_radius=0.2),
 }
 
 

@@ -116,11 +116,17 @@ def query_range(n_queries, world, rank):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def skip_queries(cloud, rng_dev, cfg, queries, sub_sample_size, chunk=4096):
-    """advance the RNG stream past ``queries`` ([m,3] device tensor, in order) without inference"""
+def skip_queries(cloud, rng_dev, cfg, queries, sub_sample_size, chunk=4096, rng_patch=None):
+    """advance the RNG stream past ``queries`` ([m,3] device tensor, in order) without inference.  Fixed-radius models:
+    ``rng_patch`` (the data set's first generator) is advanced past the patch choices of the same queries."""
     m = int(queries.shape[0])
     if m == 0:
         return
+    if float(cfg.get('patch_radius', 0.0) or 0.0) > 0.0:
+        from . import engine
+        if rng_patch is None:
+            raise ValueError('fixed-radius model: the generator of the patch choice is required')
+        engine.ball_skip(cloud, rng_patch, queries, float(cfg['patch_radius']), int(cfg.get('points_per_patch', 300)))
     # fixed_subsample: every query re-seeds the generator, nothing carries over -- but ``rng.seed(42)`` sits INSIDE the
     # N >= sub_sample_size branch (reference source/base/utils.py:210-211): a cloud with fewer points still shuffles
     # shape.pts from the dataset-wide stream, also in fixed mode (the NULL-ids skip takes the shuffle + pad path)
@@ -136,13 +142,15 @@ def skip_queries(cloud, rng_dev, cfg, queries, sub_sample_size, chunk=4096):
             rng_dev.skip(cloud, sub_sample_size, query_ms=queries[s:s + chunk])
 
 
-def skip_shape_stream(cloud, rng_dev, cfg, grid_resolution, epsilon, sub_sample_size, chunk=4096):
+def skip_shape_stream(cloud, rng_dev, cfg, grid_resolution, epsilon, sub_sample_size, chunk=4096, rng_patch=None):
     """Advance the dataset-wide RNG stream past one shape without running the encoders and without
     materialising ids (NULL-ids path of the C ABI: p2s_max = a count of session values, p2s_vanilla = tables +
     offsets pass only)."""
     import torch
     q = cloud.query_grid(grid_resolution, epsilon)
-    skip_queries(cloud, rng_dev, cfg, q, sub_sample_size, chunk=chunk)
+    skip_queries(cloud, rng_dev, cfg, q, sub_sample_size, chunk=chunk, rng_patch=rng_patch)
     torch.cuda.synchronize()
     rng_dev.check()
+    if rng_patch is not None:
+        rng_patch.check()
     return int(q.shape[0])

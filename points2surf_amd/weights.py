@@ -44,7 +44,7 @@ class ModelCfg(ctypes.Structure):
                 ('use_point_stn', ctypes.c_int32), ('shared_transformer', ctypes.c_int32),
                 ('weighted_subsample', ctypes.c_int32), ('encoder_bf16', ctypes.c_int32),
                 ('fixed_subsample', ctypes.c_int32), ('single_transformer', ctypes.c_int32),
-                ('reserved', ctypes.c_int32 * 6)]
+                ('patch_radius', ctypes.c_double), ('reserved', ctypes.c_int32 * 4)]
 
 
 def _np(v):
@@ -187,6 +187,7 @@ def build_blob(state_dict, cfg):
     mc.weighted_subsample = int(not bool(cfg.get('uniform_subsample', False)))
     mc.fixed_subsample = int(bool(cfg.get('fixed_subsample', False)))
     mc.single_transformer = int(single)
+    mc.patch_radius = max(float(cfg.get('patch_radius', 0.0) or 0.0), 0.0)     # the float64 of the reference's Python float
     mc.encoder_bf16 = int(cfg.get('encoder_bf16', 0) or 0)      # 0 fp32, 1 bf16, 2 / 3 split bf16 (pieces per operand), 4 fp16 pair
     if mc.output_dim not in (1, 2):
         raise ValueError('engine supports outputs imp_surf (pred_dim 1) or imp_surf_magnitude + imp_surf_sign (pred_dim 2)')

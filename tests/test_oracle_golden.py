@@ -114,6 +114,32 @@ def test_end_to_end_prefix_matches_reference(golden_dir, fixture_cloud, meta):
     assert np.array_equal(np.sign(sdf), np.sign(ref))
 
 
+@pytest.mark.parametrize('model', ['p2s_small_radius', 'p2s_medium_radius', 'p2s_large_radius'])
+def test_fixed_radius_prefix_matches_reference(golden_dir, fixture_cloud, meta, model):
+    """fixed-radius models (experiments/train_p2s_*_radius.sh): ball query + random choice from the data set's FIRST
+    generator + distance-weighted sub-sample from the second, a prefix of the shape's queries, against the SDF the
+    unmodified reference wrote (oracle/make_golden_sizes.py rec <model> testset 32)"""
+    g = np.load(os.path.join(golden_dir, 'ref_rec_%s_testset_grid32.npz' % model))
+    w, cfg = synth.make_weights(model)
+    assert cfg['patch_radius'] > 0
+    rng, rng_patch = O.LegacyMT19937(meta['seed_data']), O.LegacyMT19937(meta['seed_data'])
+    nq = {'p2s_small_radius': 40, 'p2s_medium_radius': 125, 'p2s_large_radius': 40}[model]   # medium: first ball > 300 at 109
+    out = O.infer_shape(w, cfg, fixture_cloud, 32, 3, rng, query_range=(0, nq), rng_patch=rng_patch, return_all=True)
+    ref = g['rec_0'][:nq]
+    assert np.abs(out['sdf'] - ref).max() < 1e-5
+    assert np.array_equal(out['sdf'] > 0, ref > 0)
+    if model != 'p2s_small_radius':
+        assert (out['ball_counts'] > 300).any()          # the random choice was exercised
+
+
+def test_oracle_permutation_is_numpys():
+    for seed, n in ((1, 2), (2, 301), (3, 1025), (4, 3643)):
+        r = O.LegacyMT19937(seed)
+        rs = np.random.RandomState(seed)
+        assert np.array_equal(r.permutation(n), rs.permutation(n))
+        assert np.array_equal(r.raw(3), rs.randint(0, 2 ** 32, 3, dtype=np.uint32))
+
+
 @pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
 def test_torch_port_matches_reference(golden_dir, fixture_cloud, meta, model):
     """the torch-CPU port timed as bench.py's cpu_baseline is the same function as the reference"""
