@@ -20,7 +20,7 @@
 // choice(arange(c), k, replace=False) = permutation(c)[:k] = the legacy shuffle: for i = c-1 .. 1: j = rk_interval(i)
 // (32-bit words, masked rejection), swap(a[i], a[j]).  How many words a query consumes depends on the words: the start
 // of query q+1 is known only behind query q.  ball_chain_kernel walks that chain with ONE wave, resolving 64 words at
-// a time: lane l accepts its word iff (w & mask) <= i - (accepted words before l), a fixed point reached from the left
+// a time: a word is accepted iff (w & mask) <= i - (accepted words before it), a fixed point reached from the left
 // and detected when an evaluation changes nothing (2-3 evaluations; model: tests/radius_model.py).  With every start
 // known, ball_patch_kernel (one wave per query, all CUs) repeats the walk, applies the swaps to the query's hit list
 // and writes the patch.
@@ -164,45 +164,85 @@ __global__ __launch_bounds__(1024) void ball_offsets_kernel(const int *__restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// the legacy shuffle, 64 words at a time (one wave).  src(p) = raw word p + lane of the stream; emit(flag, i, j, t, steps):
-// flag lanes carry step t (< steps) of this block: swap(a[i - t], a[j]).  Returns the position behind the shuffle.
+// the legacy shuffle, 64 W words at a time (one wave, W words per lane: word 64 u + lane of the block in slot u).
+// Word j of a block belongs to step i - A_j (A_j = accepted words before it): it is accepted iff
+//     (w_j & mask(i - A_j)) <= i - A_j,      mask(t) = smallest 2^b - 1 >= t,
+// a fixed point in the accept flags that is reached from the left (word 0 is right after one evaluation) and detected
+// when an evaluation changes nothing.  The first evaluation starts from the expected counts A_j ~ j (i + 1) / 2^bits.
+// Model with evaluation counts: tests/radius_model.py (n = 3047: 18 blocks, 2.2 evaluations each).
+// src.prepare(p) / src.word(p, u) = raw word p + 64 u + lane of the stream; put(flag, t, j): flagged lanes carry step
+// t (< steps) of this block, whose swap is (a[i - t], a[j]); flush(i, steps) closes the block.  Returns the position
+// behind the shuffle.  i, pos and every count are wave-uniform and live in scalar registers as long as n does (callers
+// pass a readlane / scalar-load value); a lone wave issues ONE instruction, vector or scalar, per 4 cycles, so the
+// cost of a block is its instruction count: ~13 per 64 words and evaluation.
 // ---------------------------------------------------------------------------------------------------------------
-template <class Src, class Emit>
-__device__ __forceinline__ long long ball_shuffle_walk(Src &&src, long long pos, int n, Emit &&emit) {
+template <int W, class Src, class Put, class Flush>
+__device__ __forceinline__ long long ball_shuffle_walk(Src &&src, long long pos, int n, Put &&put, Flush &&flush) {
     const int lane = threadIdx.x & 63;
-    const uint64_t lt = (1ull << lane) - 1ull;
     int i = n - 1;
     while (i >= 1) {
-        uint32_t mask = (uint32_t)i;
-        mask |= mask >> 1;
-        mask |= mask >> 2;
-        mask |= mask >> 4;
-        mask |= mask >> 8;
-        mask |= mask >> 16;
-        const int lim = i - (int)(mask >> 1);                   // steps left under this mask
-        const int v = (int)(src(pos) & mask);
-        uint64_t b = __ballot(v <= i);
-        bool acc;
+        uint32_t w[W];
+        int v[W], before[W];
+        uint64_t b[W];
+        src.prepare(pos);
+        const int bits = 32 - __builtin_clz((uint32_t)i);
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            w[u] = src.word(pos, u);
+            const int thr = i - (int)(((uint32_t)(64 * u + lane) * (uint32_t)(i + 1)) >> bits);       // expected step of this word
+            const uint32_t m = 0xffffffffu >> __builtin_clz((uint32_t)(thr > 1 ? thr : 1));
+            b[u] = __builtin_amdgcn_ballot_w64((int)(w[u] & m) <= thr);
+        }
         for (;;) {
-            acc = v <= i - __popcll(b & lt);
-            const uint64_t b2 = __ballot(acc);
-            if (b2 == b) break;
-            b = b2;
+            int base = 0;
+#pragma unroll
+            for (int u = 0; u < W; ++u) {                       // accepted words before this one: v_mbcnt_lo / _hi
+                before[u] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b[u], (uint32_t)base));
+                base += __popcll(b[u]);
+            }
+            uint64_t diff = 0;
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
+                // words behind the last step (thr < 1) may come out "accepted" (thr = 0: an even word): they lie behind
+                // the cut below and change nothing before it -- the flags are still a function of the flags to their left
+                const int thr = i - before[u];
+                const uint32_t m = 0xffffffffu >> __builtin_clz((uint32_t)(thr > 1 ? thr : 1));
+                v[u] = (int)(w[u] & m);
+                const uint64_t nb = __builtin_amdgcn_ballot_w64(v[u] <= thr);
+                diff |= nb ^ b[u];
+                b[u] = nb;
+            }
+            if (diff == 0) break;
         }
-        const int before = __popcll(b & lt);
-        const int total = __popcll(b);
-        int consumed = 64, steps = total;
-        if (total >= lim) {
-            const uint64_t hit = __ballot(acc && before == lim - 1);
-            consumed = __ffsll((long long)hit);                 // lane of the lim-th accepted word, + 1
-            steps = lim;
+        int total = 0;
+#pragma unroll
+        for (int u = 0; u < W; ++u) total += __popcll(b[u]);
+        int consumed = 64 * W, steps = total;
+        if (total >= i) {                                       // the shuffle ends inside this block: stop behind step i
+            steps = i;
+            int base = 0;
+            bool found = false;
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
+                const int cnt = __popcll(b[u]);
+                if (!found && base + cnt >= i) {
+                    const uint64_t hit = b[u] & __ballot(before[u] == i - 1);
+                    consumed = 64 * u + __ffsll((long long)hit);
+                    found = true;
+                }
+                base += cnt;
+            }
         }
-        emit(acc && before < steps, i, v, before, steps);
+#pragma unroll
+        for (int u = 0; u < W; ++u) put(((b[u] >> lane) & 1ull) != 0 && before[u] < steps, before[u], v[u]);
+        flush(i, steps);
         pos += consumed;
         i -= steps;
     }
     return pos;
 }
+
+constexpr int BALL_W = 4;                            // words per lane and block
 
 constexpr int BC_RING = 8192;                        // words staged in LDS by the chain wave
 
@@ -234,20 +274,32 @@ __global__ __launch_bounds__(64) void ball_chain_kernel(const uint32_t *__restri
     };
     issue();
     bool overflow = false;
-    auto src = [&](long long p) -> uint32_t {
-        while (p + 64 > w_hi) commit();
-        overflow |= p + 64 > cap_words;
-        return bc_ring[(p + lane) & (BC_RING - 1)];
-    };
-    auto no_emit = [](bool, int, int, int, int) {};
+    struct RingSrc {
+        decltype(commit) &commit_;
+        long long &w_hi_;
+        bool &overflow_;
+        long long cap_;
+        const uint32_t *ring_;
+        int lane_;
+        __device__ __forceinline__ void prepare(long long p) {
+            while (p + 64 * BALL_W > w_hi_) commit_();
+            overflow_ |= p + 64 * BALL_W > cap_;
+        }
+        __device__ __forceinline__ uint32_t word(long long p, int u) const {
+            return ring_[((uint32_t)p + 64u * (uint32_t)u + (uint32_t)lane_) & (BC_RING - 1)];
+        }
+    } src{commit, w_hi, overflow, cap_words, bc_ring, lane};
+    auto no_put = [](bool, int, int) {};
+    auto no_flush = [](int, int) {};
+    __builtin_amdgcn_s_setprio(3);
     for (int q0 = 0; q0 < nq; q0 += 64) {
         const int mine = q0 + lane < nq ? count[q0 + lane] : 0;
         long long my_s = 0, my_t = 0;
         const int m = nq - q0 < 64 ? nq - q0 : 64;
         for (int u = 0; u < m; ++u) {
-            const int c = __shfl(mine, u);
+            const int c = __builtin_amdgcn_readlane(mine, u);      // scalar: the whole walk stays on the scalar unit
             if (lane == u) my_s = pos;
-            if (c > k) pos = ball_shuffle_walk(src, pos, c, no_emit);
+            if (c > k) pos = ball_shuffle_walk<BALL_W>(src, pos, c, no_put, no_flush);
             if (lane == u) my_t = pos;
             pos += tail_words;
         }
@@ -273,7 +325,7 @@ __global__ __launch_bounds__(64) void ball_patch_kernel(const uint32_t *__restri
                                                         float *__restrict__ patch_out, float *__restrict__ radius_out,
                                                         const long long *__restrict__ meta) {
     __shared__ int lds_list[BP_CAP];
-    __shared__ int jbuf[64];
+    __shared__ int jbuf[64 * BALL_W];
     const int w = blockIdx.x, lane = threadIdx.x;
     if (meta[1] != 0) return;
     const int c = count[w];
@@ -284,9 +336,20 @@ __global__ __launch_bounds__(64) void ball_patch_kernel(const uint32_t *__restri
             arr = lds_list;
             __syncthreads();
         }
-        auto src = [&](long long p) -> uint32_t { return p + lane < cap_words ? words[p + lane] : 0u; };
-        auto emit = [&](bool flag, int i, int j, int t, int steps) {
+        struct GlobalSrc {
+            const uint32_t *words_;
+            long long cap_;
+            int lane_;
+            __device__ __forceinline__ void prepare(long long) const {}
+            __device__ __forceinline__ uint32_t word(long long p, int u) const {
+                const long long w = p + 64 * u + lane_;
+                return w < cap_ ? words_[w] : 0u;
+            }
+        } src{words, cap_words, lane};
+        auto put = [&](bool flag, int t, int j) {
             if (flag) jbuf[t] = j;
+        };
+        auto flush = [&](int i, int steps) {
             __syncthreads();
             if (lane == 0)
                 for (int u = 0; u < steps; ++u) {
@@ -297,7 +360,7 @@ __global__ __launch_bounds__(64) void ball_patch_kernel(const uint32_t *__restri
                 }
             __syncthreads();
         };
-        (void)ball_shuffle_walk(src, spos[w], c, emit);
+        (void)ball_shuffle_walk<BALL_W>(src, spos[w], c, put, flush);
     }
     const float qx = q[3 * (size_t)w + 0], qy = q[3 * (size_t)w + 1], qz = q[3 * (size_t)w + 2];
     for (int t = lane; t < k; t += 64) {

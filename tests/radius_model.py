@@ -5,9 +5,9 @@ tests/wchoice_model.py models the weighted sub-sample: the numpy-legacy shuffle 
     = RandomState.permutation(point_count)[:points_per_patch]
     = for i = n-1 .. 1:  j = rk_interval(i)  (32-bit words, masked rejection);  swap(a[i], a[j])
 
-resolved 64 raw words at a time: lane l accepts its word iff (w & mask) <= i - (accepted words before l) -- a fixed point
-that is reached from the left (lane 0 is right after one evaluation, lane l after l + 1 at the latest) and detected when
-an evaluation changes nothing.  A block ends early where the mask changes (i crosses a power of two)."""
+resolved 256 raw words at a time (the kernels' block, four words per lane): word j is accepted iff
+(w_j & mask(i - A_j)) <= i - A_j with A_j = accepted words before it -- a fixed point that is reached from the left (word 0
+is right after one evaluation, word j after j + 1 at the latest) and detected when an evaluation changes nothing."""
 import numpy as np
 
 
@@ -18,29 +18,42 @@ def smear(i):
     return m
 
 
-def walk_blocks(words, pos, n, lanes=64):
-    """-> (position after the shuffle of n elements, [(i, j)] in execution order, blocks, evaluations)"""
+def _smear_v(x):
+    x = x.copy()
+    for s in (1, 2, 4, 8, 16):
+        x |= x >> s
+    return x
+
+
+def walk_blocks(words, pos, n, lanes=256, guess=True):
+    """-> (position after the shuffle of n elements, [(i, j)] in execution order, blocks, evaluations).
+    Word j of a block belongs to step i - A_j: its mask and its threshold follow from the accepted words before it, so
+    a block runs across the powers of two and only the end of the shuffle cuts it short."""
     i = n - 1
     swaps = []
     blocks = evals = 0
     lane = np.arange(lanes)
     while i >= 1:
-        mask = smear(i)
-        lim = i - (mask >> 1)                       # steps left under this mask
-        v = (words[pos:pos + lanes] & np.uint32(mask)).astype(np.int64)
-        acc = v <= i
+        w = words[pos:pos + lanes].astype(np.int64)
+        bits = int(smear(i)).bit_length()
+
+        def evaluate(before):
+            thr = i - before
+            v = w & _smear_v(np.maximum(thr, 1))
+            return (thr >= 1) & (v <= thr), v
+        acc, v = evaluate((lane * (i + 1)) >> bits if guess else np.zeros(lanes, np.int64))
         while True:
             evals += 1
             before = np.concatenate(([0], np.cumsum(acc)[:-1]))
-            acc2 = v <= i - before
+            acc2, v = evaluate(before)
             if np.array_equal(acc2, acc):
                 break
             acc = acc2
         before = np.concatenate(([0], np.cumsum(acc)[:-1]))
         total = int(acc.sum())
-        if total >= lim:
-            last = int(lane[acc & (before == lim - 1)][0])
-            consumed, steps = last + 1, lim
+        if total >= i:
+            last = int(lane[acc & (before == i - 1)][0])
+            consumed, steps = last + 1, i
         else:
             consumed, steps = lanes, total
         for l in lane[acc & (before < steps)]:
@@ -51,8 +64,8 @@ def walk_blocks(words, pos, n, lanes=64):
     return pos, swaps, blocks, evals
 
 
-def permutation(words, pos, n):
-    pos2, swaps, _, _ = walk_blocks(words, pos, n)
+def permutation(words, pos, n, lanes=256):
+    pos2, swaps, _, _ = walk_blocks(words, pos, n, lanes=lanes)
     a = np.arange(n, dtype=np.int64)
     for i, j in swaps:
         a[i], a[j] = a[j], a[i]

@@ -119,7 +119,7 @@ def test_ball_patch_with_rotation_interleaves_the_rand3(fixture_cloud):
 
 
 def test_ball_patch_long_lists_and_many_queries():
-    """the 86,648-point cloud at r = 0.2: hit lists beyond the LDS capacity (global-memory shuffle), several thousand
+    """the 86,648-point cloud at r = 0.3: a third of the hit lists beyond the LDS capacity (global-memory shuffle), several thousand
     queries in one call (word staging of the chain wave wraps its ring many times)"""
     import torch
     from points2surf_amd import engine
@@ -128,10 +128,10 @@ def test_ball_patch_long_lists_and_many_queries():
     tree = spatial.cKDTree(pts, 1000)
     cloud = engine.Cloud(pts)
     q = _queries(pts, 1500, 3, spread=0.01)
-    ids_r, patch_r, counts, _, rs = _reference_patches(1, pts, tree, q, 0.2, 300)
-    assert counts.max() > 8192
+    ids_r, patch_r, counts, _, rs = _reference_patches(1, pts, tree, q, 0.3, 300)
+    assert counts.max() > 8192 and (counts <= 8192).any()
     rng = engine.Rng(1)
-    ids, patch, _, _ = engine.ball_patch(cloud, rng, torch.from_numpy(q).cuda(), 0.2, 300)
+    ids, patch, _, _ = engine.ball_patch(cloud, rng, torch.from_numpy(q).cuda(), 0.3, 300)
     rng.check()
     assert np.array_equal(ids.cpu().numpy(), ids_r)
     assert np.array_equal(patch.cpu().numpy().view(np.uint32), patch_r.view(np.uint32))

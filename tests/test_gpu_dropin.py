@@ -37,7 +37,8 @@ def _write_model_files(modeldir, name):
     torch.save(synth.to_torch_state_dict(w), os.path.join(modeldir, name + '_model.pth'))
     ns = argparse.Namespace(
         outputs=['imp_surf_magnitude', 'imp_surf_sign', 'patch_pts_ids', 'p_index'], points_per_patch=300,
-        patch_center='mean', sub_sample_size=1000, patch_radius=0.0, uniform_subsample=int(cfg['uniform_subsample']),
+        patch_center='mean', sub_sample_size=1000, patch_radius=float(cfg.get('patch_radius', 0.0)),
+        uniform_subsample=int(cfg['uniform_subsample']),
         fixed_subsample=0, net_size=1024, use_point_stn=int(cfg['use_point_stn']), use_feat_stn=1, sym_op='max',
         single_transformer=0, shared_transformer=int(cfg['shared_transformer']), batchSize=501)
     torch.save(ns, os.path.join(modeldir, name + '_params.pth'))
@@ -303,3 +304,45 @@ def test_standin_dataset_of_22_clouds_sharded_like_single_process(dropin_source,
         assert a.shape == b.shape and a.size > 3000 and np.isfinite(a).all() and np.array_equal(a, b), n
         counts.add(a.size)
     assert len(counts) > 10
+
+
+def test_fixed_radius_model_through_the_dropin_and_sharded(dropin_source, tmp_path, fixture_cloud, golden_dir, monkeypatch):
+    """experiments/train_p2s_medium_radius.sh through the drop-in: (1) the files equal the SDF the unmodified reference
+    wrote; (2) two shapes, two sequential "ranks" with the exact dataset-wide streams (BOTH generators advanced past the
+    other rank's shape) = the single-process run"""
+    ev, _ = dropin_source
+    name = 'p2s_medium_radius'
+    modeldir = str(tmp_path / 'models')
+    _write_model_files(modeldir, name)
+
+    def run(root, outdir, world=1, rank=0):
+        monkeypatch.setenv('WORLD_SIZE', str(world))
+        monkeypatch.setenv('RANK', str(rank))
+        monkeypatch.setenv('LOCAL_RANK', '0')
+        opt = ev.parse_arguments(['--indir', root, '--outdir', outdir, '--dataset', 'testset.txt', '--modeldir', modeldir,
+                                  '--models', name, '--query_grid_resolution', '32', '--epsilon', '3',
+                                  '--certainty_threshold', '13', '--sigma', '5', '--workers', '0', '--batchSize', '501',
+                                  '--cache_capacity', '5'])
+        opt.reconstruction = True
+        ev.points_to_surf_eval(opt)
+
+    root1 = str(tmp_path / 'one')
+    _make_dataset(root1, fixture_cloud)
+    run(root1, str(tmp_path / 'res1'))
+    sdf = np.load(os.path.join(str(tmp_path / 'res1'), 'rec', 'dist_ms', SHAPE + '.xyz.npy'))
+    ref = np.load(os.path.join(golden_dir, 'ref_rec_%s_testset_grid32.npz' % name))['rec_0']
+    # 1e-4 contract; a fixed-radius model's distances are not scaled by a patch radius of ~0.05: |sdf| up to 1
+    assert np.abs(sdf - ref).max() < 1e-4 and int(((sdf > 0) != (ref > 0)).sum()) == 0
+    root2 = str(tmp_path / 'two')
+    names = _make_dataset(root2, fixture_cloud, n_shapes=2)
+    run(root2, str(tmp_path / 'single'))
+    for rank in (0, 1):
+        run(root2, str(tmp_path / 'sharded'), world=2, rank=rank)
+    for n in names:
+        a = np.load(os.path.join(str(tmp_path / 'single'), 'rec', 'dist_ms', n + '.xyz.npy'))
+        b = np.load(os.path.join(str(tmp_path / 'sharded'), 'rec', 'dist_ms', n + '.xyz.npy'))
+        assert np.array_equal(a, b), n
+    # the second copy of the cloud continues both streams: not the first shape's values again
+    a0 = np.load(os.path.join(str(tmp_path / 'single'), 'rec', 'dist_ms', names[0] + '.xyz.npy'))
+    a1 = np.load(os.path.join(str(tmp_path / 'single'), 'rec', 'dist_ms', names[1] + '.xyz.npy'))
+    assert not np.array_equal(a0, a1)
