@@ -83,7 +83,7 @@ def test_reference_volumes_32_are_meshed_like_scikit_image(key):
 
 
 @pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
-@pytest.mark.parametrize('res', [128, 256])
+@pytest.mark.parametrize('res', [128, 256, 512])
 def test_reference_sdf_to_mesh_counts_equal_scikit_image(model, res, fixture_cloud):
     """BASELINE north_star: 'bit-identical mesh vertex/face counts'.  The reference's full-grid SDF golden -> sign
     propagation ON THE DEVICE (volume hash = the volume scikit-image was given) -> iso-surface ON THE DEVICE: the counts
