@@ -588,16 +588,28 @@ def infer_queries(w, cfg, pts, queries, rng_sub, rng_rot=None, points_per_patch=
     from oracle import trimesh_restated as trafo
     pts = np.asarray(pts, dtype=np.float32)
     q = np.asarray(queries, dtype=np.float32).reshape(-1, 3)
-    ids = knn_ids(pts, q, points_per_patch)
-    r, patch_ps = patch_radius_and_ps(pts, ids, q)
+    radius = float(cfg.get('patch_radius', 0.0) or 0.0)
+    n = q.shape[0]
+    if radius > 0.0:
+        # fixed-radius models: the patch choice of query i draws from dataset.rng (= rng_rot) BEFORE that query's
+        # rand(3) (source/data_loader.py:336, :384); the distance output is not rescaled
+        from scipy import spatial
+        tree = spatial.cKDTree(pts, 1000)
+        r = np.ones(n, np.float32)
+        patch_ps = np.zeros((n, points_per_patch, 3), np.float32)
+    else:
+        ids = knn_ids(pts, q, points_per_patch)
+        r, patch_ps = patch_radius_and_ps(pts, ids, q)
     uniform = bool(cfg.get('uniform_subsample', False))
     fixed = bool(cfg.get('fixed_subsample', False))
-    n = q.shape[0]
     sub = np.zeros((n, sub_sample_size, 3), np.float32)
     q_rot = q.copy()
     patch_rot = patch_ps.copy()
     rots = np.zeros((n, 3, 3))
     for i in range(n):
+        if radius > 0.0:
+            _, patch_ps[i], _ = ball_patch(rng_rot, pts, tree, q[i], radius, points_per_patch)
+            patch_rot[i] = patch_ps[i]
         sub_ids = subsample_ids(rng_sub, pts, q[i], sub_sample_size, uniform, fixed)
         sub[i] = pts[sub_ids]
         if rng_rot is not None:

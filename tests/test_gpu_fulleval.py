@@ -42,7 +42,8 @@ def _write_model_files(modeldir, name):
     torch.save(synth.to_torch_state_dict(w), os.path.join(modeldir, name + '_model.pth'))
     ns = argparse.Namespace(
         outputs=['imp_surf_magnitude', 'imp_surf_sign', 'patch_pts_ids', 'p_index'], points_per_patch=300,
-        patch_center='mean', sub_sample_size=1000, patch_radius=0.0, uniform_subsample=int(cfg['uniform_subsample']),
+        patch_center='mean', sub_sample_size=1000, patch_radius=float(cfg.get('patch_radius', 0.0)),
+        uniform_subsample=int(cfg['uniform_subsample']),
         fixed_subsample=0, net_size=1024, use_point_stn=int(cfg['use_point_stn']), use_feat_stn=1, sym_op='max',
         single_transformer=0, shared_transformer=int(cfg['shared_transformer']), batchSize=501)
     torch.save(ns, os.path.join(modeldir, name + '_params.pth'))
@@ -56,8 +57,10 @@ def _eval_predictions_row(pred, gt):
             'var_gt': (gt * gt).mean() - gt.mean() * gt.mean(), 'var_pred': (pred * pred).mean() - pred.mean() * pred.mean()}
 
 
-@pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
+@pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla', 'p2s_medium_radius'])
 def test_full_eval_call_sequence_matches_reference(model, dropin_eval, tmp_path):
+    # fixed-radius model: distances are not scaled by a ~0.05 patch radius, |sdf| up to 1 -> absolute noise 20x (contract 1e-4)
+    tol = 1e-4 if model.endswith('_radius') else 1e-5
     key = 'ref_fulleval_%s_abc3_grid32' % model
     if not os.path.isfile(os.path.join(GOLDEN, key + '.npz')):
         pytest.skip(key + ' not generated')
@@ -110,7 +113,7 @@ def test_full_eval_call_sequence_matches_reference(model, dropin_eval, tmp_path)
         d = float(np.abs(pred - ref).max())
         flips = int((np.sign(pred) != np.sign(ref)).sum())
         print('%s GT-query pass shape %d: max|dSDF| %.3g, sign flips %d/%d' % (model, i, d, flips, ref.size))
-        assert pred.shape == ref.shape == (2000,) and d < 1e-5 and flips == 0
+        assert pred.shape == ref.shape == (2000,) and d < tol and flips == 0
         assert os.path.isfile(os.path.join(res_dir_eval, 'eval', n + '.xyz.txt'))
         assert os.path.isfile(os.path.join(res_dir_eval, 'vis', n + '.ply'))
         assert not os.path.exists(os.path.join(res_dir_eval, 'dist_ms'))          # only written in reconstruction mode
@@ -124,7 +127,7 @@ def test_full_eval_call_sequence_matches_reference(model, dropin_eval, tmp_path)
         d = float(np.abs(rec - ref).max())
         flips = int((np.sign(rec) != np.sign(ref)).sum())
         print('%s reconstruction pass shape %d: max|dSDF| %.3g, sign flips %d/%d' % (model, i, d, flips, ref.size))
-        assert rec.shape == ref.shape and d < 1e-5 and flips == 0
+        assert rec.shape == ref.shape and d < tol and flips == 0
         for sub in ('eval', 'query_pts_ms'):
             assert os.path.isfile(os.path.join(res_dir_rec, sub, n + '.xyz.npy'))
         assert os.path.isfile(os.path.join(res_dir_rec, 'query_pts_ms_vis', n + '.ply'))

@@ -132,6 +132,24 @@ def test_fixed_radius_prefix_matches_reference(golden_dir, fixture_cloud, meta, 
         assert (out['ball_counts'] > 300).any()          # the random choice was exercised
 
 
+def test_fixed_radius_gt_query_pass_matches_reference(golden_dir, meta):
+    """GT-query pass of a fixed-radius model (the reference's own full_eval.py wrote the golden): per query the patch
+    choice and THEN rand(3), both from the data set's first generator"""
+    path = os.path.join(golden_dir, 'ref_fulleval_p2s_medium_radius_abc3_grid32.npz')
+    if not os.path.isfile(path):
+        pytest.skip('golden not generated')
+    g = np.load(path)
+    fix = os.path.join(golden_dir, 'abc_minimal')
+    with open(os.path.join(fix, 'abc3.txt')) as f:
+        name = [x.strip() for x in f if x.strip()][0]
+    pts = np.load(os.path.join(fix, '04_pts', name + '.xyz.npy')).astype(np.float32)
+    q = np.load(os.path.join(fix, '05_query_pts', name + '.ply.npy')).astype(np.float32)[:60]
+    w, cfg = synth.make_weights('p2s_medium_radius')
+    sdf = O.infer_queries(w, cfg, pts, q, O.LegacyMT19937(meta['seed_data']), O.LegacyMT19937(meta['seed_data']))
+    ref = g['eval_0'][:60]
+    assert np.abs(sdf - ref).max() < 1e-5 and np.array_equal(sdf > 0, ref > 0)
+
+
 def test_oracle_permutation_is_numpys():
     for seed, n in ((1, 2), (2, 301), (3, 1025), (4, 3643)):
         r = O.LegacyMT19937(seed)
