@@ -164,3 +164,33 @@ def test_radius_models_match_the_reference_golden(fixture_cloud, golden_dir, mod
         engine.infer_shape(m, cloud, rng, 32, 3)
     m.close()
     cloud.close()
+
+
+def test_radius_model_is_invariant_to_chunking_and_query_ranges(fixture_cloud):
+    """size-independent property: where a query's random words start depends on the queries before it, never on how the
+    pipeline batches them -- default chunks vs chunks of 777 queries vs two query ranges with the generators advanced
+    past the first (what query-range sharding does) give the same SDF, bit for bit, at 64^3 (12k queries)"""
+    import torch
+    from points2surf_amd import engine, sharding, synth
+    w, cfg = synth.make_weights('p2s_large_radius')
+    m = engine.Model(w, cfg)
+    cloud = engine.Cloud(fixture_cloud)
+
+    def run(**kw):
+        r1, r2 = engine.Rng(11), engine.Rng(11)
+        sdf, _ = engine.infer_shape(m, cloud, r1, 64, 3, rng_patch=r2, **kw)
+        return sdf.cpu().numpy(), r1.get_state(), r2.get_state()
+
+    a, s1, s2 = run()
+    b, t1, t2 = run(chunk=777)
+    assert a.shape[0] > 10000 and np.array_equal(a, b)
+    assert np.array_equal(s1[0], t1[0]) and s1[1] == t1[1] and np.array_equal(s2[0], t2[0]) and s2[1] == t2[1]
+    # second half only: both generators skipped past the first half
+    q = cloud.query_grid(64, 3)
+    half = int(q.shape[0]) // 2 + 13
+    r1, r2 = engine.Rng(11), engine.Rng(11)
+    sharding.skip_queries(cloud, r1, cfg, q[:half], 1000, rng_patch=r2)
+    c, _ = engine.infer_shape(m, cloud, r1, 64, 3, q_begin=half, rng_patch=r2)
+    assert np.array_equal(c.cpu().numpy(), a[half:])
+    m.close()
+    cloud.close()
