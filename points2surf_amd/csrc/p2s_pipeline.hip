@@ -220,7 +220,9 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         // measured slower: the masked compute stream lost far more than the masked-off CUs.)
         int lo = 0, hi = 0;
         P2S_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, hi));
+        // development knob P2S_AUX_PRIO=normal: the auxiliary stream without the priority (A/B of the scheduling)
+        const char *pr = getenv("P2S_AUX_PRIO");
+        P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, (pr && !strcmp(pr, "normal")) ? lo : hi));
     }
     hipStream_t sa = m->overlap ? m->aux : s;
     // OPT-IN (P2S_PREP_STREAM=1): kNN + gather of chunk i+1 on a third stream, under the encoders of chunk i.  Measured
