@@ -34,6 +34,8 @@ NAMED_MODELS = {
     # experiments/train_p2s_{small,medium,large}_radius.sh (--patch_radius 0.05 / 0.1 / 0.2): the patch is every point within
     # that distance of the query -- a random 300 of them if there are more, padded with the query point if fewer
     # (source/base/point_cloud.py:177-191)
+    # train --use_feat_stn 0 (no script of the reference sets it): p2s_max without the 64x64 feature transforms
+    'p2s_max_no_feat_stn': dict(use_point_stn=False, shared_transformation=False, uniform_subsample=True, use_feat_stn=False),
     'p2s_small_radius': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, patch_radius=0.05),
     'p2s_medium_radius': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, patch_radius=0.1),
     'p2s_large_radius': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, patch_radius=0.2),

@@ -19,7 +19,7 @@ _FC4_BIAS_SHIFT = {'p2s_max': (6.289174, 2.416443), 'p2s_vanilla': (2.6854432, 4
                    'p2s_uniform': (4.6575, 2.458), 'p2s_no_qstn': (2.3863, 1.8502), 'p2s_small_kNN': (4.2235, 2.2435),
                    'p2s_large_kNN': (4.9557, 2.6857), 'p2s_regression': (3.7676,), 'p2s_shared_encoder': (-0.2, -3.9804),
                    'p2s_small_radius': (2.6671, 1.4694), 'p2s_medium_radius': (3.4947, 2.3483),
-                   'p2s_large_radius': (3.9348, 2.7203)}
+                   'p2s_large_radius': (3.9348, 2.7203), 'p2s_max_no_feat_stn': (0.1092, 2.8237)}
 
 
 # Second synthetic weight set of p2s_vanilla: the same weights with the bias of the SIGN logit moved by the median of
@@ -86,7 +86,7 @@ def make_weights(model='p2s_max', seed=1234, net_size_max=1024, output_dim=None)
     cfg_out = dict(
         use_point_stn=bool(cfg.get('use_point_stn', False)),
         shared_transformer=bool(cfg.get('shared_transformation', False)),
-        use_feat_stn=True, single_transformer=single,
+        use_feat_stn=bool(cfg.get('use_feat_stn', True)), single_transformer=single,
         uniform_subsample=bool(cfg.get('uniform_subsample', False)), fixed_subsample=False,
         net_size=net_size_max, points_per_patch=int(cfg.get('points_per_patch', 300)), sub_sample_size=1000,
         output_dim=output_dim, patch_radius=float(cfg.get('patch_radius', 0.0)))

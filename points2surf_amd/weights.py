@@ -131,7 +131,22 @@ def build_blob(state_dict, cfg):
     use_point_stn = bool(cfg.get('use_point_stn', False))
     shared = bool(cfg.get('shared_transformer', False))
     if not bool(cfg.get('use_feat_stn', True)):
-        raise ValueError('use_feat_stn=0 ablation is not on the accelerated path')
+        # train --use_feat_stn 0 (set by none of the reference's scripts): PointNetfeat without the 64x64 feature
+        # transform (reference source/points_to_surf_model.py:151-153,194-199).  The engine keeps its one code path and
+        # gets the identity from an all-zero STN: trans = 0 + bias(I) exactly, and the fold W1' = conv1 . I is exact
+        # (one non-zero product per sum).  The STN trunk still runs -- not optimised, no script uses it.
+        w = dict(w)
+        for pre in (('feat_local_global',) if bool(cfg.get('single_transformer', False)) else ('feat_local', 'feat_global')):
+            s = pre + '.stn2'
+            for name, shape in (('conv1', (64, 64, 1)), ('conv2', (128, 64, 1)), ('conv3', (1024, 128, 1)),
+                                ('fc1', (512, 1024)), ('fc2', (256, 512)), ('fc3', (4096, 256))):
+                w[s + '.' + name + '.weight'] = np.zeros(shape, np.float32)
+                w[s + '.' + name + '.bias'] = np.zeros(shape[0], np.float32)
+            for bn, c in (('bn1', 64), ('bn2', 128), ('bn3', 1024), ('bn4', 512), ('bn5', 256)):
+                w[s + '.' + bn + '.weight'] = np.ones(c, np.float32)
+                w[s + '.' + bn + '.bias'] = np.zeros(c, np.float32)
+                w[s + '.' + bn + '.running_mean'] = np.zeros(c, np.float32)
+                w[s + '.' + bn + '.running_var'] = np.ones(c, np.float32)
     single = bool(cfg.get('single_transformer', False))
     if cfg.get('sym_op', 'max') != 'max':
         raise ValueError("Unsupported symmetric operation: %s" % cfg.get('sym_op'))

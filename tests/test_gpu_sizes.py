@@ -246,13 +246,14 @@ def test_small_cloud_shuffle_and_pad_matches_reference(model):
 
 
 @pytest.mark.parametrize('model', ['p2s_uniform', 'p2s_no_qstn', 'p2s_small_kNN', 'p2s_large_kNN', 'p2s_regression',
-                                   'p2s_shared_encoder'])
+                                   'p2s_shared_encoder', 'p2s_max_no_feat_stn'])
 def test_ablation_models_match_reference(model):
     """the paper's ablation models whose branches the engine implements (reference experiments/train_p2s_*.sh): QSTN
     inside feat_global (sees the sub-sample only; its rotation also turns the patch -- source/points_to_surf_model.py
     :283-284, :337-339), no QSTN with the weighted sub-sample, 75- and 1200-point patches, the regression model (ONE
     output: the signed distance, sdf_nn.py:6-8) and the single encoder over cat(patch, sub-sample) (--single_transformer
-    1, :253-263, :320-323).  Whole grid-32 shape against the unmodified reference."""
+    1, :253-263, :320-323); p2s_max_no_feat_stn = --use_feat_stn 0 (set by no script; the engine runs its usual path with
+    an all-zero STN whose output is exactly the identity).  Whole grid-32 shape against the unmodified reference."""
     import torch
     from points2surf_amd import engine, synth
     key = 'ref_rec_%s_testset_grid32' % model

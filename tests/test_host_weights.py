@@ -86,11 +86,21 @@ def test_engine_algebra_matches_oracle(model, fixture_cloud):
 
 def test_unsupported_configs_raise():
     w, cfg = synth.make_weights('p2s_max')
-    for bad in (dict(use_feat_stn=False), dict(sym_op='sum'), dict(net_size=512), dict(output_dim=3)):
+    for bad in (dict(sym_op='sum'), dict(net_size=512), dict(output_dim=3)):
         c = dict(cfg)
         c.update(bad)
         with pytest.raises(ValueError):
             weights.build_blob(w, c)
+
+
+def test_no_feat_stn_becomes_an_exact_identity_transform():
+    """train --use_feat_stn 0: the blob holds an all-zero feature STN whose fc3 bias is the identity"""
+    w, cfg = synth.make_weights('p2s_max_no_feat_stn')
+    blob, offs, mc = weights.build_blob(w, cfg)
+    for e in range(2):
+        o = offs.enc[e]
+        assert np.array_equal(blob[o.sfb3:o.sfb3 + 4096].reshape(64, 64), np.eye(64, dtype=np.float32))
+        assert not blob[o.sf3:o.sf3 + 256 * 4096].any() and not blob[o.s3:o.s3 + 128 * 1024].any()
 
 
 def test_qstn_weights_come_from_the_right_module():

@@ -150,6 +150,16 @@ def test_fixed_radius_gt_query_pass_matches_reference(golden_dir, meta):
     assert np.abs(sdf - ref).max() < 1e-5 and np.array_equal(sdf > 0, ref > 0)
 
 
+def test_no_feat_stn_prefix_matches_reference(golden_dir, fixture_cloud, meta):
+    """train --use_feat_stn 0 (PointNetfeat without the 64x64 feature transform, source/points_to_surf_model.py:151-153)"""
+    g = np.load(os.path.join(golden_dir, 'ref_rec_p2s_max_no_feat_stn_testset_grid32.npz'))
+    w, cfg = synth.make_weights('p2s_max_no_feat_stn')
+    assert not cfg['use_feat_stn'] and not any('stn2' in k for k in w)
+    q, sdf = O.infer_shape(w, cfg, fixture_cloud, 32, 3, O.LegacyMT19937(meta['seed_data']), query_range=(0, 64))
+    ref = g['rec_0'][:64]
+    assert np.abs(sdf - ref).max() < 1e-5 and np.array_equal(sdf > 0, ref > 0)
+
+
 def test_oracle_permutation_is_numpys():
     for seed, n in ((1, 2), (2, 301), (3, 1025), (4, 3643)):
         r = O.LegacyMT19937(seed)
