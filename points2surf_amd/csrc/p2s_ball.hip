@@ -21,7 +21,7 @@
 // (32-bit words, masked rejection), swap(a[i], a[j]).  How many words a query consumes depends on the words: the start
 // of query q+1 is known only behind query q.  ball_chain_kernel walks that chain with ONE wave, resolving 64 words at
 // a time: a word is accepted iff (w & mask) <= i - (accepted words before it), a fixed point reached from the left
-// and detected when an evaluation changes nothing (2-3 evaluations; model: tests/radius_model.py).  With every start
+// and detected when an evaluation changes nothing (1-2 evaluations; model: tests/radius_model.py).  With every start
 // known, ball_patch_kernel (one wave per query, all CUs) repeats the walk, applies the swaps to the query's hit list
 // and writes the patch.
 #include "p2s_common.h"
@@ -164,17 +164,18 @@ __global__ __launch_bounds__(1024) void ball_offsets_kernel(const int *__restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// the legacy shuffle, 64 W words at a time (one wave, W words per lane: word 64 u + lane of the block in slot u).
-// Word j of a block belongs to step i - A_j (A_j = accepted words before it): it is accepted iff
+// the legacy shuffle (one wave): 64 W words are fetched at a time (word 64 u + lane in slot u), the slots are resolved
+// one after the other.  Word j of a slot belongs to step i - A_j (A_j = accepted words before it): it is accepted iff
 //     (w_j & mask(i - A_j)) <= i - A_j,      mask(t) = smallest 2^b - 1 >= t,
 // a fixed point in the accept flags that is reached from the left (word 0 is right after one evaluation) and detected
 // when an evaluation changes nothing.  The first evaluation starts from the expected counts A_j ~ j (i + 1) / 2^bits.
-// Model with evaluation counts: tests/radius_model.py (n = 3047: 18 blocks, 2.2 evaluations each).
+// Model with evaluation counts: tests/radius_model.py (n = 3047: 70 slots, 1.2 evaluations each; resolving all 256
+// words at once needs 2.2 evaluations of FOUR slots each -- twice the instructions).
 // src.prepare(p) / src.word(p, u) = raw word p + 64 u + lane of the stream; put(flag, t, j): flagged lanes carry step
-// t (< steps) of this block, whose swap is (a[i - t], a[j]); flush(i, steps) closes the block.  Returns the position
+// t (< steps) of this slot, whose swap is (a[i - t], a[j]); flush(i, steps) closes the slot.  Returns the position
 // behind the shuffle.  i, pos and every count are wave-uniform and live in scalar registers as long as n does (callers
 // pass a readlane / scalar-load value); a lone wave issues ONE instruction, vector or scalar, per 4 cycles, so the
-// cost of a block is its instruction count: ~13 per 64 words and evaluation.
+// cost of the walk is its instruction count.
 // ---------------------------------------------------------------------------------------------------------------
 template <int W, class Src, class Put, class Flush>
 __device__ __forceinline__ long long ball_shuffle_walk(Src &&src, long long pos, int n, Put &&put, Flush &&flush) {
@@ -182,62 +183,41 @@ __device__ __forceinline__ long long ball_shuffle_walk(Src &&src, long long pos,
     int i = n - 1;
     while (i >= 1) {
         uint32_t w[W];
-        int v[W], before[W];
-        uint64_t b[W];
         src.prepare(pos);
-        const int bits = 32 - __builtin_clz((uint32_t)i);
+#pragma unroll
+        for (int u = 0; u < W; ++u) w[u] = src.word(pos, u);
+        long long p = pos;
 #pragma unroll
         for (int u = 0; u < W; ++u) {
-            w[u] = src.word(pos, u);
-            const int thr = i - (int)(((uint32_t)(64 * u + lane) * (uint32_t)(i + 1)) >> bits);       // expected step of this word
-            const uint32_t m = 0xffffffffu >> __builtin_clz((uint32_t)(thr > 1 ? thr : 1));
-            b[u] = __builtin_amdgcn_ballot_w64((int)(w[u] & m) <= thr);
-        }
-        for (;;) {
-            int base = 0;
-#pragma unroll
-            for (int u = 0; u < W; ++u) {                       // accepted words before this one: v_mbcnt_lo / _hi
-                before[u] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b[u], (uint32_t)base));
-                base += __popcll(b[u]);
-            }
-            uint64_t diff = 0;
-#pragma unroll
-            for (int u = 0; u < W; ++u) {
+            if (i < 1) break;                                   // the shuffle ended in an earlier slot
+            const int bits = 32 - __builtin_clz((uint32_t)i);
+            const int thr0 = i - (int)(((uint32_t)lane * (uint32_t)(i + 1)) >> bits);      // expected step of this word
+            const uint32_t m0 = 0xffffffffu >> __builtin_clz((uint32_t)(thr0 > 1 ? thr0 : 1));
+            uint64_t b = __builtin_amdgcn_ballot_w64((int)(w[u] & m0) <= thr0);
+            int before, v;
+            for (;;) {
                 // words behind the last step (thr < 1) may come out "accepted" (thr = 0: an even word): they lie behind
                 // the cut below and change nothing before it -- the flags are still a function of the flags to their left
-                const int thr = i - before[u];
+                before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                const int thr = i - before;
                 const uint32_t m = 0xffffffffu >> __builtin_clz((uint32_t)(thr > 1 ? thr : 1));
-                v[u] = (int)(w[u] & m);
-                const uint64_t nb = __builtin_amdgcn_ballot_w64(v[u] <= thr);
-                diff |= nb ^ b[u];
-                b[u] = nb;
+                v = (int)(w[u] & m);
+                const uint64_t nb = __builtin_amdgcn_ballot_w64(v <= thr);
+                if (nb == b) break;
+                b = nb;
             }
-            if (diff == 0) break;
-        }
-        int total = 0;
-#pragma unroll
-        for (int u = 0; u < W; ++u) total += __popcll(b[u]);
-        int consumed = 64 * W, steps = total;
-        if (total >= i) {                                       // the shuffle ends inside this block: stop behind step i
-            steps = i;
-            int base = 0;
-            bool found = false;
-#pragma unroll
-            for (int u = 0; u < W; ++u) {
-                const int cnt = __popcll(b[u]);
-                if (!found && base + cnt >= i) {
-                    const uint64_t hit = b[u] & __ballot(before[u] == i - 1);
-                    consumed = 64 * u + __ffsll((long long)hit);
-                    found = true;
-                }
-                base += cnt;
+            const int total = __popcll(b);
+            int consumed = 64, steps = total;
+            if (total >= i) {                                   // the shuffle ends inside this slot: stop behind step i
+                steps = i;
+                consumed = __ffsll((long long)(b & __builtin_amdgcn_ballot_w64(before == i - 1)));
             }
+            put(((b >> lane) & 1ull) != 0 && before < steps, before, v);
+            flush(i, steps);
+            p += consumed;
+            i -= steps;
         }
-#pragma unroll
-        for (int u = 0; u < W; ++u) put(((b[u] >> lane) & 1ull) != 0 && before[u] < steps, before[u], v[u]);
-        flush(i, steps);
-        pos += consumed;
-        i -= steps;
+        pos = p;
     }
     return pos;
 }
@@ -325,7 +305,7 @@ __global__ __launch_bounds__(64) void ball_patch_kernel(const uint32_t *__restri
                                                         float *__restrict__ patch_out, float *__restrict__ radius_out,
                                                         const long long *__restrict__ meta) {
     __shared__ int lds_list[BP_CAP];
-    __shared__ int jbuf[64 * BALL_W];
+    __shared__ int jbuf[64];
     const int w = blockIdx.x, lane = threadIdx.x;
     if (meta[1] != 0) return;
     const int c = count[w];

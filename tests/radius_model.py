@@ -5,7 +5,7 @@ tests/wchoice_model.py models the weighted sub-sample: the numpy-legacy shuffle 
     = RandomState.permutation(point_count)[:points_per_patch]
     = for i = n-1 .. 1:  j = rk_interval(i)  (32-bit words, masked rejection);  swap(a[i], a[j])
 
-resolved 256 raw words at a time (the kernels' block, four words per lane): word j is accepted iff
+resolved 64 raw words at a time (the kernels fetch 256 and resolve the four slots one after the other): word j is accepted iff
 (w_j & mask(i - A_j)) <= i - A_j with A_j = accepted words before it -- a fixed point that is reached from the left (word 0
 is right after one evaluation, word j after j + 1 at the latest) and detected when an evaluation changes nothing."""
 import numpy as np
@@ -25,7 +25,7 @@ def _smear_v(x):
     return x
 
 
-def walk_blocks(words, pos, n, lanes=256, guess=True):
+def walk_blocks(words, pos, n, lanes=64, guess=True):
     """-> (position after the shuffle of n elements, [(i, j)] in execution order, blocks, evaluations).
     Word j of a block belongs to step i - A_j: its mask and its threshold follow from the accepted words before it, so
     a block runs across the powers of two and only the end of the shuffle cuts it short."""
@@ -64,7 +64,7 @@ def walk_blocks(words, pos, n, lanes=256, guess=True):
     return pos, swaps, blocks, evals
 
 
-def permutation(words, pos, n, lanes=256):
+def permutation(words, pos, n, lanes=64):
     pos2, swaps, _, _ = walk_blocks(words, pos, n, lanes=lanes)
     a = np.arange(n, dtype=np.int64)
     for i, j in swaps:

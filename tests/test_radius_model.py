@@ -24,4 +24,4 @@ def test_fixed_point_needs_few_evaluations():
     rs = np.random.RandomState(5)
     words = raw_words(rs, 20000)
     _, _, blocks, evals = walk_blocks(words, 0, 5903)
-    assert blocks <= 36 and evals / blocks < 3.0
+    assert blocks <= 140 and evals / blocks < 1.5
