@@ -197,7 +197,8 @@ def golden_check(engine, parity, model, w, cfg, shapes, res, sdfs, tol, bf16):
         rec['max_abs_diff_unmasked'] = max(rec['max_abs_diff_unmasked'], unmasked)
         rec['sign_flips'] += int(fl.size)
         not_ties = int(fl.size)
-        if 0 < fl.size <= 32 and not bf16:       # ~1 query in 400,000 has a sign logit within fp32 noise of zero
+        if 0 < fl.size <= 32 and bf16 in (0, 3, 4):   # ~1 query in 400,000 has a sign logit within fp32 noise of zero
+            # (split-precision encoders 3 / 4 claim fp32 accuracy: their flips are classified the same way)
             not_ties = 0
             # position a stream at this shape's first draw: skip the shapes before it
             for j in fl:
