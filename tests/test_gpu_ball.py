@@ -73,7 +73,9 @@ def test_ball_count_is_scipys(cloud_i, radius):
     cloud.close()
 
 
-@pytest.mark.parametrize('radius,k,nq', [(0.05, 300, 96), (0.1, 300, 96), (0.2, 300, 40), (0.1, 75, 64), (0.3, 1200, 24)])
+@pytest.mark.parametrize('radius,k,nq', [(0.05, 300, 96), (0.1, 300, 96), (0.2, 300, 40), (0.1, 75, 64), (0.3, 1200, 24),
+                                         (2.0, 300, 6),        # the whole cloud in every ball: lists of 34,693, shuffled in place
+                                         (1e-4, 300, 8)])      # (almost) empty balls: padding only
 def test_ball_patch_matches_scipy_and_numpy_choice(fixture_cloud, radius, k, nq):
     import torch
     from points2surf_amd import engine
@@ -82,6 +84,7 @@ def test_ball_patch_matches_scipy_and_numpy_choice(fixture_cloud, radius, k, nq)
     q = _queries(fixture_cloud, nq, 7)
     ids_r, patch_r, counts, _, rs = _reference_patches(99, fixture_cloud, tree, q, radius, k)
     assert (counts > k).any() or radius < 0.1
+    assert radius != 2.0 or counts.max() == fixture_cloud.shape[0]
     rng = engine.Rng(99)
     # ragged calls: the stream continues across them
     parts = [engine.ball_patch(cloud, rng, torch.from_numpy(q[a:b]).cuda(), radius, k) for a, b in ((0, 3), (3, 40), (40, nq)) if b > a]
