@@ -48,17 +48,21 @@ def main():
         return int(out.shape[0]), nv, nf
 
     shape(clouds[0])                                           # warm-up (allocations)
+    shape(clouds[1 % len(clouds)])
     torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
     t0 = time.time()
     res = [shape(c) for c in clouds]
     torch.cuda.synchronize()
     dt = time.time() - t0
+    free1 = torch.cuda.mem_get_info()[0]
     nq = sum(r[0] for r in res)
     print(json.dumps({'model': args.model, 'encoder_bf16': args.encoder, 'res': args.res, 'shapes': args.shapes,
                       'mesh_stage': bool(args.mesh), 'queries': nq, 'seconds': dt, 'queries_per_s': nq / dt,
                       'shapes_per_hour': args.shapes / dt * 3600.0,
                       'queries_per_shape_min_max': [min(r[0] for r in res), max(r[0] for r in res)],
-                      'vertices_faces_total': [sum(r[1] for r in res), sum(r[2] for r in res)]}))
+                      'vertices_faces_total': [sum(r[1] for r in res), sum(r[2] for r in res)],
+                      'device_memory_growth_MB_over_the_run': (free0 - free1) / 1e6}))
 
 
 if __name__ == '__main__':
