@@ -197,3 +197,29 @@ def test_radius_model_is_invariant_to_chunking_and_query_ranges(fixture_cloud):
     assert np.array_equal(c.cpu().numpy(), a[half:])
     m.close()
     cloud.close()
+
+
+@pytest.mark.parametrize('n,seed', [(5, 0), (63, 1), (64, 2), (65, 3), (999, 4), (1001, 5), (2500, 6), (4097, 7)])
+def test_ball_patch_on_odd_clouds(n, seed):
+    """clouds around the wave and leaf sizes, with duplicated points and a rounded coordinate (ties in the tree build),
+    k larger and smaller than the balls, queries on points and far away"""
+    import torch
+    from points2surf_amd import engine
+    r = np.random.RandomState(seed)
+    pts = (r.rand(n, 3).astype(np.float32) - 0.5)
+    pts[::7] = pts[0]
+    pts[:, 1] = np.round(pts[:, 1], 2)
+    tree = spatial.cKDTree(pts, 1000)
+    cloud = engine.Cloud(pts)
+    q = np.concatenate([pts[r.randint(0, n, 20)], (r.rand(12, 3) - 0.5).astype(np.float32), np.float32([[4, 4, 4]])]).astype(np.float32)
+    for radius, k in ((0.3, 16), (0.6, 300), (2.0, 50)):
+        ids_r, patch_r, counts, _, rs = _reference_patches(seed + 100, pts, tree, q, radius, k)
+        rng = engine.Rng(seed + 100)
+        got = engine.ball_count(cloud, torch.from_numpy(q).cuda(), radius).cpu().numpy()
+        assert np.array_equal(got, counts)
+        ids, patch, _, _ = engine.ball_patch(cloud, rng, torch.from_numpy(q).cuda(), radius, k)
+        rng.check()
+        assert np.array_equal(ids.cpu().numpy(), ids_r), (n, radius, k)
+        assert np.array_equal(patch.cpu().numpy().view(np.uint32), patch_r.view(np.uint32))
+        assert _same_generator(rng, rs)
+    cloud.close()
