@@ -188,6 +188,7 @@ int p2s_model_destroy(p2s_model_t m) {
         if (ev) (void)hipEventDestroy(ev);
     if (m->aux) (void)hipStreamDestroy(m->aux);
     if (m->prep) (void)hipStreamDestroy(m->prep);
+    if (m->ball) (void)hipStreamDestroy(m->ball);
     delete m;
     return P2S_OK;
 }

@@ -16,6 +16,7 @@ struct PipeBuffers {
     hipEvent_t freed[2] = {};       // the gather has read the sub-sample ids of the buffer (prep stream)
     hipEvent_t prepped[2] = {};     // kNN patch + gathered sub-sample of the buffer are complete (prep stream)
     hipEvent_t done[2] = {};        // encoders finished reading the buffer (main stream)
+    hipEvent_t ball_ready[2] = {};  // fixed-radius patch of the buffer finished (ball stream)
     hipEvent_t grid = nullptr;
     int32_t *knn_ids[2] = {};       // [C][k]   } only for clouds with fewer points than the sub-sample
     int32_t *perm[2] = {};          // [C][N]   } (shape.pts is shuffled in place by every query)
@@ -47,6 +48,8 @@ struct p2s_model_s {
     // auxiliary stream: the data path (kNN, sub-sample) of chunk i+1, i+2 overlaps the encoders of chunk i
     hipStream_t aux = nullptr;     // high-priority stream of the sub-sample generator
     hipStream_t prep = nullptr;    // high-priority stream of kNN + gather of chunk i+1 (runs under the encoders of chunk i)
+    hipStream_t ball = nullptr;    // fixed-radius models: the serial walk along the first generator's stream (one wave) -- its own
+                                   // stream so that it runs beside the sub-sample kernels of the auxiliary stream, not behind them
     bool overlap = true;
     PipeBuffers pipe;
     int fault_chunk = -1;          // test hook (p2s_debug_fault_chunk): fail with P2S_EHIP before this chunk

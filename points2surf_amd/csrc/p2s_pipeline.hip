@@ -32,6 +32,7 @@ void p2s_pipe_free(p2s_model_s *m) {
         if (b.freed[i]) (void)hipEventDestroy(b.freed[i]);
         if (b.prepped[i]) (void)hipEventDestroy(b.prepped[i]);
         if (b.done[i]) (void)hipEventDestroy(b.done[i]);
+        if (b.ball_ready[i]) (void)hipEventDestroy(b.ball_ready[i]);
     }
     if (b.grid) (void)hipEventDestroy(b.grid);
     b = PipeBuffers();
@@ -56,7 +57,8 @@ int pipe_reserve(p2s_model_s *m, int C, int k, int n, bool small) {
              hipEventCreateWithFlags(&b.ready[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&b.freed[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&b.prepped[i], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&b.done[i], hipEventDisableTiming) == hipSuccess;
+             hipEventCreateWithFlags(&b.done[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&b.ball_ready[i], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) {
         (void)hipGetLastError();
@@ -238,6 +240,15 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->prep, hipStreamNonBlocking, hi));
     }
     hipStream_t sp = prep_overlap ? m->prep : s;
+    // fixed radius: the walk along the first generator's stream is ONE wave for tens of ms per chunk; on the auxiliary
+    // stream it would sit in front of (or behind) the sub-sample's all-CU kernels, on its own stream it runs beside them
+    // (P2S_BALL_STREAM=0: development / A-B, everything on the auxiliary stream)
+    const bool ball_own = m->cfg.patch_radius > 0.0 && m->overlap && !(getenv("P2S_BALL_STREAM") && atoi(getenv("P2S_BALL_STREAM")) == 0);
+    if (ball_own && !m->ball) {
+        int lo = 0, hi = 0;
+        P2S_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->ball, hipStreamNonBlocking, hi));
+    }
     p2s_cloud_note_stream(c, s);
     p2s_cloud_note_stream(c, sa);
     p2s_cloud_note_stream(c, sp);
@@ -263,7 +274,8 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
     auto fail = [&](int code) {
         const hipError_t e1 = hipStreamSynchronize(s);
         hipError_t e2 = (sa != s) ? hipStreamSynchronize(sa) : hipSuccess;
-        const hipError_t e3 = (sp != s) ? hipStreamSynchronize(sp) : hipSuccess;
+        hipError_t e3 = (sp != s) ? hipStreamSynchronize(sp) : hipSuccess;
+        if (e3 == hipSuccess && m->ball) e3 = hipStreamSynchronize(m->ball);
         if (e2 == hipSuccess) e2 = e3;
         if (code == P2S_OK && (e1 != hipSuccess || e2 != hipSuccess)) {
             p2s_set_error("p2s pipeline: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
@@ -279,10 +291,13 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
             return fail(P2S_EHIP);                                                                         \
         }                                                                                                  \
     } while (0)
+    hipStream_t sbl = ball_own ? m->ball : sa;        // stream of the fixed-radius patch work
+    if (ball_own) p2s_cloud_note_stream(c, sbl);
     if (sa != s || sp != s) {
         PIPE_HIP(hipEventRecord(b.grid, s));
         if (sa != s) PIPE_HIP(hipStreamWaitEvent(sa, b.grid, 0));
         if (sp != s) PIPE_HIP(hipStreamWaitEvent(sp, b.grid, 0));
+        if (sbl != sa) PIPE_HIP(hipStreamWaitEvent(sbl, b.grid, 0));
     }
 
     // fixed radius: the number of points in every query's ball, on the host too (batch sizes and the random words each
@@ -294,7 +309,7 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         if ((rc = p2s_ball_counts_to_host(r_patch, c, q_all + (size_t)q_begin * 3, nq, ball_r, &ball_cd, &ball_ch, s))) return fail(rc);
         p2s_prof_span(m, ST_KNN, eb0, p2s_prof_mark(m, s));
     }
-    const bool use_done = sp != s || (ball && sa != s);
+    const bool use_done = sp != s || (ball && sbl != s);
 
     const int64_t nchunks = (nq + C - 1) / C;
     auto produce = [&](int64_t ci) -> int {       // sub-sample ids of chunk ci on the aux stream
@@ -313,17 +328,18 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
                            : p2s_subsample_uniform(r, c, cur, n, b.sub_ids[bi], nullptr, sa);
         if (rc2) return fail(rc2);
         p2s_prof_span(m, ST_SUB, e0, p2s_prof_mark(m, sa));
+        if (sa != s) PIPE_HIP(hipEventRecord(b.ready[bi], sa));
         if (ball) {
             // patch choice (+ the rotation of the GT-query pass): a serial walk along the first generator's stream, under
             // the encoders of the chunks before; the encoders of chunk ci - nbuf read the patch buffer it fills
-            if (ci >= nbuf && sa != s) PIPE_HIP(hipStreamWaitEvent(sa, b.done[bi], 0));
-            const int eb0 = p2s_prof_mark(m, sa);
+            if (ci >= nbuf && sbl != s) PIPE_HIP(hipStreamWaitEvent(sbl, b.done[bi], 0));
+            const int eb0 = p2s_prof_mark(m, sbl);
             rc2 = p2s_ball_patch_counted(r_patch, c, q_all + (size_t)q0 * 3, ball_cd + (q0 - q_begin), ball_ch + (q0 - q_begin), cur,
-                                         ball_r, k, r_rot ? 6 : 0, nullptr, b.patch[bi], b.radius[bi], r_rot ? b.rot[bi] : nullptr, sa);
+                                         ball_r, k, r_rot ? 6 : 0, nullptr, b.patch[bi], b.radius[bi], r_rot ? b.rot[bi] : nullptr, sbl);
             if (rc2) return fail(rc2);
-            p2s_prof_span(m, ST_KNN, eb0, p2s_prof_mark(m, sa));
+            p2s_prof_span(m, ST_KNN, eb0, p2s_prof_mark(m, sbl));
+            if (sbl != s) PIPE_HIP(hipEventRecord(b.ball_ready[bi], sbl));
         }
-        if (sa != s) PIPE_HIP(hipEventRecord(b.ready[bi], sa));
         return P2S_OK;
     };
 
@@ -344,6 +360,7 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
             p2s_prof_span(m, ST_KNN, ek0, p2s_prof_mark(m, sp));
         }
         if (sa != sp) PIPE_HIP(hipStreamWaitEvent(sp, b.ready[bi], 0));
+        if (ball && sbl != sp) PIPE_HIP(hipStreamWaitEvent(sp, b.ball_ready[bi], 0));
         if (small) {       // the patch is gathered from the array as the queries before this one left it
             rc2 = p2s_patch_from_ids(c, b.knn_ids[bi], b.perm[bi], qc, cur, k, b.patch[bi], b.radius[bi], sp);
             if (rc2) return fail(rc2);
