@@ -1,5 +1,5 @@
 """Fixed-radius models on the abc_minimal test shape: stand-alone cost of the patch stages (no encoders running) and
-whole-shape throughput at 128^3.    python tools/ball_bench.py [--no-models]"""
+whole-shape throughput at 128^3.    python tools/ball_bench.py [--no-models | --only-models]"""
 import os
 import sys
 import time
@@ -28,7 +28,7 @@ def timed(fn, reps=2):
 cloud = engine.Cloud(pts)
 q = cloud.query_grid(128, 3)
 n = int(q.shape[0])
-for radius in (0.05, 0.1, 0.2):
+for radius in (() if '--only-models' in sys.argv else (0.05, 0.1, 0.2)):
     rng = engine.Rng(1)
     c = engine.ball_count(cloud, q, radius)
     t_count = timed(lambda: engine.ball_count(cloud, q, radius))
