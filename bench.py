@@ -224,7 +224,10 @@ def golden_check(engine, parity, model, w, cfg, shapes, res, sdfs, tol, bf16):
         srec['sign_flips_not_ties'] = not_ties
         rec['sign_flips_not_ties'] += not_ties
         rec['shapes'].append(srec)
-        if cmp_['max_abs_dsdf'] > tol or (not bf16 and not_ties):
+        # fp32 and the split-precision encoders 3 / 4 (advertised as fp32-accurate): any flipped sign that is not a
+        # verified tie fails the check -- more than 32 flips are never classified, so they fail as well; plain bf16 /
+        # two bf16 pieces (modes 1 / 2, outside the contract) are reported only
+        if cmp_['max_abs_dsdf'] > tol or (bf16 in (0, 3, 4) and not_ties):
             ok = False
     return rec, ok
 
@@ -465,7 +468,8 @@ def main():
                         'chain_ms': cnt['ms_chain_stn'] + cnt['ms_chain_main'], 'chain_launches': int(cnt['launches_chain'])}
                 if os.path.isfile(gfile):
                     ref2 = np.load(gfile)['rec_0']
-                    rec2, ok2 = golden_check(engine, parity, m2, w2, cfg2, [(FIXTURE_SHAPE, fixture, ref2)], args.res, [s2], 1e-4, 0)
+                    rec2, ok2 = golden_check(engine, parity, m2, w2, cfg2, [(FIXTURE_SHAPE, fixture, ref2)], args.res, [s2], 1e-4,
+                                              extra.get('encoder_bf16', 0))
                     rec2['file'] = os.path.relpath(gfile, REPO)
                     srec['vs_reference_golden'] = {k: rec2[k] for k in ('file', 'queries', 'max_abs_dsdf', 'max_abs_diff_unmasked',
                                                                         'sign_flips', 'sign_flips_not_ties', 'flipped')}

@@ -10,8 +10,9 @@ own code: this module loads the reference's ``source/sdf.py`` from the other ``s
 ``visualize_query_points``) are this module's own and need neither the reference checkout nor scikit-image / trimesh.
 No CPU fallback: without a GPU they raise.
 
-Differences from the reference, all declared in INTEGRATION.md: the iso-surface is marching cubes with the asymptotic
-decider (scikit-image's Lewiner tables are unavailable offline: vertex / face counts are not pinned to skimage's);
+The iso-surface is scikit-image's ``marching_cubes_lewiner`` itself, re-implemented for the device and pinned to
+scikit-image 0.18.3 (identical vertices and oriented triangles on the reference's volumes 32^3 ... 512^3,
+tests/test_gpu_mesh.py).  Differences from the reference, all declared in INTEGRATION.md:
 ``implicit_surface_to_mesh_directory`` runs the shapes serially in this process whatever ``num_processes`` says (a HIP
 context cannot be used from the forked ``multiprocessing.Pool`` workers of source/base/utils_mp.py:33-35).
 """

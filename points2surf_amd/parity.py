@@ -7,7 +7,8 @@ queries are compared by magnitude and reported separately; whether a flip really
 caller from the device's own sign logit (engine.query_logits)."""
 import numpy as np
 
-TIE_LOGIT = 5e-5       # |sign logit| below which a flipped sign counts as an fp32 tie
+TIE_LOGIT = 2e-5       # |sign logit| below which a flipped sign counts as an fp32 tie (largest tie observed: 8e-6;
+                       # logit accuracy of the fp32 path ~1.5e-5)
 
 
 def compare_sdf(sdf, ref):
