@@ -249,7 +249,7 @@ def main():
     if world > torch.cuda.device_count() and not share:
         raise SystemExit('bench.py: %d ranks, %d device(s)' % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
-    if world > 1:
+    if world > 1 or os.environ.get('P2S_DIST_FORCE'):
         if share and (args.backend or 'nccl') == 'nccl':
             raise SystemExit('P2S_BENCH_SHARE_GPU needs --backend gloo (RCCL refuses two ranks on one device)')
         if share:        # init by hand: sharding.init_process_group binds LOCAL_RANK to its own device
@@ -293,50 +293,75 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # dataset = world x (warmup + steps) shapes; shape i -> rank i mod world; all ranks work on the same cloud in a step
+    # dataset = world x (warmup + steps) shapes in one list; shape g = cloud (g // world) mod 3 (every round of ``world``
+    # shapes is one cloud: weak scaling).  Owner of a shape: sharding.assign_shapes (LPT over the query counts, the
+    # drop-in's policy), separately for the warm-up block and the timed block so that every rank has timed work.
     ev = {}
+    n_rounds = args.warmup + args.steps
+    cloud_of = [(g // world) % len(shapes) for g in range(n_rounds * world)]
+    q_of_cloud = []
+    for _, pts, _ in shapes:                       # untimed: the query count of each distinct cloud
+        c = engine.Cloud(pts)
+        q_of_cloud.append(c.count_queries(args.res, EPSILON))
+        c.close()
+    owner = []
+    for lo, hi in ((0, args.warmup * world), (args.warmup * world, n_rounds * world)):
+        _, own = sharding.assign_shapes([q_of_cloud[cloud_of[g]] for g in range(lo, hi)], world)
+        owner += own
+    handoff = None
+    if world > 1 and args.rng_mode == 'dataset' and sharding.stream_handoff_enabled():
+        handoff = sharding.StreamHandoff('bench', owner, rank=rank)
+    stream_mode = ('per_shape' if args.rng_mode == 'per_shape' else
+                   ('dataset/handoff' if handoff is not None else ('dataset/replicate' if world > 1 else 'dataset')))
 
-    def run_step(step, timed):
-        """all shapes of dataset round ``step``: mine is inferred, the others' draws are skipped (exact mode)"""
-        out = dev = None
-        pts = shapes[step % len(shapes)][1]
-        for r in range(world):
-            shape_ind = step * world + r
+    def run_block(lo, hi, timed):
+        """shapes lo..hi-1 of the dataset in order: mine are inferred (complete shapes, host to host); returns the list
+        of (host SDF, device SDF)"""
+        outs = []
+        for g in range(lo, hi):
+            pts = shapes[cloud_of[g]][1]
+            if owner[g] != rank:
+                if args.rng_mode == 'dataset' and handoff is None:
+                    other = engine.Cloud(pts)        # replicate mode: index + voxelise the shape to consume its draws
+                    sharding.skip_shape_stream(other, rng, cfg, args.res, EPSILON, n_sub)
+                    other.close()
+                continue
             if args.rng_mode == 'per_shape':
-                if r != rank:
-                    continue
-                key = np.random.RandomState((SEED_DATA + shape_ind) & 0xffffffff).get_state()[1]   # init_genrand
+                key = np.random.RandomState((SEED_DATA + g) & 0xffffffff).get_state()[1]   # init_genrand
                 rng.set_state(key, 624)
-            if r == rank:
-                out, dev = complete_shape(engine, model, pts, rng, args.res, args.chunk, ev if timed else None)
-            else:
-                other = engine.Cloud(pts)            # a rank has to index + voxelise a shape to know its draw count
-                sharding.skip_shape_stream(other, rng, cfg, args.res, EPSILON, n_sub)
-                other.close()
-        return out, dev
+            elif handoff is not None:
+                handoff.begin(g, [rng])
+                if handoff.must_publish(g):
+                    def advance():
+                        c2 = engine.Cloud(pts)
+                        sharding.skip_shape_stream(c2, rng, cfg, args.res, EPSILON, n_sub)
+                        c2.close()
+                    handoff.publish_after(g, [rng], advance)
+            outs.append(complete_shape(engine, model, pts, rng, args.res, args.chunk, ev if timed else None) + (cloud_of[g],))
+            if timed:
+                for k, v in model.counters().items():        # per pipeline call (reset at its start)
+                    acc[k] = acc.get(k, 0) + v
+            if handoff is not None:
+                handoff.done(g)
+        return outs
 
-    sdf = None
-    for s in range(args.warmup):
-        sdf, _ = run_step(s, False)
+    acc = {}
+    run_block(0, args.warmup * world, False)
     barrier()
     t0 = time.time()
-    n_queries = 0
-    acc = {}
+    mine_timed = run_block(args.warmup * world, n_rounds * world, True)
+    n_queries = sum(int(o[0].shape[0]) for o in mine_timed)
+    per_shape_q = {shapes[ci][0][:8]: q_of_cloud[ci] for ci in sorted(set(cloud_of[args.warmup * world:]))}
     gathered = 0
-    per_shape_q = {}
-    for s in range(args.steps):
-        sdf, sdf_dev = run_step(args.warmup + s, True)
-        n_queries += int(sdf.shape[0])
-        per_shape_q[shapes[(args.warmup + s) % len(shapes)][0][:8]] = int(sdf.shape[0])
-        for k, v in model.counters().items():
-            acc[k] = acc.get(k, 0) + v
-        if world > 1:
-            # final gather of the variable-length per-shape SDF to rank 0 (RCCL over xGMI): the only exchange
-            parts = sharding.gather_variable(sdf_dev, dst=0)
-            if rank == 0:
-                gathered += sum(int(p.shape[0]) for p in parts)
+    if sharding.is_initialized():
+        # the final variable-length gather of the SDF values to rank 0 (RCCL over xGMI): the path's only exchange
+        mine_dev = torch.cat([o[1] for o in mine_timed]) if mine_timed else torch.empty((0,), dtype=torch.float32, device='cuda')
+        parts = sharding.gather_variable(mine_dev, dst=0)
+        if rank == 0:
+            gathered = sum(int(p_.shape[0]) for p_ in parts)
     barrier()
     dt = time.time() - t0
+    sdf = mine_timed[-1][0] if mine_timed else None
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -349,6 +374,8 @@ def main():
             raise SystemExit('gather returned %d SDF values, ranks produced %d' % (gathered, total_queries))
     else:
         total_queries = n_queries
+        if sharding.is_initialized() and gathered != total_queries:        # P2S_DIST_FORCE: the group at world size 1
+            raise SystemExit('gather returned %d SDF values, the rank produced %d' % (gathered, total_queries))
 
     if rank == 0:
         value = total_queries / dt
@@ -393,7 +420,11 @@ def main():
                                    'available offline)' % workload,
                        'queries_per_shape': per_shape_q,
                        'parallelism': 'shape-sharded x%d' % world + (' (REHEARSAL: all ranks share one GPU, gloo)' if share else ''),
-                       'rng_mode': args.rng_mode,
+                       'rng_mode': args.rng_mode, 'stream_mode': stream_mode,
+                       'assignment': 'sharding.assign_shapes: LPT over query counts',
+                       'collective': (dist.get_backend() + ' (world %d): one all_gather of sizes + one padded gather at the '
+                                      'end of the timed region' % dist.get_world_size()) if sharding.is_initialized() else None,
+                       'stream_wait_s_rank0': None if handoff is None else handoff.waited_s,
                        'shapes_per_hour': world * args.steps / dt * 3600.0,
                        'queries_per_s_per_gpu': value / world},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
@@ -494,7 +525,7 @@ def main():
             out['cpu_baseline'] = None
         out['self_check'] = check
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharding.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

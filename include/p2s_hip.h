@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define P2S_ABI_VERSION 3
+#define P2S_ABI_VERSION 4
 
 #define P2S_OK            0
 #define P2S_EINVAL       -1   /* bad argument / unsupported configuration */
@@ -356,6 +356,20 @@ int p2s_points_remove_close(const float *pts_dev, int64_t m, double radius, int6
  * Hausdorff distance, *sum_host = the Chamfer term; dist_out_dev [n] float64 may be NULL.  Synchronises. */
 int p2s_nn_distance_stats(p2s_cloud_t target, const float *query_dev, int64_t n, double *dist_out_dev, double *max_host,
                           double *sum_host, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * "next" row: the per-shape text / debug files of save_evaluation and implicit_surface_to_mesh, written
+ * by native HOST code (no device is touched; all pointers are host pointers).  Byte-identical to what the reference's
+ * numpy / Python calls write.
+ * p2s_write_txt_f32:       np.savetxt(path, sdf) (reference source/points_to_surf_eval.py:210): '%.18e' per line.
+ * p2s_write_query_vis_ply: sdf.visualize_query_points (source/sdf.py:269-285) in the drop-in's PLY layout
+ *                          (points2surf_amd/ply.py): float32 xyz + uchar rgba per query point.
+ * p2s_write_coff_samples:  mesh_io.write_off(file, query_pts_ms, [], colors_vertex=...) with the colours of
+ *                          source/sdf.py:203-209 (source/base/mesh_io.py:75-140): str() of every number.
+ * ------------------------------------------------------------------------------------------ */
+int p2s_write_txt_f32(const char *path, const float *values_host, int64_t n);
+int p2s_write_query_vis_ply(const char *path, const float *query_host, const float *dist_host, int64_t n);
+int p2s_write_coff_samples(const char *path, const float *query_host, const float *dist_host, int64_t n);
 
 /* per-stage counters of the last p2s_encode_decode / p2s_infer_shape on this model
  * (HIP-event milliseconds on the launch stream; valid after the stream is synchronised) */

@@ -83,6 +83,9 @@ PROTOTYPES = {
                                       ctypes.POINTER(ctypes.c_double), c_void_p]),
     'p2s_set_profiling': (c_int, [c_void_p, c_int]),
     'p2s_get_counters': (c_int, [c_void_p, ctypes.POINTER(Counters)]),
+    'p2s_write_txt_f32': (c_int, [ctypes.c_char_p, c_void_p, c_int64]),
+    'p2s_write_query_vis_ply': (c_int, [ctypes.c_char_p, c_void_p, c_void_p, c_int64]),
+    'p2s_write_coff_samples': (c_int, [ctypes.c_char_p, c_void_p, c_void_p, c_int64]),
 }
 
 

@@ -5,6 +5,13 @@ drop-in's ``source`` package in front of the reference's.
     python -m points2surf_amd.dropin.run full_eval.py --indir datasets --outdir results ...
     torchrun --nproc-per-node 8 -m points2surf_amd.dropin.run full_eval.py ...
 
+**All visible GPUs by default.**  The reference wraps its model in ``torch.nn.DataParallel`` without ``device_ids``
+(source/points_to_surf_eval.py:168): ``python full_eval.py`` on an 8-GPU node uses all 8.  The launcher keeps that:
+started WITHOUT a torchrun environment (no ``WORLD_SIZE``) on a node with more than one visible device it re-executes
+itself under ``torch.distributed.run`` with one rank per device (127.0.0.1 rendezvous, a free port); the ranks shard the
+shapes (points2surf_amd/sharding.py).  ``P2S_GPUS=<n>`` picks the number of ranks (``P2S_GPUS=1``: stay in this
+process; more than the visible devices is an error), ``HIP_VISIBLE_DEVICES`` the devices.
+
 Why a launcher: ``python full_eval.py`` puts the script's directory at ``sys.path[0]``, i.e. BEFORE anything on
 ``PYTHONPATH``, so ``from source import points_to_surf_eval`` would find the reference's own ``source`` package first.
 Here ``sys.path`` becomes [drop-in, script directory, ...] and the script runs under ``runpy`` as ``__main__`` --
@@ -15,6 +22,29 @@ import runpy
 import sys
 
 
+def ranks_to_spawn(environ=None, device_count=None):
+    """how many ranks the launcher starts by itself: 0 = run in this process.  Under torchrun (WORLD_SIZE set) never;
+    otherwise one per visible device, or P2S_GPUS of them."""
+    environ = os.environ if environ is None else environ
+    if 'WORLD_SIZE' in environ:
+        return 0
+    want = environ.get('P2S_GPUS')
+    if want is not None and int(want) <= 1:
+        return 0
+    if device_count is None:
+        import torch
+        device_count = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    n = device_count if want is None else int(want)
+    if n > device_count:
+        raise SystemExit('points2surf_amd.dropin.run: P2S_GPUS=%d but %d device(s) visible' % (n, device_count))
+    return n if n > 1 else 0
+
+
+def spawn_command(n, argv, port):
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+            '--master-addr', '127.0.0.1', '--master-port', str(port), '-m', 'points2surf_amd.dropin.run'] + list(argv)
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     if not argv or argv[0] in ('-h', '--help'):
@@ -23,6 +53,19 @@ def main(argv=None):
     script = os.path.abspath(argv[0])
     if not os.path.isfile(script):
         raise SystemExit('points2surf_amd.dropin.run: no such script: %s' % argv[0])
+    n = ranks_to_spawn()
+    if n:
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        repo_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        env['PYTHONPATH'] = repo_root + (os.pathsep + env['PYTHONPATH'] if env.get('PYTHONPATH') else '')
+        print('points2surf_amd.dropin.run: %d visible devices -> %d ranks (P2S_GPUS=1 to stay in one process)' % (n, n),
+              flush=True)
+        return subprocess.call(spawn_command(n, [script] + argv[1:], port), env=env)
     here = os.path.dirname(os.path.abspath(__file__))
     repo = os.path.dirname(os.path.dirname(here))
     for p in (os.path.dirname(script), repo, here):

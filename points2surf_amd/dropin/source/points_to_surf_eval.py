@@ -18,9 +18,10 @@ Deliberate differences (documented in INTEGRATION.md):
   * the GT-query pass (``reconstruction=False``: query points from ``05_query_pts``, one random rotation per query
     from the dataset's first RandomState, source/data_loader.py:365-393) runs on the device too (p2s_infer_queries);
     ``full_eval.py`` calls it first whenever ``<indir>/05_query_dist`` exists (:31-33);
-  * with torchrun (WORLD_SIZE > 1) shapes are sharded over ranks (one process per GPU).  By default every
-    rank also consumes the sub-sample draws of the shapes it does not own, so results stay identical to the
-    single-process run (dataset-wide stream); ``P2S_RNG_MODE=per_shape`` instead seeds shape i with
+  * with torchrun (WORLD_SIZE > 1; ``python -m points2surf_amd.dropin.run`` starts one rank per visible GPU by
+    itself) shapes are sharded over ranks (one process per GPU, LPT by query count).  By default the results stay
+    identical to the single-process run (dataset-wide stream): the owner of a shape hands the generator state to the
+    owner of the next one (sharding.StreamHandoff); ``P2S_RNG_MODE=per_shape`` instead seeds shape i with
     ``seed + i`` (no cross-shape dependency, scales freely, but differs from the reference from the second
     shape on -- a declared deviation).
 """
@@ -36,6 +37,9 @@ import torch
 from points2surf_amd import engine as _engine
 from points2surf_amd import sharding as _sharding
 from points2surf_amd.model_spec import strip_module_prefix
+
+
+_HANDOFF_SEQ = 0
 
 
 def parse_arguments(args=None):
@@ -144,25 +148,19 @@ def _infer_one_shape(model, cloud, rng_dev, res, eps, chunk, rng_patch=None):
 
 def _visualize_query_points(query_pts_ms, query_dist_ms, file_out):
     """sdf.visualize_query_points (reference source/sdf.py:269-285): red = negative, green = positive distance,
-    brightness = |d| / max|d|; written as a coloured point-cloud PLY"""
-    from points2surf_amd import ply
-    d = np.asarray(query_dist_ms)
-    d_abs = np.abs(d)
-    with np.errstate(invalid='ignore', divide='ignore'):
-        d_norm = d_abs / d_abs.max()
-    col = np.zeros((d.shape[0], 3))
-    neg, pos = d < 0.0, d > 0.0
-    col[neg, 0] = 0.5 + 0.5 * d_norm[neg]
-    col[pos, 1] = 0.5 + 0.5 * d_norm[pos]
-    os.makedirs(os.path.dirname(file_out), exist_ok=True)
-    ply.write_ply(file_out, query_pts_ms, vertex_colors=col)
+    brightness = |d| / max|d|; written as a coloured point-cloud PLY by the native host writer (p2s_write_query_vis_ply)"""
+    from points2surf_amd import writers
+    writers.query_vis_ply(file_out, query_pts_ms, query_dist_ms)
 
 
 def _save_shape(model_out_dir, shape_name, sdf_np, q_np, reconstruction=True):
-    """files of save_evaluation (+ save_reconstruction_data in reconstruction mode), reference :199-222, :263-282"""
+    """files of save_evaluation (+ save_reconstruction_data in reconstruction mode), reference :199-222, :263-282.  The
+    text file is np.savetxt's bytes from the native host writer (p2s_write_txt_f32: the GIL is released, the writer
+    threads run beside the inference loop)"""
+    from points2surf_amd import writers
     os.makedirs(os.path.join(model_out_dir, 'eval'), exist_ok=True)
     np.save(os.path.join(model_out_dir, 'eval', shape_name + '.xyz.npy'), sdf_np)
-    np.savetxt(os.path.join(model_out_dir, 'eval', shape_name + '.xyz.txt'), sdf_np)
+    writers.savetxt_f32(os.path.join(model_out_dir, 'eval', shape_name + '.xyz.txt'), sdf_np)
     _visualize_query_points(q_np, sdf_np, os.path.join(model_out_dir, 'vis', shape_name + '.ply'))
     if not reconstruction:
         return
@@ -257,22 +255,34 @@ def points_to_surf_eval(eval_opt):
         ball = cfg['patch_radius'] > 0.0
         rng_rot = None if (reconstruction and not ball) else _engine.Rng(eval_opt.seed, device=device)
         mine = set(range(len(shape_names)))
-        if world > 1:
-            sizes = [os.path.getsize(os.path.join(eval_opt.indir, '04_pts', n + '.xyz.npy'))
-                     if os.path.isfile(os.path.join(eval_opt.indir, '04_pts', n + '.xyz.npy')) else 1
-                     for n in shape_names]
-            mine = set(_sharding.assign_lpt(sizes, world)[rank])
+        per_shape_rng = os.environ.get('P2S_RNG_MODE', 'dataset') == 'per_shape'
+        # P2S_SHARD=queries: every rank takes a contiguous query range of EVERY shape (few, large shapes; 512^3 grids)
+        # instead of whole shapes; the RNG stream is advanced past the other ranks' queries, results stay identical
+        shard_queries = world > 1 and os.environ.get('P2S_SHARD', 'shapes') == 'queries' and not per_shape_rng \
+            and reconstruction
+        owner, handoff = None, None
+        if world > 1 and reconstruction and not shard_queries:
+            # ONE policy (sharding.assign_shapes, also bench.py's): LPT over the shapes' query counts -- every rank
+            # voxelises every cloud once up front (upload + index + grid: ~1.5 ms per shape) and gets the same list
+            counts = []
+            for n in shape_names:
+                c = _engine.Cloud(_load_points(eval_opt.indir, n), device=device)
+                counts.append(c.count_queries(eval_opt.query_grid_resolution, eval_opt.epsilon))
+                c.close()
+            parts, owner = _sharding.assign_shapes(counts, world)
+            mine = set(parts[rank])
+            if not per_shape_rng and _sharding.stream_handoff_enabled():
+                # keys are written once per store: every call of this function (all ranks make the same calls in the
+                # same order) gets its own key space
+                global _HANDOFF_SEQ
+                _HANDOFF_SEQ += 1
+                handoff = _sharding.StreamHandoff('eval%d/%s' % (_HANDOFF_SEQ, model_name), owner, rank=rank)
         total_q = 0
         t0 = time.time()
         # result files are written on background threads while the next shape is on the GPU (np.savetxt alone
         # costs ~0.27 s per 300k values -- a quarter of a shape's inference time)
         writers = concurrent.futures.ThreadPoolExecutor(max_workers=2)
         pending = []
-        per_shape_rng = os.environ.get('P2S_RNG_MODE', 'dataset') == 'per_shape'
-        # P2S_SHARD=queries: every rank takes a contiguous query range of EVERY shape (few, large shapes; 512^3 grids)
-        # instead of whole shapes; the RNG stream is advanced past the other ranks' queries, results stay identical
-        shard_queries = world > 1 and os.environ.get('P2S_SHARD', 'shapes') == 'queries' and not per_shape_rng \
-            and reconstruction
         if shard_queries:
             # stale pieces of an earlier run into the same outdir must not be mistaken for this run's
             if rank == 0:
@@ -311,13 +321,32 @@ def points_to_surf_eval(eval_opt):
                 rng_dev = _engine.Rng((eval_opt.seed + shape_ind) & 0xffffffff, device=device)
                 if ball:
                     rng_rot = _engine.Rng((eval_opt.seed + shape_ind) & 0xffffffff, device=device)
+            if shape_ind not in mine and handoff is not None:
+                continue                   # exact stream by hand-off: a rank never touches a foreign shape
             pts_np = _load_points(eval_opt.indir, shape_name)
             if shape_ind not in mine:
-                # keep the dataset-wide stream exact on every rank: consume this shape's draws without inference
+                # no process group (ranks run one after the other) / P2S_STREAM_HANDOFF=replicate: keep the
+                # dataset-wide stream exact on every rank by consuming this shape's draws without inference
                 cloud = _engine.Cloud(pts_np, device=device)
-                _sharding.skip_shape_stream(cloud, rng_dev, cfg, eval_opt.query_grid_resolution,
-                                            eval_opt.epsilon, model.sub_sample_size, rng_patch=rng_rot)
+                try:
+                    _sharding.skip_shape_stream(cloud, rng_dev, cfg, eval_opt.query_grid_resolution,
+                                                eval_opt.epsilon, model.sub_sample_size, rng_patch=rng_rot)
+                finally:
+                    cloud.close()
                 continue
+            if handoff is not None:
+                rngs = [rng_dev] + ([rng_rot] if rng_rot is not None else [])
+                handoff.begin(shape_ind, rngs)             # blocks until the owner of the shape before has published
+                if handoff.must_publish(shape_ind):
+                    def _advance():
+                        # on a handle of its own: a cloud smaller than the sub-sample is shuffled in place by its draws
+                        c2 = _engine.Cloud(pts_np, device=device)
+                        try:
+                            _sharding.skip_shape_stream(c2, rng_dev, cfg, eval_opt.query_grid_resolution,
+                                                        eval_opt.epsilon, model.sub_sample_size, rng_patch=rng_rot)
+                        finally:
+                            c2.close()
+                    handoff.publish_after(shape_ind, rngs, _advance)
             cloud = _engine.Cloud(pts_np, device=device)
             sdf, q = _infer_one_shape(model, cloud, rng_dev, eval_opt.query_grid_resolution, eval_opt.epsilon, chunk,
                                       rng_patch=rng_rot)
@@ -326,6 +355,8 @@ def points_to_surf_eval(eval_opt):
             total_q += sdf_np.shape[0]
             pending.append(writers.submit(_save_shape, model_out_dir, shape_name, sdf_np, q_np))
             cloud.close()
+            if handoff is not None:
+                handoff.done(shape_ind)
         for f in pending:
             f.result()                     # re-raise writer errors; everything is on disk when we return
         writers.shutdown(wait=True)

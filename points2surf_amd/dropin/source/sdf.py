@@ -85,32 +85,10 @@ def propagate_sign(vol, sigma=5, certainty_threshold=13):
 
 
 def visualize_query_points(query_pts_ms, query_dist_ms, file_out_off):
-    """reference :269-285: red = negative, green = positive distance, brightness = |d| / max|d|; coloured point-cloud PLY"""
-    from points2surf_amd import ply
-    d = np.asarray(query_dist_ms)
-    d_abs = np.abs(d)
-    with np.errstate(invalid='ignore', divide='ignore'):
-        d_norm = d_abs / d_abs.max()
-    col = np.zeros((d.shape[0], 3))
-    neg, pos = d < 0.0, d > 0.0
-    col[neg, 0] = 0.5 + 0.5 * d_norm[neg]
-    col[pos, 1] = 0.5 + 0.5 * d_norm[pos]
-    if os.path.dirname(file_out_off):
-        os.makedirs(os.path.dirname(file_out_off), exist_ok=True)
-    ply.write_ply(file_out_off, query_pts_ms, vertex_colors=col)
-
-
-def _write_coff_points(file_path, vertices, colors):
-    """mesh_io.write_off(file, vertices, [], colors_vertex=colors) of the reference (source/base/mesh_io.py:75-140): COFF"""
-    if len(vertices) == 0:
-        return
-    if os.path.dirname(file_path):
-        os.makedirs(os.path.dirname(file_path), exist_ok=True)
-    with open(file_path, 'w') as fp:
-        fp.write('COFF\n')
-        fp.write(str(len(vertices)) + ' 0 0\n')
-        for v, c in zip(vertices, colors):
-            fp.write(str(v[0]) + ' ' + str(v[1]) + ' ' + str(v[2]) + ' ' + ''.join(str(x) + ' ' for x in c) + '\n')
+    """reference :269-285: red = negative, green = positive distance, brightness = |d| / max|d|; coloured point-cloud PLY
+    (native host writer, p2s_write_query_vis_ply)"""
+    from points2surf_amd import writers
+    writers.query_vis_ply(file_out_off, query_pts_ms, query_dist_ms)
 
 
 def implicit_surface_to_mesh(query_dist_ms, query_pts_ms, volume_out_file, mc_out_file, grid_res, sigma,
@@ -118,7 +96,7 @@ def implicit_surface_to_mesh(query_dist_ms, query_pts_ms, volume_out_file, mc_ou
     """reference :181-230 with the volume, the iso-surface and the inversion fix on the device"""
     _check_process()
     import torch
-    from points2surf_amd import engine, ply
+    from points2surf_amd import engine, ply, writers
     query_dist_ms = np.asarray(query_dist_ms)
     if query_dist_ms.max() == 0.0 and query_dist_ms.min() == 0.0:
         print('WARNING: implicit surface for {} contains only zeros'.format(volume_out_file))
@@ -128,12 +106,10 @@ def implicit_surface_to_mesh(query_dist_ms, query_pts_ms, volume_out_file, mc_ou
     torch.cuda.synchronize()
     print('Sign propagation took: {}'.format(time.time() - start))
 
-    # green = inside; red = outside (the reference's debug output of the samples, :203-209)
-    norm = query_dist_ms / np.max(np.abs(query_dist_ms))
-    col = np.zeros((norm.shape[0], 3))
-    col[norm < 0.0, 0] = np.abs(norm[norm < 0.0]) + 1.0 / 2.0
-    col[norm > 0.0, 1] = norm[norm > 0.0] + 1.0 / 2.0
-    _write_coff_points(volume_out_file, np.asarray(query_pts_ms), col)
+    # green = inside; red = outside (the reference's debug output of the samples, :203-209 -> mesh_io.write_off,
+    # source/base/mesh_io.py:75-140): the same bytes from the native host writer (p2s_write_coff_samples) instead of a
+    # Python loop with six str() calls per sample (seconds per 256^3 shape)
+    writers.coff_samples(volume_out_file, np.asarray(query_pts_ms), query_dist_ms)
 
     # reference :211-229: mesh only if the volume holds both signs; an iso-surface without a 0-level set is empty, so
     # the extraction itself answers that (no separate min / max pass over the volume)

@@ -1,10 +1,14 @@
 """Shape-level sharding across the GPUs of one node (one process per GPU, torch.distributed).
 
 The path has no cross-query state, so shapes shard embarrassingly: longest-processing-time-first
-assignment, no data-path collective.  Two things cross ranks:
-  * the dataset-wide sub-sample RNG stream (reference source/data_loader.py:274-277): every rank
-    consumes the draws of the shapes it does not own (``skip_shape_stream``), which keeps results
-    bit-identical to the single-process run;
+assignment by query count (``assign_shapes``: ONE policy for bench.py and the drop-in), no data-path collective.
+Two things cross ranks:
+  * the dataset-wide sub-sample RNG stream (reference source/data_loader.py:274-277), which keeps results
+    bit-identical to the single-process run.  ``StreamHandoff`` (default when a process group exists): the owner of
+    shape i consumes ITS shape's draws once more ahead of the inference (``skip_shape_stream`` on a snapshot) and
+    hands the generator state (2.5 KB) to the owner of shape i+1 through the rendezvous store -- control plane, no
+    collective; a rank never touches a shape it does not own.  Without a process group (ranks run one after the
+    other, tests) or with ``P2S_STREAM_HANDOFF=replicate`` every rank consumes the draws of every foreign shape itself;
   * the final variable-length gather of per-shape results to rank 0 (``gather_variable``; RCCL over
     xGMI with the nccl backend, gloo in the CPU tests).
 Replaces the reference's only multi-GPU mechanism, ``torch.nn.DataParallel`` (reference
@@ -34,6 +38,18 @@ def assign_lpt(costs, world):
     return [sorted(x) for x in out]
 
 
+def assign_shapes(query_counts, world):
+    """THE shape -> rank policy of bench.py and the drop-in: longest-processing-time-first over the shapes' query counts
+    (Cloud.count_queries: the cost of a shape is proportional to it).  Returns (lists of shape indices per rank, each
+    ascending; owner[i] = rank of shape i)."""
+    parts = assign_lpt(query_counts, world)
+    owner = [0] * len(query_counts)
+    for r, items in enumerate(parts):
+        for i in items:
+            owner[i] = r
+    return parts, owner
+
+
 def is_initialized():
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized()
@@ -50,7 +66,9 @@ def init_process_group(backend=None):
     import torch
     import torch.distributed as dist
     world, rank, local_rank = dist_env()
-    if world == 1 or dist.is_initialized():
+    # P2S_DIST_FORCE=1: create the process group also at world size 1 (one GPU: RCCL then really executes the
+    # all_gather / gather / barrier of this module -- tests/test_gpu_rccl_world1.py)
+    if (world == 1 and not os.environ.get('P2S_DIST_FORCE')) or dist.is_initialized():
         return world, rank, local_rank
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
@@ -91,9 +109,9 @@ def gather_variable(t, dst=0):
     None elsewhere.  One all_gather of the sizes + one padded gather (the path's only collective)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [t]
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world, rank = dist.get_world_size(), dist.get_rank()      # world size 1 with a group: the collectives still run
     t = t.to(collective_device(t.device))
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
@@ -154,3 +172,86 @@ def skip_shape_stream(cloud, rng_dev, cfg, grid_resolution, epsilon, sub_sample_
     if rng_patch is not None:
         rng_patch.check()
     return int(q.shape[0])
+
+
+class StreamHandoff:
+    """The dataset-wide generator state(s) handed from the owner of shape i to the owner of shape i+1 through the
+    process group's rendezvous store (TCPStore; keys are written once, ``get`` blocks until the key exists): the exact
+    single-process stream without any rank consuming the draws of a foreign shape.
+
+        h = StreamHandoff('rec/p2s_max', owner)              # owner[i] = rank of shape i, same list on every rank
+        for i in my shapes, ascending:
+            h.begin(i, rngs)                                 # my generators -> start of shape i (blocks for the token)
+            if h.must_publish(i):                            # the next shape belongs to another rank
+                h.publish_after(i, rngs, advance)            # advance(): consume shape i's draws (skip_shape_stream)
+            ... infer shape i with rngs ...
+            h.done(i)
+
+    ``rngs``: list of engine.Rng (the sub-sample generator; fixed-radius models add the patch-choice generator)."""
+
+    def __init__(self, tag, owner, rank=None, store=None, timeout_s=7200.0):
+        import torch.distributed as dist
+        self.owner = list(owner)
+        self.rank = dist.get_rank() if rank is None else int(rank)
+        if store is None:
+            from torch.distributed.distributed_c10d import _get_default_store
+            store = _get_default_store()
+        self.store = store
+        self.tag = str(tag)
+        self.timeout_s = float(timeout_s)
+        self.at = 0                     # my generators are positioned at the start of this shape
+        self.waited_s = 0.0
+
+    def _key(self, i):
+        return 'p2s/stream/%s/%d' % (self.tag, i)
+
+    @staticmethod
+    def pack(rngs):
+        out = []
+        for r in rngs:
+            mt, pos = r.get_state()
+            out.append(np.concatenate([np.ascontiguousarray(mt, dtype=np.uint32), np.array([pos], dtype=np.uint32)]))
+        return np.concatenate(out).tobytes()
+
+    @staticmethod
+    def unpack(blob, rngs):
+        a = np.frombuffer(blob, dtype=np.uint32)
+        if a.size != 625 * len(rngs):
+            raise RuntimeError('stream hand-off: %d words for %d generators' % (a.size, len(rngs)))
+        for k, r in enumerate(rngs):
+            r.set_state(a[625 * k:625 * k + 624].copy(), int(a[625 * k + 624]))
+
+    def begin(self, i, rngs):
+        """position ``rngs`` at the first draw of shape ``i`` (which this rank owns)"""
+        import datetime
+        import time
+        if self.owner[i] != self.rank:
+            raise ValueError('shape %d belongs to rank %d' % (i, self.owner[i]))
+        if i == self.at or i == 0:
+            self.at = i
+            return
+        t0 = time.time()
+        self.store.wait([self._key(i)], datetime.timedelta(seconds=self.timeout_s))
+        self.unpack(self.store.get(self._key(i)), rngs)
+        self.waited_s += time.time() - t0
+        self.at = i
+
+    def must_publish(self, i):
+        return i + 1 < len(self.owner) and self.owner[i + 1] != self.rank
+
+    def publish_after(self, i, rngs, advance):
+        """run ``advance()`` (consume the draws of shape i), publish the state as the start of shape i+1, then put the
+        generators back to the start of shape i"""
+        snap = [r.get_state() for r in rngs]
+        advance()
+        self.store.set(self._key(i + 1), self.pack(rngs))
+        for r, (mt, pos) in zip(rngs, snap):
+            r.set_state(mt, pos)
+
+    def done(self, i):
+        self.at = i + 1
+
+
+def stream_handoff_enabled():
+    """token hand-off needs a process group (its store); P2S_STREAM_HANDOFF=replicate forces the replicate mode"""
+    return is_initialized() and os.environ.get('P2S_STREAM_HANDOFF', 'token') != 'replicate'
