@@ -171,6 +171,81 @@ def complete_shape(engine, model, pts_host, rng, res, chunk, ev=None):
     return out, sdf
 
 
+def dropin_leg(shapes, res, encoder, golden, parity):
+    """The hot path measured THROUGH the boundary the north_star names (B1): the drop-in's
+    ``source.points_to_surf_eval.points_to_surf_eval(opt)`` in reconstruction mode over the dataset (files loaded from
+    disk, all result files written), followed by ``source.sdf.implicit_surface_to_mesh_directory`` -- the sequence and the
+    timed region of the reference's full_eval.py:44-64.  Returns the record for ``secondary.dropin_<encoder>``."""
+    import shutil
+    import tempfile
+    from points2surf_amd import synth
+    dropin = os.path.join(REPO, 'points2surf_amd', 'dropin')
+    if dropin not in sys.path:
+        sys.path.insert(0, dropin)
+    from source import points_to_surf_eval as ev
+    from source import sdf as dsdf
+    tmp = tempfile.mkdtemp(prefix='p2s_bench_dropin_')
+    prev = os.environ.get('P2S_ENCODER')
+    try:
+        root = os.path.join(tmp, 'abc_minimal')
+        os.makedirs(os.path.join(root, '04_pts'))
+        for name, pts, _ in shapes:
+            np.save(os.path.join(root, '04_pts', name + '.xyz.npy'), pts)
+        with open(os.path.join(root, 'testset.txt'), 'w') as f:
+            f.write('\n'.join(n for n, _, _ in shapes) + '\n')
+        modeldir = os.path.join(tmp, 'models')
+        synth.write_model_files(modeldir, 'p2s_max')
+        os.environ['P2S_ENCODER'] = encoder
+        stats = {}
+
+        def run(outdir, grid):
+            opt = ev.parse_arguments(['--indir', root, '--outdir', outdir, '--dataset', 'testset.txt', '--modeldir', modeldir,
+                                      '--models', 'p2s_max', '--query_grid_resolution', str(grid), '--epsilon', str(EPSILON),
+                                      '--certainty_threshold', '13', '--sigma', '5', '--workers', '7', '--batchSize', '0'])
+            opt.reconstruction = True                          # full_eval.py:45
+            t0 = time.time()
+            ev.points_to_surf_eval(opt)                        # full_eval.py:46
+            t1 = time.time()
+            stats.clear()
+            stats.update(ev.last_run_stats)
+            rec = os.path.join(outdir, 'rec')
+            dsdf.implicit_surface_to_mesh_directory(            # full_eval.py:51-64
+                os.path.join(rec, 'dist_ms'), os.path.join(rec, 'query_pts_ms'), os.path.join(rec, 'vol'),
+                os.path.join(rec, 'mesh'), opt.query_grid_resolution, opt.sigma, opt.certainty_threshold, opt.workers)
+            return t1 - t0, time.time() - t1, rec
+
+        run(os.path.join(tmp, 'warm'), 64)                      # warm-up (block cache, generator session, page cache)
+        t_eval, t_mesh, rec = run(os.path.join(tmp, 'out'), res)
+        nq, worst, flips, files = 0, 0.0, 0, 0
+        for name, _, ref in shapes:
+            sdf = np.load(os.path.join(rec, 'dist_ms', name + '.xyz.npy'))
+            nq += int(sdf.shape[0])
+            for sub, ext in (('eval', '.xyz.npy'), ('eval', '.xyz.txt'), ('query_pts_ms', '.xyz.npy'), ('vis', '.ply'),
+                             ('query_pts_ms_vis', '.ply'), ('vol', '.off'), ('mesh', '.ply')):
+                files += int(os.path.getsize(os.path.join(rec, sub, name + ext)) > 0)
+            if ref is not None:
+                c = parity.compare_sdf(sdf, ref)
+                worst, flips = max(worst, c['max_abs_dsdf']), flips + int(c['flipped'].size)
+        return {'value': nq / t_eval, 'unit': 'queries/s', 'queries': nq, 'shapes': len(shapes), 'encoder': encoder,
+                'seconds_points_to_surf_eval': t_eval, 'seconds_mesh_directory': t_mesh,
+                'seconds_shape_loop': stats.get('seconds_shapes'), 'seconds_model_create': stats.get('seconds_model_create'),
+                'value_shape_loop': nq / max(stats.get('seconds_shapes') or t_eval, 1e-9),
+                'shapes_per_hour_eval': len(shapes) / t_eval * 3600.0,
+                'shapes_per_hour_incl_mesh': len(shapes) / (t_eval + t_mesh) * 3600.0,
+                'files_written': files, 'vs_reference_golden': None if golden is None else
+                {'file': golden, 'max_abs_dsdf': worst, 'sign_flips': flips},
+                'what': 'source.points_to_surf_eval.points_to_surf_eval(opt) of the drop-in (reconstruction pass: clouds '
+                        'loaded from .npy files, eval/.npy + .txt, dist_ms, query_pts_ms and both visualisation PLYs '
+                        'written) then source.sdf.implicit_surface_to_mesh_directory (.off + mesh .ply per shape), timed '
+                        'like full_eval.py:44-64; model load included'}
+    finally:
+        if prev is None:
+            os.environ.pop('P2S_ENCODER', None)
+        else:
+            os.environ['P2S_ENCODER'] = prev
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def golden_check(engine, parity, model, w, cfg, shapes, res, sdfs, tol, bf16):
     """every query of the run ``sdfs`` (one array per shape, one stream from SEED_DATA in dataset order) against the
     goldens the unmodified reference wrote.  Signs: a flipped sign is accepted as an fp32 TIE only if BOTH the device's
@@ -353,6 +428,7 @@ def main():
     n_queries = sum(int(o[0].shape[0]) for o in mine_timed)
     per_shape_q = {shapes[ci][0][:8]: q_of_cloud[ci] for ci in sorted(set(cloud_of[args.warmup * world:]))}
     gathered = 0
+    parts = None
     if sharding.is_initialized():
         # the final variable-length gather of the SDF values to rank 0 (RCCL over xGMI): the path's only exchange
         mine_dev = torch.cat([o[1] for o in mine_timed]) if mine_timed else torch.empty((0,), dtype=torch.float32, device='cuda')
@@ -455,6 +531,26 @@ def main():
                 bail('against the reference golden', check)
         elif golden_file is not None:
             check['vs_reference_golden'] = {'file': os.path.relpath(golden_file, REPO), 'missing': True}
+        # (1b) N > 1 with the stream hand-off: rank 0 re-derives the LAST timed shape of another rank from scratch (fresh
+        # stream, every earlier shape's draws consumed one after the other) and compares it with what that rank produced
+        if handoff is not None and parts is not None:
+            lo = args.warmup * world
+            foreign = [g for g in range(lo, n_rounds * world) if owner[g] != 0]
+            if foreign:
+                gstar = foreign[-1]
+                r_chk = engine.Rng(SEED_DATA)
+                for g in range(gstar):
+                    c2 = engine.Cloud(shapes[cloud_of[g]][1])
+                    sharding.skip_shape_stream(c2, r_chk, cfg, args.res, EPSILON, n_sub)
+                    c2.close()
+                mine_again = complete_shape(engine, model, shapes[cloud_of[gstar]][1], r_chk, args.res, args.chunk)[0].numpy()
+                before = sum(q_of_cloud[cloud_of[g]] for g in range(lo, gstar) if owner[g] == owner[gstar])
+                theirs = parts[owner[gstar]][before:before + mine_again.shape[0]].cpu().numpy()
+                same = bool(theirs.shape == mine_again.shape and np.array_equal(theirs, mine_again))
+                check['stream_handoff'] = {'shape': gstar, 'owner': owner[gstar], 'queries': int(mine_again.shape[0]),
+                                           'bit_identical_to_single_stream': same}
+                if not same:
+                    bail('stream hand-off: shape %d of rank %d differs from the single-stream result' % (gstar, owner[gstar]), check)
         # (2) the r02 measurement beside the headline: cloud handles + query grids resident, SDF left on the device
         if world == 1:
             resident = [engine.Cloud(pts) for _, pts, _ in shapes]
@@ -509,6 +605,16 @@ def main():
                         bail('in the secondary pass ' + key, check)
                 sec[key] = srec
                 m2.close()
+            # the same workload measured through boundary B1 (drop-in API, files in / files out), fp32 and fp16 pair
+            gname = os.path.relpath(golden_file, REPO) if golden_file and os.path.isfile(golden_file) else None
+            for enc in ('fp32', 'fp16x2'):
+                srec = dropin_leg(shapes, args.res, enc, gname, parity)
+                srec['ratio_to_engine'] = srec['value_shape_loop'] / (value if enc == 'fp32' else max(sec['p2s_max_fp16x2']['value'], 1e-9))
+                g_ = srec['vs_reference_golden']
+                if g_ is not None and (g_['max_abs_dsdf'] > 1e-4 or g_['sign_flips'] > 4):
+                    check['secondary_dropin_' + enc] = srec
+                    bail('in the drop-in pass ' + enc, check)
+                sec['dropin_' + enc] = srec
             out['secondary'] = sec
         # (4) the CPU baseline on the first shape's first queries, and the device against it
         if args.cpu_seconds > 0 and world == 1:

@@ -40,6 +40,7 @@ from points2surf_amd.model_spec import strip_module_prefix
 
 
 _HANDOFF_SEQ = 0
+last_run_stats = {}          # timings of the most recent points_to_surf_eval call (bench.py's drop-in leg reads them)
 
 
 def parse_arguments(args=None):
@@ -224,7 +225,9 @@ def points_to_surf_eval(eval_opt):
         raise ValueError('reconstruction needs --query_grid_resolution and --epsilon')
 
     world, rank, local_rank = _sharding.dist_env()
-    if world > 1 and 'MASTER_PORT' in os.environ:        # launched by torchrun (tests run "ranks" one after the other)
+    # launched by torchrun (tests run "ranks" one after the other without a rendezvous); P2S_DIST_FORCE: the group also
+    # at world size 1 (RCCL then executes the barriers of this function on a one-GPU box)
+    if (world > 1 or os.environ.get('P2S_DIST_FORCE')) and 'MASTER_PORT' in os.environ:
         _sharding.init_process_group()
     device = _engine.select_device(eval_opt.gpu_idx if world == 1 else _sharding.local_device_index(local_rank))
 
@@ -238,7 +241,10 @@ def points_to_surf_eval(eval_opt):
         pred_dim = get_output_dimensions(train_opt)
         cfg = _engine_cfg(train_opt, pred_dim)
         state = strip_module_prefix(torch.load(model_filename, map_location='cpu', weights_only=False))
+        t_load0 = time.time()
         model = _engine.Model(state, cfg, device=device)
+        torch.cuda.synchronize(device)
+        t_model = time.time() - t_load0
         chunk = int(eval_opt.batchSize) if int(eval_opt.batchSize) > 0 else 0
 
         with open(os.path.join(eval_opt.indir, eval_opt.dataset)) as f:
@@ -361,8 +367,7 @@ def points_to_surf_eval(eval_opt):
             f.result()                     # re-raise writer errors; everything is on disk when we return
         writers.shutdown(wait=True)
         dt = time.time() - t0
-        if world > 1:
-            _sharding.barrier()
+        _sharding.barrier()                # no-op without a process group
         if shard_queries:
             # every piece is on disk (barrier): rank r takes the shapes i = r mod world first; the claim is atomic,
             # so ranks run one after the other (tests) work too: the last one finds all pieces
@@ -377,6 +382,9 @@ def points_to_surf_eval(eval_opt):
                        if not os.path.isfile(os.path.join(model_out_dir, d, n + '.xyz.npy'))]
             if missing:
                 raise RuntimeError('points_to_surf_eval: outputs missing after the run: %s' % missing[:4])
+        last_run_stats.update(model=model_name, queries=int(total_q), shapes=len(mine), seconds_shapes=dt,
+                              seconds_model_create=t_model, rank=rank, world=world,
+                              stream_wait_s=None if handoff is None else handoff.waited_s)
         print('evaluated %d patches of %d shapes in %.2f s (%.0f queries/s on rank %d)'
               % (total_q, len(mine), dt, total_q / max(dt, 1e-9), rank))
         model.close()

@@ -156,3 +156,26 @@ def make_standin_dataset(root, base_clouds, n_shapes, list_name='testset.txt'):
     with open(os.path.join(root, list_name), 'w') as f:
         f.write('\n'.join(names) + '\n')
     return names
+
+
+def write_model_files(modeldir, model, seed=1234, encoder_cfg=None):
+    """<modeldir>/<model>_model.pth (DataParallel-prefixed state_dict) + <model>_params.pth (the pickled train
+    Namespace), the two files ``points_to_surf_eval`` loads (reference source/points_to_surf_eval.py:167-170,316) -- for
+    the seeded synthetic weights (no pretrained weights exist offline).  Returns (weights, cfg)."""
+    import argparse
+    import os
+    import torch
+    w, cfg = make_weights(model, seed=seed)
+    os.makedirs(modeldir, exist_ok=True)
+    torch.save(to_torch_state_dict(w), os.path.join(modeldir, model + '_model.pth'))
+    outputs = ['imp_surf', 'patch_pts_ids', 'p_index'] if int(cfg.get('output_dim', 2)) == 1 else \
+        ['imp_surf_magnitude', 'imp_surf_sign', 'patch_pts_ids', 'p_index']
+    ns = argparse.Namespace(
+        outputs=outputs, points_per_patch=int(cfg.get('points_per_patch', 300)), patch_center='mean',
+        sub_sample_size=int(cfg.get('sub_sample_size', 1000)), patch_radius=float(cfg.get('patch_radius', 0.0)),
+        uniform_subsample=int(cfg['uniform_subsample']), fixed_subsample=int(cfg.get('fixed_subsample', 0)), net_size=1024,
+        use_point_stn=int(cfg['use_point_stn']), use_feat_stn=int(cfg.get('use_feat_stn', True)), sym_op=cfg.get('sym_op', 'max'),
+        single_transformer=int(cfg.get('single_transformer', False)), shared_transformer=int(cfg['shared_transformer']),
+        batchSize=501)
+    torch.save(ns, os.path.join(modeldir, model + '_params.pth'))
+    return w, cfg

@@ -80,3 +80,78 @@ def test_query_range_is_an_ordered_balanced_partition():
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
             sizes = [b - a for a, b in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_assign_shapes_is_lpt_with_owner_list():
+    costs = [307237, 571597, 499408, 307237, 571597, 499408, 10]
+    for world in (1, 2, 4, 8):
+        parts, owner = sharding.assign_shapes(costs, world)
+        assert parts == sharding.assign_lpt(costs, world)
+        assert all(owner[i] == r for r, p in enumerate(parts) for i in p) and len(owner) == len(costs)
+
+
+class _FakeRng:
+    """stands in for engine.Rng (get_state / set_state): the 'stream' is a counter in mt[0], 'position' in pos"""
+
+    def __init__(self, seed):
+        self.mt = np.zeros(624, np.uint32)
+        self.mt[0] = seed
+        self.pos = 624
+
+    def get_state(self):
+        return self.mt.copy(), self.pos
+
+    def set_state(self, mt, pos):
+        self.mt, self.pos = np.array(mt, dtype=np.uint32), int(pos)
+
+    def consume(self, n):                      # a shape that draws n words
+        self.mt[0] = np.uint32((int(self.mt[0]) * 1664525 + n) & 0xffffffff)
+        self.pos = (self.pos + n) % 625
+
+
+DRAWS = [11, 7, 5, 13, 3, 17, 19, 2, 23]          # words each shape consumes
+OWNER = [0, 1, 1, 2, 0, 0, 2, 1, 0]
+
+
+def _handoff_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    sharding.init_process_group('gloo')
+    assert sharding.stream_handoff_enabled()
+    a, b = _FakeRng(40938661), _FakeRng(99)       # two generators (fixed-radius models hand over both)
+    h = sharding.StreamHandoff('test', OWNER, rank=rank)
+    seen = {}
+    for i in [k for k, o in enumerate(OWNER) if o == rank]:
+        h.begin(i, [a, b])
+        seen[i] = (int(a.mt[0]), a.pos, int(b.mt[0]), b.pos)
+        if h.must_publish(i):
+            def advance():
+                a.consume(DRAWS[i])
+                b.consume(2 * DRAWS[i])
+            h.publish_after(i, [a, b], advance)
+            assert (int(a.mt[0]), a.pos, int(b.mt[0]), b.pos) == seen[i]     # put back to the start of shape i
+        a.consume(DRAWS[i])                       # "inference" of shape i
+        b.consume(2 * DRAWS[i])
+        h.done(i)
+    np.save(os.path.join(outdir, 'seen_%d.npy' % rank), np.array([[k] + list(v) for k, v in seen.items()], dtype=np.int64))
+    sharding.barrier()
+    dist.destroy_process_group()
+
+
+def test_stream_handoff_gives_every_owner_the_single_process_state(tmp_path):
+    """sharding.StreamHandoff over the rendezvous store, 3 gloo ranks: every shape's owner starts from exactly the state
+    a single process walking all shapes in order would have (also across consecutive shapes of one owner, and with the
+    owner of shape i+1 still busy when shape i publishes)"""
+    port = _free_port()
+    mp.spawn(_handoff_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    a, b = _FakeRng(40938661), _FakeRng(99)
+    want = {}
+    for i, n in enumerate(DRAWS):
+        want[i] = (int(a.mt[0]), a.pos, int(b.mt[0]), b.pos)
+        a.consume(n)
+        b.consume(2 * n)
+    got = {}
+    for r in range(3):
+        for row in np.load(os.path.join(str(tmp_path), 'seen_%d.npy' % r)):
+            got[int(row[0])] = tuple(int(x) for x in row[1:])
+    assert got == want
