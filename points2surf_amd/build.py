@@ -29,12 +29,43 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, extra_flags=()):
+def _flags(extra_flags=()):
+    return ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function'] + \
+        list(extra_flags) + os.environ.get('P2S_EXTRA_HIPCC_FLAGS', '').split()
+
+
+def build(force=False, verbose=True, extra_flags=(), jobs=None):
+    """one object per translation unit under csrc/_obj/ (rebuilt when the source, a header or the flags changed), linked
+    into libp2s_hip.so; ``force`` recompiles everything"""
+    import concurrent.futures
+    import hashlib
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc_path(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
-           '-o', LIB] + list(extra_flags) + os.environ.get('P2S_EXTRA_HIPCC_FLAGS', '').split() + sources()
+    flags = _flags(extra_flags)
+    objdir = os.path.join(CSRC, '_obj')
+    os.makedirs(objdir, exist_ok=True)
+    headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inl')) + \
+        glob.glob(os.path.join(os.path.dirname(HERE), 'include', '*.h'))
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+    tag = hashlib.sha1(' '.join(flags).encode()).hexdigest()[:10]
+    todo, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, '%s.%s.o' % (os.path.basename(src)[:-4], tag))
+        objs.append(obj)
+        if force or not os.path.isfile(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            todo.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [hipcc_path()] + flags + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    jobs = jobs or int(os.environ.get('P2S_BUILD_JOBS', min(8, os.cpu_count() or 1)))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [hipcc_path(), '--offload-arch=gfx950', '-shared', '-fPIC', '-fno-gpu-rdc', '-o', LIB] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

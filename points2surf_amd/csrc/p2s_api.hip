@@ -527,7 +527,9 @@ static int run_batched(p2s_model_s *m, const float *patch, const float *sub, con
     }
     p2s_prof_collect(m);
     m->counters.queries += B;
-    return P2S_OK;
+    // fp16 pair encoder: the sticky range flag is reported (and cleared) by the call that raised it -- not by the next
+    // pipeline call on this model (this synchronises `s` in that mode only)
+    return p2s_model_check_range(m, s);
 }
 
 extern "C" {

@@ -365,12 +365,15 @@ __global__ __launch_bounds__(64) void ball_patch_kernel(const uint32_t *__restri
 
 // rand(3) -> rotation matrices from per-query word positions (GT-query pass of a fixed-radius model)
 __global__ __launch_bounds__(256) void ball_rot_words_kernel(const uint32_t *__restrict__ words, const long long *__restrict__ tpos,
-                                                             long long n, uint32_t *__restrict__ six) {
+                                                             long long n, uint32_t *__restrict__ six, long long alloc_words,
+                                                             const long long *__restrict__ meta) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t *w = words + tpos[i];
+    // a sticky generator error (meta[1] != 0): the chain kernel returned before writing tpos -- nothing to read
+    const long long t = meta[1] != 0 ? -1 : tpos[i];
+    const bool ok = t >= 0 && t + 6 <= alloc_words;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) six[6 * i + j] = w[j];
+    for (int j = 0; j < 6; ++j) six[6 * i + j] = ok ? words[t + j] : 0u;
 }
 
 int ball_ws_reserve(p2s_rng_s *r, size_t bytes) {
@@ -549,7 +552,8 @@ int p2s_ball_patch_counted(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, con
                            radius_out_dev ? radius_out_dev + done : (float *)nullptr, meta);
         P2S_LAUNCH_CHECK("fixed-radius patch kernels");
         if (rot_out_dev && tail_words == 6) {
-            hipLaunchKernelGGL(ball_rot_words_kernel, dim3((unsigned)((cur + 255) / 256)), dim3(256), 0, s, r->tmp, tpos, (long long)cur, six);
+            hipLaunchKernelGGL(ball_rot_words_kernel, dim3((unsigned)((cur + 255) / 256)), dim3(256), 0, s, r->tmp, tpos, (long long)cur, six,
+                               cap + 624, meta);
             P2S_LAUNCH_CHECK("ball_rot_words_kernel");
             rc = p2s_rotations_from_words(six, cur, rot_out_dev + (size_t)done * 9, s);
             if (rc) return rc;
@@ -591,8 +595,8 @@ extern "C" int p2s_ball_patch(p2s_rng_t r, p2s_cloud_t c, const float *q_dev, in
                               int with_rotation, int32_t *ids_out_dev, float *patch_out_dev, float *radius_out_dev,
                               double *rot_out_dev, void *stream) {
     if (!r || !c || nq < 0 || (nq > 0 && !q_dev) || !(radius > 0.0) || points_per_patch < 1 ||
-        points_per_patch > 4096 || (with_rotation && !rot_out_dev)) {
-        p2s_set_error("p2s_ball_patch: bad argument");
+        points_per_patch > 4096 || (with_rotation && !rot_out_dev) || (ids_out_dev && !patch_out_dev)) {
+        p2s_set_error("p2s_ball_patch: bad argument (ids_out_dev needs patch_out_dev)");
         return P2S_EINVAL;
     }
     if (nq == 0) return P2S_OK;

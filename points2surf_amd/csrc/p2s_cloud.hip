@@ -975,6 +975,7 @@ void p2s_cloud_pool_release(int device) {
 }
 
 void p2s_cloud_note_stream(p2s_cloud_s *c, hipStream_t s) {
+    if (c->foreign_streams_quiet > 0) return;      // inside run_pipeline: its streams are drained before it returns
     for (int i = 0; i < c->n_streams; ++i)
         if (c->streams[i] == s) return;
     if (c->n_streams < 4) c->streams[c->n_streams++] = s;
@@ -1098,6 +1099,7 @@ int p2s_cloud_destroy(p2s_cloud_t c) {
     if (c->many_streams) (void)hipDeviceSynchronize();
     else
         for (int i = 0; i < c->n_streams; ++i) (void)hipStreamSynchronize(c->streams[i]);
+    (void)hipGetLastError();        // a caller's stream that no longer exists: ignored, and not left for the next launch check
     if (c->grid_ev) (void)hipEventDestroy(c->grid_ev);
     p2s_pool_free(c->device, c->arena);
     p2s_pool_free(c->device, c->occ);
@@ -1187,6 +1189,7 @@ int p2s_cloud_grid(p2s_cloud_s *c, int res, int eps, const float **q_out, long l
         if (c->many_streams) (void)hipDeviceSynchronize();
         else
             for (int i = 0; i < c->n_streams; ++i) (void)hipStreamSynchronize(c->streams[i]);
+        (void)hipGetLastError();
     };
     if (words > c->occ_words) {
         if (c->occ) {

@@ -99,6 +99,10 @@ struct p2s_cloud_s {
     hipStream_t streams[4] = {};
     int n_streams = 0;
     bool many_streams = false;
+    // > 0 while a per-shape pipeline runs on this handle: the model-owned auxiliary streams it uses are NOT noted --
+    // run_pipeline drains them on every exit, and a handle must never synchronise a stream it does not own (the model
+    // may be destroyed before the cloud)
+    int foreign_streams_quiet = 0;
     // query-grid scratch (grown on demand)
     uint32_t *occ = nullptr;
     size_t occ_words = 0;

@@ -249,11 +249,27 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         P2S_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->ball, hipStreamNonBlocking, hi));
     }
+    // the handle remembers only the CALLER's stream.  The model-owned streams (aux / prep / ball) are drained by this
+    // function on every exit (fail(), and the guard below as a backstop): a cloud handle must not keep, let alone
+    // synchronise, a stream of a model that may be destroyed before it
     p2s_cloud_note_stream(c, s);
-    p2s_cloud_note_stream(c, sa);
-    p2s_cloud_note_stream(c, sp);
     const int64_t nq = q_end - q_begin;
     if (nq <= 0) return P2S_OK;
+    struct QuietGuard {
+        p2s_cloud_s *c;
+        p2s_model_s *m;
+        bool drained = false;
+        ~QuietGuard() {
+            if (!drained) {
+                if (m->aux) (void)hipStreamSynchronize(m->aux);
+                if (m->prep) (void)hipStreamSynchronize(m->prep);
+                if (m->ball) (void)hipStreamSynchronize(m->ball);
+                (void)hipGetLastError();
+            }
+            --c->foreign_streams_quiet;
+        }
+    } quiet{c, m};
+    ++c->foreign_streams_quiet;
     const int C = (int)std::min<int64_t>(chunk, nq);
     // clouds with fewer points than the sub-sample: shuffle + pad, and shape.pts permuted under the kd-tree
     // (reference source/base/utils.py:221-226; p2s_subsample_shuffle_pad)
@@ -272,6 +288,7 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
     // every exit after the first launch: both streams drained, so the caller may free / reuse its buffers and the
     // model-owned chunk buffers are idle again
     auto fail = [&](int code) {
+        quiet.drained = true;
         const hipError_t e1 = hipStreamSynchronize(s);
         hipError_t e2 = (sa != s) ? hipStreamSynchronize(sa) : hipSuccess;
         hipError_t e3 = (sp != s) ? hipStreamSynchronize(sp) : hipSuccess;
@@ -292,7 +309,6 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         }                                                                                                  \
     } while (0)
     hipStream_t sbl = ball_own ? m->ball : sa;        // stream of the fixed-radius patch work
-    if (ball_own) p2s_cloud_note_stream(c, sbl);
     if (sa != s || sp != s) {
         PIPE_HIP(hipEventRecord(b.grid, s));
         if (sa != s) PIPE_HIP(hipStreamWaitEvent(sa, b.grid, 0));

@@ -144,6 +144,11 @@ def skip_queries(cloud, rng_dev, cfg, queries, sub_sample_size, chunk=4096, rng_
         from . import engine
         if rng_patch is None:
             raise ValueError('fixed-radius model: the generator of the patch choice is required')
+        if cloud.n < sub_sample_size:
+            # the inference path refuses such a cloud (p2s_infer_shape_ball: P2S_EINVAL) -- refuse here as well, BEFORE
+            # either generator is advanced, so that all shard paths behave alike
+            raise ValueError('fixed-radius model: a cloud with fewer points (%d) than the sub-sample (%d) is not supported'
+                             % (cloud.n, sub_sample_size))
         engine.ball_skip(cloud, rng_patch, queries, float(cfg['patch_radius']), int(cfg.get('points_per_patch', 300)))
     # fixed_subsample: every query re-seeds the generator, nothing carries over -- but ``rng.seed(42)`` sits INSIDE the
     # N >= sub_sample_size branch (reference source/base/utils.py:210-211): a cloud with fewer points still shuffles

@@ -169,6 +169,37 @@ def test_radius_models_match_the_reference_golden(fixture_cloud, golden_dir, mod
     cloud.close()
 
 
+@pytest.mark.parametrize('model,chunk', [('p2s_small_radius', 0), ('p2s_medium_radius', 777), ('p2s_large_radius', 0)])
+def test_radius_models_match_the_reference_at_128(fixture_cloud, golden_dir, model, chunk):
+    """the fixed-radius models at a quoted size -- every one of the 68,088 queries of the 128^3 grid
+    against the SDF the unmodified reference wrote (oracle/make_golden_sizes.py rec <model> testset 128; ~25 min of
+    reference CPU each): the ball scan, the serial stream chain (ring wrap, 256-word blocks across thousands of queries)
+    and the legacy shuffle at shape scale against the reference itself, not against numpy alone.  One model runs with
+    chunks of 777 queries."""
+    from points2surf_amd import engine, parity, synth
+    path = os.path.join(golden_dir, 'ref_rec_%s_testset_grid128.npz' % model)
+    if not os.path.isfile(path):
+        pytest.skip('golden not generated yet: ' + os.path.basename(path))
+    ref = np.load(path)['rec_0']
+    w, cfg = synth.make_weights(model)
+    m = engine.Model(w, cfg)
+    cloud = engine.Cloud(fixture_cloud)
+    with open(os.path.join(golden_dir, 'meta.json')) as f:
+        seed = json.load(f)['seed_data']
+    rng, rng_patch = engine.Rng(seed), engine.Rng(seed)
+    sdf, q = engine.infer_shape(m, cloud, rng, 128, 3, rng_patch=rng_patch, chunk=chunk)
+    sdf = sdf.cpu().numpy()
+    assert sdf.shape == ref.shape == (68088,)
+    c = parity.compare_sdf(sdf, ref)
+    print('%s 128^3 (chunk %d): max|dSDF| %.3g, sign flips %d / %d, positive in the reference %.1f %%'
+          % (model, chunk, c['max_abs_dsdf'], c['flipped'].size, ref.size, 100.0 * (ref > 0).mean()))
+    assert c['max_abs_dsdf'] < 1e-4 and c['flipped'].size == 0
+    rng.check()
+    rng_patch.check()
+    m.close()
+    cloud.close()
+
+
 def test_radius_model_is_invariant_to_chunking_and_query_ranges(fixture_cloud):
     """size-independent property: where a query's random words start depends on the queries before it, never on how the
     pipeline batches them -- default chunks vs chunks of 777 queries vs two query ranges with the generators advanced

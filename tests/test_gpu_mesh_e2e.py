@@ -49,7 +49,15 @@ def _mesh(engine, torch, q, sdf, res):
     return vol.cpu().numpy(), v.cpu().numpy(), f.cpu().numpy(), iters
 
 
-CASES = [('p2s_max', 'testset', 128), ('p2s_vanilla', 'testset', 128), ('p2s_max', 'testset', 256),
+def _clouds(dataset):
+    from points2surf_amd import synth
+    if dataset == 'standin2':               # stand-in clouds (rotated + re-normalised fixtures), see tests/test_gpu_sizes.py
+        bases = [np.load(os.path.join(FIX, '04_pts', n + '.xyz.npy')) for n in sorted(_names('abc3'))]
+        return [synth.standin_cloud(bases[i], i) for i in range(2)]
+    return [np.load(os.path.join(FIX, '04_pts', n + '.xyz.npy')) for n in _names(dataset)]
+
+
+CASES = [('p2s_max', 'standin2', 64), ('p2s_vanilla', 'standin2', 64), ('p2s_max', 'testset', 128), ('p2s_vanilla', 'testset', 128), ('p2s_max', 'testset', 256),
          ('p2s_vanilla', 'testset', 256), ('p2s_max', 'abc3', 64), ('p2s_vanilla', 'abc3', 64), ('p2s_max', 'abc3', 256)]
 
 
@@ -65,10 +73,10 @@ def test_cloud_to_mesh_equals_scikit_image_on_the_reference_sdf(model_name, data
     w, cfg = synth.make_weights(model_name)
     model = engine.Model(w, cfg)
     rng = engine.Rng(SEED)
-    for i, name in enumerate(_names(dataset)):
+    for i, pts in enumerate(_clouds(dataset)):
         key = '%s_grid%d' % (model_name, res) if dataset == 'testset' else '%s_%s_%d_grid%d' % (model_name, dataset, i, res)
         m = meta[key]
-        cloud = engine.Cloud(np.load(os.path.join(FIX, '04_pts', name + '.xyz.npy')))
+        cloud = engine.Cloud(pts)
         sdf, q = engine.infer_shape(model, cloud, rng, res, 3)
         ref = g['rec_%d' % i]
         # (1) the reference's SDF -> the volume scikit-image was given -> scikit-image's mesh, on the device

@@ -34,6 +34,16 @@ def _golden(job, model, dataset, res):
     return np.load(path), meta
 
 
+def _clouds(dataset):
+    """the clouds of a dataset in order; ``standin2``: two stand-in clouds of SURVEY 8d configs 3-5 (the first two
+    abc_minimal clouds under seeded rotations, re-normalised: points2surf_amd/synth.py:standin_cloud, seeds 0 / 1)"""
+    from points2surf_amd import synth
+    if dataset == 'standin2':
+        bases = [np.load(os.path.join(FIX, '04_pts', n + '.xyz.npy')) for n in sorted(_names('abc3'))]
+        return [synth.standin_cloud(bases[i], i) for i in range(2)]
+    return [np.load(os.path.join(FIX, '04_pts', n + '.xyz.npy')) for n in _names(dataset)]
+
+
 def _run_dataset(model_name, dataset, res):
     """what points_to_surf_eval does for a dataset in reconstruction mode: one stream over all shapes"""
     import torch
@@ -42,8 +52,8 @@ def _run_dataset(model_name, dataset, res):
     model = engine.Model(w, cfg)
     rng = engine.Rng(SEED)
     out = []
-    for n in _names(dataset):
-        cloud = engine.Cloud(np.load(os.path.join(FIX, '04_pts', n + '.xyz.npy')))
+    for pts in _clouds(dataset):
+        cloud = engine.Cloud(pts)
         sdf, q = engine.infer_shape(model, cloud, rng, res, 3)
         torch.cuda.synchronize()
         out.append((sdf.cpu().numpy(), q.cpu().numpy()))
@@ -161,6 +171,18 @@ def test_three_clouds_one_stream_matches_reference(model, res):
     job = 'fulleval' if res == 32 else 'rec'
     g, meta = _golden(job, model, 'abc3', res)
     _compare(_run_dataset(model, 'abc3', res), g, meta)
+
+
+@pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
+def test_standin_clouds_match_reference(model):
+    """non-fixture geometry -- two STAND-IN clouds (abc_minimal clouds under
+    seeded random rotations, re-normalised to the unit cube like make_pc_dataset.py:20-36; other bounding boxes, cell
+    grids, query grids and MT masks than the fixtures) as one dataset at 64^3, against the unmodified reference.  Pins
+    the generator (synth.standin_cloud: the reference ran on the same arrays) and the path on them."""
+    g, meta = _golden('rec', model, 'standin2', 64)
+    out = _run_dataset(model, 'standin2', 64)
+    assert [o[0].shape[0] for o in out] == [s['queries'] for s in meta['shapes']]
+    _compare(out, g, meta)
 
 
 @pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
