@@ -81,7 +81,11 @@ typedef struct {
                                     this distance, a random points_per_patch of them if there are more, padded with the
                                     query point if fewer (reference source/base/point_cloud.py:177-191).  The float64
                                     value of the reference's Python float: the ball test is r * r in float64          */
-    int32_t reserved[4];
+    int32_t sym_sum;             /* train --sym_op sum (reference source/points_to_surf_model.py:170-175,211-214; set by no
+                                    experiment script): the pool of PointNetfeat is a SUM over the points instead of the
+                                    max.  The STN / QSTN trunks keep their max-pool in the reference too (:47, :106).
+                                    Not with single_transformer                                                     */
+    int32_t reserved[3];
 } p2s_model_cfg;
 
 /* Offsets (in floats) into the weight blob.  The blob holds BatchNorm-folded fp32 weights,

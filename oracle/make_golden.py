@@ -48,7 +48,7 @@ def train_namespace(cfg, batch=500):
         points_per_patch=int(cfg.get('points_per_patch', 300)), patch_center='mean', sub_sample_size=1000,
         patch_radius=float(cfg.get('patch_radius', 0.0)),
         uniform_subsample=int(cfg['uniform_subsample']), fixed_subsample=0, net_size=1024,
-        use_point_stn=int(cfg['use_point_stn']), use_feat_stn=int(cfg.get('use_feat_stn', True)), sym_op='max',
+        use_point_stn=int(cfg['use_point_stn']), use_feat_stn=int(cfg.get('use_feat_stn', True)), sym_op=cfg.get('sym_op', 'max'),
         single_transformer=int(cfg.get('single_transformer', False)), shared_transformer=int(cfg['shared_transformer']),
         batchSize=batch)
 

@@ -19,6 +19,8 @@ Jobs
             then the reconstruction pass.  The meshing / mesh-metric stages that follow (full_eval.py:51-75)
             need scikit-image + trimesh and are replaced by no-ops from the outside.
   rec       run ``points_to_surf_eval`` in reconstruction mode only.
+  recsample the same with ``--sampling sequential_shapes_random_patches --patches_per_shape 150`` (the sampler's own
+            RandomState picks 150 query indices per shape; the queries are evaluated in THAT order).
 Datasets: ``testset`` = abc_minimal/testset.txt (1 shape); ``abc3`` = all three abc_minimal shapes in one
 list (one dataset-wide RNG stream across the shapes, --workers 0); ``standin2`` = two stand-in clouds
 (points2surf_amd/synth.py:standin_cloud, rotation seeds 0 / 1) as one dataset.
@@ -101,6 +103,7 @@ def dataset_dir(tmp):
 
 
 STANDIN = 'standin2'        # two stand-in clouds as one dataset (non-fixture geometry: rotated bbox / cell grid / query grid)
+PATCHES_PER_SHAPE = 150     # job recsample
 SMALL = 'small800'          # 800 points: fewer than the sub-sample size -> shuffle + pad branch (utils.py:221-226)
 
 
@@ -145,6 +148,8 @@ def run(job, model, dataset, res, batch=500, fixed=0):
                 '--modeldir', modeldir, '--models', model, '--query_grid_resolution', str(res),
                 '--epsilon', '3', '--certainty_threshold', '13', '--sigma', '5', '--gpu_idx', '-1',
                 '--workers', '0', '--batchSize', str(batch), '--cache_capacity', '5']
+        if job == 'recsample':            # --sampling sequential_shapes_random_patches (source/points_to_surf_eval.py:126-136)
+            args += ['--sampling', 'sequential_shapes_random_patches', '--patches_per_shape', str(PATCHES_PER_SHAPE)]
         opt = ref_eval.parse_arguments(args)
         names = shapes_of(dataset)
         t0 = time.time()
@@ -173,6 +178,8 @@ def run(job, model, dataset, res, batch=500, fixed=0):
             d = np.load(os.path.join(res_root, 'rec', 'dist_ms', n + '.xyz.npy')).astype(np.float32)
             q = np.load(os.path.join(res_root, 'rec', 'query_pts_ms', n + '.xyz.npy'))
             out['rec_%d' % i] = d
+            if job == 'recsample':        # <outdir>/rec/<shape>.idx: the sampled query indices, in evaluation order
+                out['idx_%d' % i] = np.loadtxt(os.path.join(res_root, 'rec', n + '.idx'), dtype=np.int64).astype(np.int32)
             meta.setdefault('shapes', []).append({'name': n, 'queries': int(d.shape[0]), 'query_sha256': sha(q),
                                                   'pos_frac': float((d > 0).mean())})
             nq += d.shape[0]

@@ -420,8 +420,9 @@ def qstn_forward(x, w, pre):
     return quat_to_rotmat(quat), quat
 
 
-def pointnetfeat_forward(x, w, pre, use_point_stn, use_feat_stn=True, return_aux=False):
-    """source/points_to_surf_model.py:177-234 (num_scales=1, sym_op='max').
+def pointnetfeat_forward(x, w, pre, use_point_stn, use_feat_stn=True, return_aux=False, sym_op='max'):
+    """source/points_to_surf_model.py:177-234 (num_scales=1; sym_op 'max' or 'sum', :211-214 -- the STN / QSTN inside
+    keep their max-pool whatever sym_op says, :47, :106).
     x: [B, P, 3] (points-major).  Returns feature [B, net_size] (+ trans)."""
     trans = None
     if use_point_stn:
@@ -438,7 +439,7 @@ def pointnetfeat_forward(x, w, pre, use_point_stn, use_feat_stn=True, return_aux
     x = _relu(_bn(_conv(x, w, pre + '.conv1'), w, pre + '.bn1', 2))
     x = _relu(_bn(_conv(x, w, pre + '.conv2'), w, pre + '.bn2', 2))
     x = _bn(_conv(x, w, pre + '.conv3'), w, pre + '.bn3', 2)     # no ReLU before the pool
-    x = x.max(axis=1)
+    x = x.max(axis=1) if sym_op == 'max' else x.sum(axis=1, dtype=np.float32)      # torch.sum(x, 2, keepdim=True)
     if return_aux:
         return x, trans, aux
     return x, trans
@@ -457,6 +458,7 @@ def model_forward(w, cfg, patch_pts_ps, pts_sub_sample_ms, query_ms, chunk=32, r
     shared = bool(cfg.get('shared_transformer', False))
     use_feat_stn = bool(cfg.get('use_feat_stn', True))
     single = bool(cfg.get('single_transformer', False))
+    sym_op = cfg.get('sym_op', 'max')
     out = []
     feats = []
     for s in range(0, B, chunk):
@@ -465,7 +467,7 @@ def model_forward(w, cfg, patch_pts_ps, pts_sub_sample_ms, query_ms, chunk=32, r
             - np.asarray(query_ms[s:s + chunk], dtype=np.float32)[:, None, :]      # :303
         if single:                                                                # :320-323
             lg, _ = pointnetfeat_forward(np.concatenate([patch, shape], axis=1), w, 'feat_local_global',
-                                         use_point_stn, use_feat_stn)
+                                         use_point_stn, use_feat_stn, sym_op=sym_op)
             f = _relu(_bn(_fc(lg, w, 'fc1_local_global'), w, 'bn1_local_global', 1))
             f = _relu(_bn(_fc(f, w, 'fc2'), w, 'bn2', 1))
             f = _relu(_bn(_fc(f, w, 'fc3'), w, 'bn3', 1))
@@ -479,11 +481,11 @@ def model_forward(w, cfg, patch_pts_ps, pts_sub_sample_ms, query_ms, chunk=32, r
             shape = np.einsum('bij,bpj->bpi', trans, shape)
             patch = np.einsum('bij,bpj->bpi', trans, patch)
         g, trans_g = pointnetfeat_forward(shape, w, 'feat_global',
-                                          use_point_stn and not shared, use_feat_stn)   # :333
+                                          use_point_stn and not shared, use_feat_stn, sym_op=sym_op)   # :333
         gfc = _relu(_bn(_fc(g, w, 'fc1_global'), w, 'bn1_global', 1))                   # :335
         if use_point_stn and not shared:                                                # :337-339
             patch = np.einsum('bij,bpj->bpi', trans_g, patch)
-        l, _ = pointnetfeat_forward(patch, w, 'feat_local', False, use_feat_stn)        # :341
+        l, _ = pointnetfeat_forward(patch, w, 'feat_local', False, use_feat_stn, sym_op=sym_op)        # :341
         lfc = _relu(_bn(_fc(l, w, 'fc1_local'), w, 'bn1_local', 1))                     # :343
         f = np.concatenate([lfc, gfc], axis=1)                                          # :346
         f = _relu(_bn(_fc(f, w, 'fc2'), w, 'bn2', 1))

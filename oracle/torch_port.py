@@ -73,6 +73,8 @@ class TorchPort:
         x = self._conv_bn(x, pre + '.conv1', pre + '.bn1')
         x = self._conv_bn(x, pre + '.conv2', pre + '.bn2')
         x = self._conv_bn(x, pre + '.conv3', pre + '.bn3', relu=False)
+        if self.cfg.get('sym_op', 'max') == 'sum':               # reference source/points_to_surf_model.py:213-214
+            return torch.sum(x, 2)
         return x.max(dim=2)[0]
 
     @torch.no_grad()

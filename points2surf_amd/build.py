@@ -35,14 +35,14 @@ def _flags(extra_flags=()):
 
 
 def build(force=False, verbose=True, extra_flags=(), jobs=None):
-    """one object per translation unit under csrc/_obj/ (rebuilt when the source, a header or the flags changed), linked
+    """one object per translation unit under <repo>/build/obj/ (rebuilt when the source, a header or the flags changed), linked
     into libp2s_hip.so; ``force`` recompiles everything"""
     import concurrent.futures
     import hashlib
     if not force and not needs_build():
         return LIB
     flags = _flags(extra_flags)
-    objdir = os.path.join(CSRC, '_obj')
+    objdir = os.path.join(os.path.dirname(HERE), 'build', 'obj')          # (build/ is git- and gpurun-ignored)
     os.makedirs(objdir, exist_ok=True)
     headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inl')) + \
         glob.glob(os.path.join(os.path.dirname(HERE), 'include', '*.h'))

@@ -91,6 +91,11 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
         p2s_set_error("p2s_model_create: unsupported cfg (net_size=%d output_dim=%d)", cfg->net_size, cfg->output_dim);
         return P2S_EINVAL;
     }
+    if (cfg->sym_sum && cfg->single_transformer) {
+        p2s_set_error("p2s_model_create: sym_op='sum' with single_transformer is not built (the pool of the one encoder over "
+                      "both point sets is combined as a max of the two branches)");
+        return P2S_EINVAL;
+    }
     if (p2s_device_count() <= device || device < 0) {
         p2s_set_error("p2s_model_create: no HIP device %d", device);
         return P2S_ENODEVICE;
@@ -379,11 +384,16 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         g.C = w.T; g.ldc = 4096; g.c_z = (long long)C * 4096; g.N = 4096; g.K = 256;
         if ((rc = p2s_launch_gemm(g, s))) return rc;
         FoldArgs f;
+        memset(&f, 0, sizeof(f));
         for (int e = 0; e < 2; ++e) {
             f.T[e] = w.T + (size_t)e * C * 4096;
             f.m1t[e] = W + o.enc[e].m1t;
             f.out[e] = w.w1p + (size_t)e * C * 4096;
+            f.outh[e] = bf16 ? w.w1h + (size_t)e * C * 4096 : nullptr;      // 16-bit modes: pieces written by the fold itself
         }
+        f.h_piece_stride = (long long)2 * C * 4096;
+        f.ns = p2s_enc_pieces(m->cfg);
+        f.f16 = p2s_enc_f16(m->cfg);
         f.n_items = C;
         if ((rc = p2s_launch_fold(f, s))) return rc;
     }
@@ -398,15 +408,13 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         b.w2 = W + eo.m2; b.b2 = W + eo.mb2; b.w3 = W + eo.m3; b.b3 = W + eo.mb3;
         b.out = w.feat + (size_t)e * C * 1024;
         b.relu_out = 0;
+        b.pool_sum = m->cfg.sym_sum ? 1 : 0;        // sym_op='sum': PointNetfeat's pool only (the STN / QSTN trunks keep the max)
         if (bf16) {
             b.w1 = reinterpret_cast<const float *>(w.w1h + (size_t)e * C * 4096);
             b.w2 = reinterpret_cast<const float *>(m->blob_h + m->h_m2[e]);
             b.w3 = reinterpret_cast<const float *>(m->blob_h + m->h_m3[e]);
         }
     }
-    for (int piece = 0; bf16 && piece < p2s_enc_pieces(m->cfg); ++piece)
-        if ((rc = p2s_launch_pack_bf16(w.w1p, w.w1h + (size_t)piece * 2 * C * 4096, 64, 64, 4096, 4096, 2 * C, piece,
-                                       p2s_enc_f16(m->cfg), s))) return rc;
     if ((rc = bf16 ? p2s_launch_chain_bf16(a, s) : p2s_launch_chain(a, s))) return rc;
     const int ev3 = p2s_prof_mark(m, s);
     m->counters.launches_chain += 2;

@@ -133,6 +133,34 @@ __device__ __forceinline__ float half_max(float m) {
     return o;
 }
 
+// sym_op='sum' (reference source/points_to_surf_model.py:213-214): sum over the VALID rows of the two row tiles of one
+// output column.  Rows past the item's last point replicate that point (harmless for a max) and are masked here.
+// Plain C++: the compiler pads the XDL-write -> VALU-read hazard itself and adds need no sNaN quieting.
+__device__ __forceinline__ float tile_colsum(const f32x16 &a, const f32x16 &b, int nvalid, int lane) {
+    float s = 0.0f;
+    if (nvalid >= 64) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += a[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += b[i];
+    } else {
+        const int r0 = 4 * (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + (i & 3) + 8 * (i >> 2);
+            s += (r < nvalid) ? a[i] : 0.0f;
+            s += (r + 32 < nvalid) ? b[i] : 0.0f;
+        }
+    }
+    return s;
+}
+__device__ __forceinline__ float half_sum(float m) {
+    const unsigned u = __float_as_uint(m);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <bool SUM>
 __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
     __shared__ __attribute__((aligned(16))) float smem[MT * SA + MT * SB];
     float *bufA = smem;
@@ -171,7 +199,7 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
 
     float rmax[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rmax[i] = -INFINITY;
+    for (int i = 0; i < 8; ++i) rmax[i] = SUM ? 0.0f : -INFINITY;
     // torch's conv/ReLU/MaxPool propagate NaN (a non-finite coordinate poisons every channel of the
     // item); v_max_f32 does not.  Track non-finite inputs and poison the pooled output instead.
     bool bad = false;
@@ -345,15 +373,22 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
                 P2S_FETCH(bA0, bA1, aA0, aA1, prn, 0)
                 P2S_MFMA16(aB0, aB1, bB0, bB1)
                 P2S_SPREAD()
-                float m0 = tile_colmax(c00, c10);
-                float m1 = tile_colmax(c01, c11);
-                m0 = half_max(m0);
-                m1 = half_max(m1);
+                float m0, m1;
+                if constexpr (SUM) {
+                    const int nvalid = P - tile * MT;       // rows of this tile that are points of the item
+                    m0 = half_sum(tile_colsum(c00, c10, nvalid, lane));
+                    m1 = half_sum(tile_colsum(c01, c11, nvalid, lane));
+                } else {
+                    m0 = half_max(tile_colmax(c00, c10));
+                    m1 = half_max(tile_colmax(c01, c11));
+                }
+#define P2S_POOL(dst, v) dst = SUM ? dst + (v) : fmaxf(dst, (v))
                 // static register indexing (runtime-indexed arrays would go to scratch)
-                if (pr == 0) { rmax[0] = fmaxf(rmax[0], m0); rmax[1] = fmaxf(rmax[1], m1); }
-                else if (pr == 1) { rmax[2] = fmaxf(rmax[2], m0); rmax[3] = fmaxf(rmax[3], m1); }
-                else if (pr == 2) { rmax[4] = fmaxf(rmax[4], m0); rmax[5] = fmaxf(rmax[5], m1); }
-                else { rmax[6] = fmaxf(rmax[6], m0); rmax[7] = fmaxf(rmax[7], m1); }
+                if (pr == 0) { P2S_POOL(rmax[0], m0); P2S_POOL(rmax[1], m1); }
+                else if (pr == 1) { P2S_POOL(rmax[2], m0); P2S_POOL(rmax[3], m1); }
+                else if (pr == 2) { P2S_POOL(rmax[4], m0); P2S_POOL(rmax[5], m1); }
+                else { P2S_POOL(rmax[6], m0); P2S_POOL(rmax[7], m1); }
+#undef P2S_POOL
             }
 #undef P2S_MFMA16
 #undef P2S_MFMA16_FIRST
@@ -370,7 +405,7 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
         const float *b3 = br.b3 + 256 * wave + lane;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            float v = rmax[t] + b3[32 * t];
+            float v = rmax[t] + (SUM ? (float)P * b3[32 * t] : b3[32 * t]);     // sum: the bias once per point
             if (br.relu_out) v = fmaxf(v, 0.0f);
             if (any_bad) v = __builtin_nanf("");
             out[32 * t] = v;
@@ -402,6 +437,39 @@ __global__ __launch_bounds__(256) void p2s_fold_kernel(FoldArgs args) {
             acc = mfma32(a, b[t], acc);
         }
     }
+    unsigned short *outh = args.outh[e];
+    if (outh) {
+        // 16-bit fragment order: element (k, n) sits at [n / 32][k / 16][lane' = 32 ((k / 8) & 1) + n % 32][k % 8]; this
+        // lane holds k = 32 jt + 8 g + 4 kk + t, t = 0..3: four consecutive halfs (8 bytes) per k-group g and piece
+        outh += (long long)item * 4096;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int kg = 4 * jt + g;
+            unsigned short *dst = outh + ((ot * 4 + (kg >> 1)) * 64 + (kg & 1) * 32 + (lane & 31)) * 8 + 4 * kk;
+            float x[4] = {acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            for (int q = 0; q < args.ns; ++q) {
+                unsigned short h[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (args.f16) {                    // fp16 pair: h0 = fp16(x); h1 = fp16((x - h0) * 2^11)
+                        const _Float16 h0 = (_Float16)x[t];
+                        h[t] = __builtin_bit_cast(unsigned short, h0);
+                        x[t] = (x[t] - (float)h0) * 2048.0f;
+                    } else {                           // bf16 pieces: round to nearest even of the residual
+                        unsigned u = __float_as_uint(x[t]);
+                        u += 0x7fffu + ((u >> 16) & 1u);
+                        h[t] = (unsigned short)(u >> 16);
+                        x[t] -= __uint_as_float((unsigned)h[t] << 16);
+                    }
+                }
+                uint2 pk;
+                pk.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+                pk.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+                *reinterpret_cast<uint2 *>(dst + (long long)q * args.h_piece_stride) = pk;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 v = {acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
@@ -422,7 +490,11 @@ int p2s_launch_chain(const ChainArgs &args_in, hipStream_t stream) {
     args.ablate = ablate;
     padlds = pad_env;
 #endif
-    hipLaunchKernelGGL(p2s_chain_kernel, dim3(n), dim3(256), padlds, stream, args);
+    // both branches of a launch pool alike (pass 2 of a sym_op='sum' model: sum; every other launch: max)
+    if (args.br[0].pool_sum || (args.br[1].n_items > 0 && args.br[1].pool_sum))
+        hipLaunchKernelGGL(p2s_chain_kernel<true>, dim3(n), dim3(256), padlds, stream, args);
+    else
+        hipLaunchKernelGGL(p2s_chain_kernel<false>, dim3(n), dim3(256), padlds, stream, args);
     P2S_LAUNCH_CHECK("p2s_chain_kernel");
     return P2S_OK;
 }

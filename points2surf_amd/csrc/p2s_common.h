@@ -64,6 +64,7 @@ struct ChainBranch {
     int n_items;
     int relu_out;            // ReLU after the pooled affine (STN trunks) or not (PointNetfeat.conv3)
     int short_chain;         // 1: 3->64->128->1024 (QSTN trunk), 0: 3->64->64->64->128->1024
+    int pool_sum;            // 1: the pool over the points is a SUM (sym_op='sum', main trunk only), out = sum + P * b3; 0: max
 };
 struct ChainArgs {
     ChainBranch br[2];       // br[0] items come first in the grid
@@ -86,8 +87,14 @@ int p2s_launch_pack_bf16(const float *src, unsigned short *dst, int K, int N, lo
 struct FoldArgs {
     const float *T[2];       // [n_items][64*64]   (I + fc3 output), row-major T[i][j]
     const float *m1t[2];     // packed conv1 weights
-    float *out[2];           // [n_items][4096] packed
+    float *out[2];           // [n_items][4096] packed (fp32 fragments; unused when outh is set)
     int n_items;
+    // 16-bit encoder modes: W1' goes straight out as the chain kernel's 16-bit B fragments ([N/32][K/16][64 lanes][8]),
+    // split into its pieces here (what p2s_pack_bf16_kernel did in 2 * ns extra launches per chunk): piece q of encoder e
+    // item i at outh[e] + q * h_piece_stride + i * 4096 halfs.  ns pieces; f16: fp16 pair (h0, (x - h0) * 2^11)
+    unsigned short *outh[2];
+    long long h_piece_stride;
+    int ns, f16;
 };
 int p2s_launch_fold(const FoldArgs &args, hipStream_t stream);
 

@@ -64,7 +64,8 @@ def parse_arguments(args=None):
     parser.add_argument('--parampostfix', type=str, default='_params.pth', help='parameter file postfix')
     parser.add_argument('--gpu_idx', type=int, default=0, help='GPU index (the engine has no CPU path)')
     parser.add_argument('--sparse_patches', type=int, default=False, help='unused by the reconstruction path')
-    parser.add_argument('--sampling', type=str, default='full', help='sampling strategy: full')
+    parser.add_argument('--sampling', type=str, default='full',
+                        help='sampling strategy, any of [full, sequential_shapes_random_patches]')
     parser.add_argument('--patches_per_shape', type=int, default=1000, help='only for random-patch sampling')
     parser.add_argument('--query_points_per_patch', type=int, default=1, help='number of query points per patch')
     parser.add_argument('--sub_sample_size', type=int, default=500, help='overridden by the training parameters')
@@ -172,6 +173,25 @@ def _save_shape(model_out_dir, shape_name, sdf_np, q_np, reconstruction=True):
     _visualize_query_points(q_np, sdf_np, os.path.join(model_out_dir, 'query_pts_ms_vis', shape_name + '.ply'))
 
 
+def _save_sampled_shape(model_out_dir, shape_name, sdf_np, q_sel, q_all, picked, reconstruction):
+    """the files of save_evaluation for ``--sampling sequential_shapes_random_patches`` (reference :263-294): the values of
+    the SAMPLED queries in evaluation order, ``<shape>.idx`` with their indices, and (reconstruction) ALL query points
+    beside them, as the reference writes them.  The reference hands all N query points with the M sampled distances to
+    sdf.visualize_query_points -- arrays of different length; the visualisations here show the sampled points."""
+    from points2surf_amd import writers
+    os.makedirs(os.path.join(model_out_dir, 'eval'), exist_ok=True)
+    np.save(os.path.join(model_out_dir, 'eval', shape_name + '.xyz.npy'), sdf_np)
+    writers.savetxt_f32(os.path.join(model_out_dir, 'eval', shape_name + '.xyz.txt'), sdf_np)
+    _visualize_query_points(q_sel, sdf_np, os.path.join(model_out_dir, 'vis', shape_name + '.ply'))
+    if reconstruction:
+        os.makedirs(os.path.join(model_out_dir, 'query_pts_ms'), exist_ok=True)
+        np.save(os.path.join(model_out_dir, 'query_pts_ms', shape_name + '.xyz.npy'), q_all)
+        os.makedirs(os.path.join(model_out_dir, 'dist_ms'), exist_ok=True)
+        np.save(os.path.join(model_out_dir, 'dist_ms', shape_name + '.xyz.npy'), sdf_np)
+        _visualize_query_points(q_sel, sdf_np, os.path.join(model_out_dir, 'query_pts_ms_vis', shape_name + '.ply'))
+    np.savetxt(os.path.join(model_out_dir, shape_name + '.idx'), picked, fmt='%d')
+
+
 def _write_part(model_out_dir, shape_name, rank, sdf_np, q_np):
     """query-range sharding: this rank's ordered piece of a shape (atomic: visible only when complete)"""
     pdir = os.path.join(model_out_dir, '.parts')
@@ -219,8 +239,9 @@ def points_to_surf_eval(eval_opt):
     if eval_opt.gpu_idx < 0:
         raise RuntimeError('points2surf_amd: --gpu_idx < 0 (CPU) is not available; the HIP engine needs an MI355X')
     reconstruction = bool(eval_opt.reconstruction)
-    if eval_opt.sampling != 'full':
-        raise ValueError('Unknown sampling strategy: %s' % eval_opt.sampling)
+    if eval_opt.sampling not in ('full', 'sequential_shapes_random_patches'):
+        raise ValueError('Unknown sampling strategy: %s' % eval_opt.sampling)          # reference :137-138
+    random_patches = eval_opt.sampling == 'sequential_shapes_random_patches'
     if reconstruction and (eval_opt.query_grid_resolution is None or eval_opt.epsilon is None):
         raise ValueError('reconstruction needs --query_grid_resolution and --epsilon')
 
@@ -295,7 +316,34 @@ def points_to_surf_eval(eval_opt):
                 import shutil
                 shutil.rmtree(os.path.join(model_out_dir, '.parts'), ignore_errors=True)
             _sharding.barrier()
+        # --sampling sequential_shapes_random_patches (reference :126-136; source/data_loader.py:88-139): the sampler's
+        # OWN RandomState(seed) picks min(patches_per_shape, count) query indices per shape with
+        # ``choice(range(start, end), size, replace=False)`` over the data set's global patch indices, and the queries
+        # are evaluated in THAT order (the sub-sample stream is consumed in it).  Host logic, numpy's own generator.
+        sampler_rng = np.random.RandomState(eval_opt.seed) if random_patches else None
+        sampler_start = 0
         for shape_ind, shape_name in enumerate(shape_names):
+            if random_patches:
+                if rank != 0:
+                    continue               # a few hundred queries per shape: rank 0 alone
+                if ball and reconstruction:
+                    raise ValueError('sampling sequential_shapes_random_patches in reconstruction mode is not built for '
+                                     'fixed-radius models')
+                cloud = _engine.Cloud(_load_points(eval_opt.indir, shape_name), device=device)
+                q_all = cloud.query_grid(eval_opt.query_grid_resolution, eval_opt.epsilon).cpu().numpy() if reconstruction \
+                    else _load_query_points(eval_opt.indir, shape_name)
+                count = int(q_all.shape[0])
+                picked = sampler_rng.choice(range(sampler_start, sampler_start + count),
+                                            size=min(int(eval_opt.patches_per_shape), count), replace=False) - sampler_start
+                sampler_start += count
+                q_sel = np.ascontiguousarray(q_all[picked])
+                sdf = _engine.infer_queries(model, cloud, rng_dev, rng_rot, _engine.upload(q_sel, device), chunk=chunk)
+                sdf_np = sdf.cpu().numpy()
+                total_q += sdf_np.shape[0]
+                pending.append(writers.submit(_save_sampled_shape, model_out_dir, shape_name, sdf_np, q_sel, q_all, picked,
+                                              reconstruction))
+                cloud.close()
+                continue
             if not reconstruction:
                 # GT-query pass: a few thousand given queries per shape and two dataset-wide streams -- rank 0 runs it
                 # alone (sharding it would cost more in stream skipping than the pass itself)

@@ -55,9 +55,11 @@ class PointsToSurfModel(nn.Module):
                  sym_op='max', use_query_point=False,
                  sub_sample_size=500, do_augmentation=True, single_transformer=False, shared_transformation=False):
         super(PointsToSurfModel, self).__init__()
-        if sym_op not in ('max',):
-            # the reference accepts 'sum' too; the engine implements the published models ('max')
-            raise ValueError('Unsupported symmetric operation: %s' % sym_op)
+        if sym_op not in ('max', 'sum'):
+            raise ValueError('Unsupported symmetric operation: %s' % sym_op)        # reference :175
+        if sym_op == 'sum' and single_transformer:
+            raise ValueError("sym_op='sum' with single_transformer is not built (no script of the reference sets either)")
+        self.sym_op = sym_op
         self.net_size_max = net_size_max
         self.num_points = num_points
         self.output_dim = output_dim
@@ -98,7 +100,7 @@ class PointsToSurfModel(nn.Module):
         return dict(net_size=self.net_size_max, points_per_patch=self.num_points,
                     sub_sample_size=self.sub_sample_size, output_dim=self.output_dim,
                     use_point_stn=self.use_point_stn, shared_transformer=self.shared_transformation,
-                    use_feat_stn=self.use_feat_stn, single_transformer=self.single_transformer, sym_op='max')
+                    use_feat_stn=self.use_feat_stn, single_transformer=self.single_transformer, sym_op=self.sym_op)
 
     def _engine(self, device):
         # the packed weight blob is rebuilt when the parameters change (load_state_dict, .to(), in-place edits)

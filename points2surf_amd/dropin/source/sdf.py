@@ -19,6 +19,7 @@ context cannot be used from the forked ``multiprocessing.Pool`` workers of sourc
 import importlib.util
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -27,6 +28,7 @@ import source as _pkg
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _IMPORT_PID = os.getpid()
+_DEVICE_STAGE = threading.Lock()
 
 
 def _load_reference_sdf():
@@ -101,29 +103,34 @@ def implicit_surface_to_mesh(query_dist_ms, query_pts_ms, volume_out_file, mc_ou
     if query_dist_ms.max() == 0.0 and query_dist_ms.min() == 0.0:
         print('WARNING: implicit surface for {} contains only zeros'.format(volume_out_file))
         return
-    start = time.time()
-    volume, _ = engine.sdf_volume(np.asarray(query_pts_ms), query_dist_ms, grid_res, sigma, certainty_threshold, clamp=True)
-    torch.cuda.synchronize()
-    print('Sign propagation took: {}'.format(time.time() - start))
+    # the device stages of one shape at a time (the library's volume / iso-surface scratch is per device); the host work
+    # around them runs in parallel when implicit_surface_to_mesh_directory uses several threads
+    with _DEVICE_STAGE:
+        start = time.time()
+        volume, _ = engine.sdf_volume(np.asarray(query_pts_ms), query_dist_ms, grid_res, sigma, certainty_threshold, clamp=True)
+        torch.cuda.synchronize()
+        print('Sign propagation took: {}'.format(time.time() - start))
+        # reference :211-229: mesh only if the volume holds both signs; an iso-surface without a 0-level set is empty, so
+        # the extraction itself answers that (no separate min / max pass over the volume)
+        start = time.time()
+        v, f, _ = engine.marching_cubes(volume, model_space=True, fix_inversion=True)
+        torch.cuda.synchronize()
+        print('Marching Cubes took: {}'.format(time.time() - start))
+        v_np, f_np = v.cpu().numpy(), f.cpu().numpy()
+        del volume, v, f
 
     # green = inside; red = outside (the reference's debug output of the samples, :203-209 -> mesh_io.write_off,
     # source/base/mesh_io.py:75-140): the same bytes from the native host writer (p2s_write_coff_samples) instead of a
     # Python loop with six str() calls per sample (seconds per 256^3 shape)
     writers.coff_samples(volume_out_file, np.asarray(query_pts_ms), query_dist_ms)
 
-    # reference :211-229: mesh only if the volume holds both signs; an iso-surface without a 0-level set is empty, so
-    # the extraction itself answers that (no separate min / max pass over the volume)
-    start = time.time()
-    v, f, _ = engine.marching_cubes(volume, model_space=True, fix_inversion=True)
-    torch.cuda.synchronize()
-    print('Marching Cubes took: {}'.format(time.time() - start))
-    if v.shape[0] == 0 and f.shape[0] == 0:
+    if v_np.shape[0] == 0 and f_np.shape[0] == 0:
         print('Warning: volume for marching cubes contains no 0-level set!')
     else:
         if os.path.dirname(mc_out_file):
             os.makedirs(os.path.dirname(mc_out_file), exist_ok=True)
         # trimesh.Trimesh(vertices=v, faces=f) of the reference (:224) merges coincident vertices before the export
-        mv, mf = ply.merge_vertices(v.cpu().numpy(), f.cpu().numpy())
+        mv, mf = ply.merge_vertices(v_np, f_np)
         ply.write_ply(mc_out_file, mv, mf)
 
 
@@ -145,8 +152,11 @@ def _call_necessary(files_in, files_out):
 
 def implicit_surface_to_mesh_directory(imp_surf_dist_ms_dir, query_pts_ms_dir, vol_out_dir, mesh_out_dir,
                                        grid_res, sigma, certainty_threshold, num_processes=1):
-    """reference :240-266 with the per-shape calls made serially in THIS process (``num_processes`` is accepted and
-    ignored: one shape's propagation + iso-surface takes milliseconds on the device, 149 s on a CPU core at 256^3)"""
+    """reference :240-266.  The reference forks ``num_processes`` workers (source/base/utils_mp.py:33-35), each running
+    149 s of sign propagation per 256^3 shape on a CPU core; here a shape's propagation + iso-surface takes milliseconds
+    on the device and what is left is host work -- loading the arrays, the coloured-samples ``.off``, the vertex merge and
+    the PLY export -- which ``num_processes`` THREADS of this process share (a HIP context does not survive a fork; the
+    native writers and numpy release the GIL)."""
     os.makedirs(vol_out_dir, exist_ok=True)
     os.makedirs(mesh_out_dir, exist_ok=True)
     dist_files = sorted(f for f in os.listdir(imp_surf_dist_ms_dir)
@@ -155,11 +165,27 @@ def implicit_surface_to_mesh_directory(imp_surf_dist_ms_dir, query_pts_ms_dir, v
     # every rank), nobody writes a file another rank writes
     from points2surf_amd import sharding
     world, rank, _ = sharding.dist_env()
+    calls = []
     for f in dist_files[rank::world] if world > 1 else dist_files:
         f_dist, f_query = os.path.join(imp_surf_dist_ms_dir, f), os.path.join(query_pts_ms_dir, f)
         f_vol, f_mesh = os.path.join(vol_out_dir, f[:-8] + '.off'), os.path.join(mesh_out_dir, f[:-8] + '.ply')
         if _call_necessary([f_dist, f_query], [f_vol, f_mesh]):
-            implicit_surface_to_mesh_file(f_dist, f_query, f_vol, f_mesh, grid_res, sigma, certainty_threshold)
+            calls.append((f_dist, f_query, f_vol, f_mesh, grid_res, sigma, certainty_threshold))
+    n_threads = max(1, min(int(num_processes or 1), len(calls), 16))
+    if n_threads <= 1:
+        for c in calls:
+            implicit_surface_to_mesh_file(*c)
+    else:
+        import concurrent.futures
+        import torch
+        dev = torch.cuda.current_device()
+
+        def work(c):
+            torch.cuda.set_device(dev)             # the current device is per thread
+            implicit_surface_to_mesh_file(*c)
+        with concurrent.futures.ThreadPoolExecutor(max_workers=n_threads) as ex:
+            for fut in [ex.submit(work, c) for c in calls]:
+                fut.result()                       # re-raise a worker's error
     if world > 1:
         sharding.barrier()               # the metrics stage that follows reads every rank's meshes
 

@@ -36,6 +36,9 @@ NAMED_MODELS = {
     # (source/base/point_cloud.py:177-191)
     # train --use_feat_stn 0 (no script of the reference sets it): p2s_max without the 64x64 feature transforms
     'p2s_max_no_feat_stn': dict(use_point_stn=False, shared_transformation=False, uniform_subsample=True, use_feat_stn=False),
+    # train --sym_op sum (set by no script of the reference): PointNetfeat pools with a sum over the points
+    # (source/points_to_surf_model.py:170-175, :211-214); the STN / QSTN trunks keep their max-pool
+    'p2s_max_sum': dict(use_point_stn=False, shared_transformation=False, uniform_subsample=True, sym_op='sum'),
     'p2s_small_radius': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, patch_radius=0.05),
     'p2s_medium_radius': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, patch_radius=0.1),
     'p2s_large_radius': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, patch_radius=0.2),

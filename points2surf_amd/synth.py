@@ -19,7 +19,8 @@ _FC4_BIAS_SHIFT = {'p2s_max': (6.289174, 2.416443), 'p2s_vanilla': (2.6854432, 4
                    'p2s_uniform': (4.6575, 2.458), 'p2s_no_qstn': (2.3863, 1.8502), 'p2s_small_kNN': (4.2235, 2.2435),
                    'p2s_large_kNN': (4.9557, 2.6857), 'p2s_regression': (3.7676,), 'p2s_shared_encoder': (-0.2, -3.9804),
                    'p2s_small_radius': (2.6671, 1.4694), 'p2s_medium_radius': (3.4947, 2.3483),
-                   'p2s_large_radius': (3.9348, 2.7203), 'p2s_max_no_feat_stn': (0.1092, 2.8237)}
+                   'p2s_large_radius': (3.9348, 2.7203), 'p2s_max_no_feat_stn': (0.1092, 2.8237),
+                   'p2s_max_sum': (3.3387, 1.0881)}
 
 
 # Second synthetic weight set of p2s_vanilla: the same weights with the bias of the SIGN logit moved by the median of
@@ -77,6 +78,13 @@ def make_weights(model='p2s_max', seed=1234, net_size_max=1024, output_dim=None)
         if name.endswith('stn1.fc3.weight') or name.endswith('stn1.fc3.bias') \
                 or name.startswith('point_stn.fc3.'):
             w[name] = (w[name] * np.float32(0.2)).astype(np.float32)
+    # sym_op='sum': the pooled feature is a sum over 300 / 1000 points -- scale the affine in front of the pool so that
+    # the features (and with them the logits) stay O(1) like those of the max models
+    if cfg.get('sym_op', 'max') == 'sum':
+        for pre, npts in (('feat_local', 300.0), ('feat_global', 1000.0)):
+            for leaf in ('weight', 'bias'):
+                if pre + '.bn3.' + leaf in w:
+                    w[pre + '.bn3.' + leaf] = (w[pre + '.bn3.' + leaf] / np.float32(npts)).astype(np.float32)
     # centre the two output logits (the random decoder has a data-dependent offset much larger than
     # its spread; measured once on the abc_minimal fixture) so that tanh is not saturated and the
     # sign logit changes sign across queries
@@ -89,7 +97,7 @@ def make_weights(model='p2s_max', seed=1234, net_size_max=1024, output_dim=None)
         use_feat_stn=bool(cfg.get('use_feat_stn', True)), single_transformer=single,
         uniform_subsample=bool(cfg.get('uniform_subsample', False)), fixed_subsample=False,
         net_size=net_size_max, points_per_patch=int(cfg.get('points_per_patch', 300)), sub_sample_size=1000,
-        output_dim=output_dim, patch_radius=float(cfg.get('patch_radius', 0.0)))
+        output_dim=output_dim, patch_radius=float(cfg.get('patch_radius', 0.0)), sym_op=cfg.get('sym_op', 'max'))
     return w, cfg_out
 
 

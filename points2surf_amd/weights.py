@@ -44,7 +44,7 @@ class ModelCfg(ctypes.Structure):
                 ('use_point_stn', ctypes.c_int32), ('shared_transformer', ctypes.c_int32),
                 ('weighted_subsample', ctypes.c_int32), ('encoder_bf16', ctypes.c_int32),
                 ('fixed_subsample', ctypes.c_int32), ('single_transformer', ctypes.c_int32),
-                ('patch_radius', ctypes.c_double), ('reserved', ctypes.c_int32 * 4)]
+                ('patch_radius', ctypes.c_double), ('sym_sum', ctypes.c_int32), ('reserved', ctypes.c_int32 * 3)]
 
 
 def _np(v):
@@ -148,8 +148,11 @@ def build_blob(state_dict, cfg):
                 w[s + '.' + bn + '.running_mean'] = np.zeros(c, np.float32)
                 w[s + '.' + bn + '.running_var'] = np.ones(c, np.float32)
     single = bool(cfg.get('single_transformer', False))
-    if cfg.get('sym_op', 'max') != 'max':
-        raise ValueError("Unsupported symmetric operation: %s" % cfg.get('sym_op'))
+    sym_op = cfg.get('sym_op', 'max')
+    if sym_op not in ('max', 'sum'):
+        raise ValueError("Unsupported symmetric operation: %s" % sym_op)        # reference points_to_surf_model.py:175
+    if sym_op == 'sum' and single:
+        raise ValueError("sym_op='sum' with single_transformer: not built (no script of the reference sets either with the other)")
 
     blob = _Blob()
     offs = WeightOffsets()
@@ -202,6 +205,7 @@ def build_blob(state_dict, cfg):
     mc.weighted_subsample = int(not bool(cfg.get('uniform_subsample', False)))
     mc.fixed_subsample = int(bool(cfg.get('fixed_subsample', False)))
     mc.single_transformer = int(single)
+    mc.sym_sum = int(sym_op == 'sum')
     mc.patch_radius = max(float(cfg.get('patch_radius', 0.0) or 0.0), 0.0)     # the float64 of the reference's Python float
     mc.encoder_bf16 = int(cfg.get('encoder_bf16', 0) or 0)      # 0 fp32, 1 bf16, 2 / 3 split bf16 (pieces per operand), 4 fp16 pair
     if mc.output_dim not in (1, 2):

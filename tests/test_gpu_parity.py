@@ -197,6 +197,31 @@ def test_forward_matches_oracle_ragged_batches(name, B, fixture_cloud, torch_cud
     assert np.abs(sdf.cpu().numpy() - O.post_process(ref, r)).max() < SDF_TOL_TIGHT
 
 
+@pytest.mark.parametrize('k', [64, 75, 96, 300])
+def test_sum_pool_masks_the_padded_rows_of_the_last_point_tile(k, fixture_cloud, torch_cuda):
+    """sym_op='sum' (reference source/points_to_surf_model.py:213-214): the last 64-point tile of an item is padded with
+    copies of its last point -- harmless for a max, wrong for a sum unless masked.  Patches of 64 (no padding), 75 (11
+    valid rows: row block 1 empty), 96 (exactly one row block) and 300 points; the 1000-point sub-sample ends with 40
+    valid rows.  Against the numpy restatement of the reference's forward."""
+    from oracle import p2s_oracle as O
+    from points2surf_amd import engine, synth
+    w, cfg = synth.make_weights('p2s_max_sum')
+    cfg = dict(cfg, points_per_patch=k)
+    model = engine.Model(w, cfg)
+    B = 37
+    rng = np.random.default_rng(k)
+    q = (fixture_cloud[rng.integers(0, fixture_cloud.shape[0], B)] + rng.normal(0, 0.01, (B, 3))).astype(np.float32)
+    ids = O.knn_ids(fixture_cloud, q, k)
+    r, ps = O.patch_radius_and_ps(fixture_cloud, ids, q)
+    sub = fixture_cloud[rng.integers(0, fixture_cloud.shape[0], (B, 1000))]
+    ref = O.model_forward(w, cfg, ps, sub, q)
+    t = lambda a: torch_cuda.from_numpy(np.ascontiguousarray(a)).cuda()
+    logits, sdf = model.forward(t(ps), t(sub), t(q), t(r), want_logits=True, want_sdf=True)
+    assert np.abs(logits.cpu().numpy() - ref).max() < LOGIT_TOL, np.abs(logits.cpu().numpy() - ref).max()
+    assert np.abs(sdf.cpu().numpy() - O.post_process(ref, r)).max() < SDF_TOL_TIGHT
+    model.close()
+
+
 def test_nan_input_maps_to_one(model_max, fixture_cloud, torch_cuda):
     model, w, cfg = model_max
     B = 2

@@ -173,6 +173,39 @@ def test_three_clouds_one_stream_matches_reference(model, res):
     _compare(_run_dataset(model, 'abc3', res), g, meta)
 
 
+@pytest.mark.parametrize('encoder', [0, 3, 4])
+def test_sym_op_sum_matches_reference(encoder):
+    """train --sym_op sum (reference source/points_to_surf_model.py:170-175, :211-214; set by no experiment script, the
+    last constructor branch of the model): PointNetfeat pools with ``torch.sum(x, 2)``, its STN keeps the max-pool.  The
+    engine sums in the MFMA accumulators' row layout with the padded rows of the last point tile masked, and adds the
+    bias once per point.  Whole grid-32 shape against the unmodified reference -- the fp32 kernel, the split bf16x3
+    kernel and the fp16 pair kernel (three code paths)."""
+    import torch
+    from points2surf_amd import engine, synth
+    key = 'ref_rec_p2s_max_sum_testset_grid32'
+    if not os.path.isfile(os.path.join(GOLDEN, key + '.npz')):
+        pytest.skip(key + ' not generated')
+    ref = np.load(os.path.join(GOLDEN, key + '.npz'))['rec_0']
+    w, cfg = synth.make_weights('p2s_max_sum')
+    assert cfg['sym_op'] == 'sum'
+    m = engine.Model(w, dict(cfg, encoder_bf16=encoder))
+    cloud = engine.Cloud(np.load(os.path.join(FIX, '04_pts', _names('testset')[0] + '.xyz.npy')))
+    sdf, _ = engine.infer_shape(m, cloud, engine.Rng(SEED), 32, 3, chunk=700)
+    torch.cuda.synchronize()
+    sdf = sdf.cpu().numpy()
+    c = parity.compare_sdf(sdf, ref)
+    print('p2s_max_sum (encoder mode %d): max|dSDF| %.3g, flips %d / %d, positive fraction %.2f'
+          % (encoder, c['max_abs_dsdf'], c['flipped'].size, sdf.size, (sdf > 0).mean()))
+    assert c['max_abs_dsdf'] < 1e-4 and c['flipped'].size == 0 and 0.2 < (sdf > 0).mean() < 0.8
+    # the max model with the same weights answers differently: the pool really is a sum
+    m2 = engine.Model(w, dict(cfg, sym_op='max'))
+    other, _ = engine.infer_shape(m2, cloud, engine.Rng(SEED), 32, 3, q_end=64)
+    assert np.abs(other.cpu().numpy() - sdf[:64]).max() > 1e-3
+    m.close()
+    m2.close()
+    cloud.close()
+
+
 @pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
 def test_standin_clouds_match_reference(model):
     """non-fixture geometry -- two STAND-IN clouds (abc_minimal clouds under

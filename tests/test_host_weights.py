@@ -86,11 +86,17 @@ def test_engine_algebra_matches_oracle(model, fixture_cloud):
 
 def test_unsupported_configs_raise():
     w, cfg = synth.make_weights('p2s_max')
-    for bad in (dict(sym_op='sum'), dict(net_size=512), dict(output_dim=3)):
+    for bad in (dict(sym_op='median'), dict(net_size=512), dict(output_dim=3)):
         c = dict(cfg)
         c.update(bad)
         with pytest.raises(ValueError):
             weights.build_blob(w, c)
+    # sym_op='sum' (reference source/points_to_surf_model.py:172-173) is built -- except together with single_transformer
+    _, _, mc = weights.build_blob(w, dict(cfg, sym_op='sum'))
+    assert mc.sym_sum == 1 and weights.build_blob(w, cfg)[2].sym_sum == 0
+    ws, cs = synth.make_weights('p2s_shared_encoder')
+    with pytest.raises(ValueError):
+        weights.build_blob(ws, dict(cs, sym_op='sum'))
 
 
 def test_no_feat_stn_becomes_an_exact_identity_transform():
