@@ -83,8 +83,7 @@ typedef struct {
                                     value of the reference's Python float: the ball test is r * r in float64          */
     int32_t sym_sum;             /* train --sym_op sum (reference source/points_to_surf_model.py:170-175,211-214; set by no
                                     experiment script): the pool of PointNetfeat is a SUM over the points instead of the
-                                    max.  The STN / QSTN trunks keep their max-pool in the reference too (:47, :106).
-                                    Not with single_transformer                                                     */
+                                    max.  The STN / QSTN trunks keep their max-pool in the reference too (:47, :106)  */
     int32_t reserved[3];
 } p2s_model_cfg;
 

@@ -91,11 +91,6 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
         p2s_set_error("p2s_model_create: unsupported cfg (net_size=%d output_dim=%d)", cfg->net_size, cfg->output_dim);
         return P2S_EINVAL;
     }
-    if (cfg->sym_sum && cfg->single_transformer) {
-        p2s_set_error("p2s_model_create: sym_op='sum' with single_transformer is not built (the pool of the one encoder over "
-                      "both point sets is combined as a max of the two branches)");
-        return P2S_EINVAL;
-    }
     if (p2s_device_count() <= device || device < 0) {
         p2s_set_error("p2s_model_create: no HIP device %d", device);
         return P2S_ENODEVICE;
@@ -432,6 +427,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         if (m->cfg.single_transformer) {      // fc1_local_global reads the ONE pooled feature; d1l / d1g are its column halves
             g.A2 = w.feat + (size_t)C * 1024;
             g.a2_z = -(long long)C * 1024;
+            g.a2_add = m->cfg.sym_sum ? 1 : 0;        // sym_op='sum': the pool over both point sets = the sum of the two sums
         }
         g.W[0] = W + o.d1l; g.W[1] = W + o.d1g; g.bias[0] = W + o.db1l; g.bias[1] = W + o.db1g;
         g.C = w.d1; g.ldc = 1024; g.c_z = 512; g.N = 512; g.K = 1024;

@@ -106,6 +106,7 @@ struct GemmArgs {
     const float *A; long long lda; long long a_z;
     const float *A2;              // optional: the activation is max(A, A2) element-wise (NaN-propagating) -- two partial max-pools
     long long a2_z;               // stride of A2 per z (may differ from a_z: with a_z = -a2_z both z see the same pair)
+    int a2_add;                   // 1: the activation is A + A2 (two partial SUM-pools, sym_op='sum') instead of max(A, A2)
     const float *W[2];
     const float *bias[2];
     float *C; long long ldc; long long c_z;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void p2s_gemm_kernel(GemmArgs g) {
             if (A2) {                 // max-pool over two point sets = max of their pools; NaN wins like torch's max
                 const f32x4 u = *reinterpret_cast<const f32x4 *>(A2 + (long long)m * g.lda + kc + 4 * (tid & 31));
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = (u[t] > v[t] || u[t] != u[t]) ? u[t] : v[t];
+                for (int t = 0; t < 4; ++t) v[t] = g.a2_add ? v[t] + u[t] : ((u[t] > v[t] || u[t] != u[t]) ? u[t] : v[t]);
             }
             *reinterpret_cast<f32x4 *>(As + r * GS + 4 * (tid & 31)) = v;
         }

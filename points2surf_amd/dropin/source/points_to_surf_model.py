@@ -57,8 +57,6 @@ class PointsToSurfModel(nn.Module):
         super(PointsToSurfModel, self).__init__()
         if sym_op not in ('max', 'sum'):
             raise ValueError('Unsupported symmetric operation: %s' % sym_op)        # reference :175
-        if sym_op == 'sum' and single_transformer:
-            raise ValueError("sym_op='sum' with single_transformer is not built (no script of the reference sets either)")
         self.sym_op = sym_op
         self.net_size_max = net_size_max
         self.num_points = num_points

@@ -39,6 +39,8 @@ NAMED_MODELS = {
     # train --sym_op sum (set by no script of the reference): PointNetfeat pools with a sum over the points
     # (source/points_to_surf_model.py:170-175, :211-214); the STN / QSTN trunks keep their max-pool
     'p2s_max_sum': dict(use_point_stn=False, shared_transformation=False, uniform_subsample=True, sym_op='sum'),
+    'p2s_shared_encoder_sum': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False,
+                                   single_transformer=True, sym_op='sum'),
     'p2s_small_radius': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, patch_radius=0.05),
     'p2s_medium_radius': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, patch_radius=0.1),
     'p2s_large_radius': dict(use_point_stn=True, shared_transformation=False, uniform_subsample=False, patch_radius=0.2),

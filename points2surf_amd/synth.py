@@ -20,7 +20,7 @@ _FC4_BIAS_SHIFT = {'p2s_max': (6.289174, 2.416443), 'p2s_vanilla': (2.6854432, 4
                    'p2s_large_kNN': (4.9557, 2.6857), 'p2s_regression': (3.7676,), 'p2s_shared_encoder': (-0.2, -3.9804),
                    'p2s_small_radius': (2.6671, 1.4694), 'p2s_medium_radius': (3.4947, 2.3483),
                    'p2s_large_radius': (3.9348, 2.7203), 'p2s_max_no_feat_stn': (0.1092, 2.8237),
-                   'p2s_max_sum': (3.3387, 1.0881)}
+                   'p2s_max_sum': (3.3387, 1.0881), 'p2s_shared_encoder_sum': (0.5145, 0.1371)}
 
 
 # Second synthetic weight set of p2s_vanilla: the same weights with the bias of the SIGN logit moved by the median of
@@ -81,7 +81,7 @@ def make_weights(model='p2s_max', seed=1234, net_size_max=1024, output_dim=None)
     # sym_op='sum': the pooled feature is a sum over 300 / 1000 points -- scale the affine in front of the pool so that
     # the features (and with them the logits) stay O(1) like those of the max models
     if cfg.get('sym_op', 'max') == 'sum':
-        for pre, npts in (('feat_local', 300.0), ('feat_global', 1000.0)):
+        for pre, npts in (('feat_local', 300.0), ('feat_global', 1000.0), ('feat_local_global', 1300.0)):
             for leaf in ('weight', 'bias'):
                 if pre + '.bn3.' + leaf in w:
                     w[pre + '.bn3.' + leaf] = (w[pre + '.bn3.' + leaf] / np.float32(npts)).astype(np.float32)

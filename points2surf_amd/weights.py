@@ -151,8 +151,6 @@ def build_blob(state_dict, cfg):
     sym_op = cfg.get('sym_op', 'max')
     if sym_op not in ('max', 'sum'):
         raise ValueError("Unsupported symmetric operation: %s" % sym_op)        # reference points_to_surf_model.py:175
-    if sym_op == 'sum' and single:
-        raise ValueError("sym_op='sum' with single_transformer: not built (no script of the reference sets either with the other)")
 
     blob = _Blob()
     offs = WeightOffsets()

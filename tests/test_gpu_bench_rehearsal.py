@@ -31,6 +31,15 @@ def test_two_ranks_on_one_gpu(mode):
     assert d['stage_ms_rank0']['ms_cloud'] > 0 and d['stage_ms_rank0']['ms_grid'] > 0      # fresh handle per step
     g = d['self_check']['vs_reference_golden']
     assert g['queries'] == 2976 and g['sign_flips'] == 0 and g['max_abs_dsdf'] < 1e-4
+    assert d['config']['assignment'].startswith('sharding.assign_shapes') and d['config']['collective'].startswith('gloo (world 2)')
+    if mode == 'dataset':
+        # the exact dataset-wide stream by hand-off through the rendezvous store: rank 0 re-derives the last shape of rank 1
+        # from a fresh single stream and finds it bit-identical
+        assert d['config']['stream_mode'] == 'dataset/handoff'
+        h = d['self_check']['stream_handoff']
+        assert h['bit_identical_to_single_stream'] is True and h['owner'] == 1 and h['queries'] == 2976
+    else:
+        assert d['config']['stream_mode'] == 'per_shape' and 'stream_handoff' not in d['self_check']
 
 
 def test_eight_ranks_three_clouds_at_the_real_world_size():
@@ -50,6 +59,19 @@ def test_eight_ranks_three_clouds_at_the_real_world_size():
     g = d['self_check']['vs_reference_golden']
     assert g['file'].endswith('ref_rec_p2s_max_abc3_grid64.npz') and len(g['shapes']) == 3
     assert g['sign_flips'] == 0 and g['max_abs_dsdf'] < 1e-4 and g['queries'] == sum(d['config']['queries_per_shape'].values())
+    h = d['self_check']['stream_handoff']
+    assert d['config']['stream_mode'] == 'dataset/handoff' and h['bit_identical_to_single_stream'] is True and h['owner'] != 0
+
+
+def test_replicate_mode_still_gives_the_exact_stream():
+    """P2S_STREAM_HANDOFF=replicate (the r03 behaviour: every rank consumes every foreign shape's draws itself)"""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env.update(P2S_BENCH_SHARE_GPU='1', P2S_STREAM_HANDOFF='replicate')
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2',
+                        '--warmup', '1', '--res', '32'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = json.loads([l for l in r.stdout.split('\n') if l.startswith('{')][0])
+    assert d['config']['stream_mode'] == 'dataset/replicate' and d['value'] > 0
 
 
 def test_golden_check_classifies_a_flipped_sign_with_device_and_cpu_logits(fixture_cloud):

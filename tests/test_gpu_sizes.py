@@ -206,6 +206,29 @@ def test_sym_op_sum_matches_reference(encoder):
     cloud.close()
 
 
+def test_sym_op_sum_with_the_single_encoder_matches_reference():
+    """sym_op='sum' together with --single_transformer 1 (one PointNetfeat over cat(patch, sub-sample), reference
+    source/points_to_surf_model.py:253-263, :213-214): the engine runs the two point sets as two branches and the decoder's
+    first layer reads the SUM of their two sum-pools (GemmArgs.a2_add); QSTN + weighted sub-sample on top."""
+    import torch
+    from points2surf_amd import engine, synth
+    key = 'ref_rec_p2s_shared_encoder_sum_testset_grid32'
+    if not os.path.isfile(os.path.join(GOLDEN, key + '.npz')):
+        pytest.skip(key + ' not generated')
+    ref = np.load(os.path.join(GOLDEN, key + '.npz'))['rec_0']
+    w, cfg = synth.make_weights('p2s_shared_encoder_sum')
+    m = engine.Model(w, cfg)
+    cloud = engine.Cloud(np.load(os.path.join(FIX, '04_pts', _names('testset')[0] + '.xyz.npy')))
+    sdf, _ = engine.infer_shape(m, cloud, engine.Rng(SEED), 32, 3)
+    torch.cuda.synchronize()
+    c = parity.compare_sdf(sdf.cpu().numpy(), ref)
+    print('p2s_shared_encoder_sum: max|dSDF| %.3g, flips %d / %d, positive fraction %.2f'
+          % (c['max_abs_dsdf'], c['flipped'].size, ref.size, (ref > 0).mean()))
+    assert c['max_abs_dsdf'] < 1e-4 and c['flipped'].size == 0 and 0.1 < (ref > 0).mean() < 0.9
+    m.close()
+    cloud.close()
+
+
 @pytest.mark.parametrize('model', ['p2s_max', 'p2s_vanilla'])
 def test_standin_clouds_match_reference(model):
     """non-fixture geometry -- two STAND-IN clouds (abc_minimal clouds under

@@ -91,12 +91,12 @@ def test_unsupported_configs_raise():
         c.update(bad)
         with pytest.raises(ValueError):
             weights.build_blob(w, c)
-    # sym_op='sum' (reference source/points_to_surf_model.py:172-173) is built -- except together with single_transformer
+    # sym_op='sum' (reference source/points_to_surf_model.py:172-173) is built, also together with single_transformer
     _, _, mc = weights.build_blob(w, dict(cfg, sym_op='sum'))
     assert mc.sym_sum == 1 and weights.build_blob(w, cfg)[2].sym_sum == 0
-    ws, cs = synth.make_weights('p2s_shared_encoder')
-    with pytest.raises(ValueError):
-        weights.build_blob(ws, dict(cs, sym_op='sum'))
+    ws, cs = synth.make_weights('p2s_shared_encoder_sum')
+    mcs = weights.build_blob(ws, cs)[2]
+    assert mcs.sym_sum == 1 and mcs.single_transformer == 1
 
 
 def test_no_feat_stn_becomes_an_exact_identity_transform():
