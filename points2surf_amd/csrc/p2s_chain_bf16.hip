@@ -165,9 +165,12 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[F16 ? 2 : 1], uns
 // (sched_group_barrier) -- and the small layers' weights fetched before the barrier that guards their input.  The
 // non-PIPE schedule (r03) issued every weight load one or two MFMAs before its use: each wave sat out the L2 latency
 // once per k-step and only the other two waves of its SIMD kept the matrix pipe at 71 %.
-template <int NS, bool F16, bool PIPE = false>
+// SUM: sym_op='sum' -- the pool over the points is a masked sum instead of the max (a compile-time variant: as a run-time
+// branch inside the unrolled column-tile loop it cost the max kernels 40 VGPRs and pushed the fp16 pair kernel into scratch)
+template <int NS, bool F16, bool PIPE = false, bool SUM = false>
 __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 : 2)) void p2s_chain_bf16_kernel(ChainArgs args) {
     static_assert(!PIPE || (F16 && NS == 2 && MT == 64), "the pipelined schedule is written for the fp16 pair mode");
+    static_assert(!(PIPE && SUM), "the sum pool is built into the default schedule only");
     constexpr int NA = F16 ? 2 : 1;                       // accumulators per tile (fp16 pair: second one scaled by 2^-11)
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_bf16[];
     constexpr int SA = MT * HA, SB = MT * HB;             // halfs per piece
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 
         for (int i = 0; i < 9; ++i) R[i] = br.rot[item * 9 + i];
     }
     float rmax[8];
-    const bool psum = br.pool_sum != 0;                   // sym_op='sum': masked sum over the points instead of the max
+    constexpr bool psum = SUM;                            // sym_op='sum': masked sum over the points instead of the max
 #pragma unroll
     for (int i = 0; i < 8; ++i) rmax[i] = psum ? 0.0f : -INFINITY;
     bool bad = false;       // non-finite input poisons the item (torch propagates NaN through conv / ReLU / max)
@@ -599,11 +602,20 @@ __global__ void p2s_pack_bf16_kernel(const float *__restrict__ src, unsigned sho
 
 }  // namespace
 
+template <int NS, bool F16, bool PIPE, bool SUM>
+static void launch_bf16(const ChainArgs &args, int n, size_t lds, hipStream_t stream) {
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)p2s_chain_bf16_kernel<NS, F16, PIPE, SUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((p2s_chain_bf16_kernel<NS, F16, PIPE, SUM>), dim3(n), dim3(256), lds, stream, args);
+}
+
 int p2s_launch_chain_bf16(const ChainArgs &args, hipStream_t stream) {
     const int n = args.br[0].n_items + args.br[1].n_items;
     if (n <= 0) return P2S_OK;
     const int ns = args.ns < 1 ? 1 : args.ns;
     const size_t lds = (size_t)ns * MT * (HA + HB) * 2;
+    // both branches of a launch pool alike (pass 2 of a sym_op='sum' model: sum; every other launch: max)
+    const bool sum = args.br[0].pool_sum || (args.br[1].n_items > 0 && args.br[1].pool_sum);
     if (args.f16) {
         if (ns != 2) {
             p2s_set_error("p2s_launch_chain_bf16: the fp16 pair mode has 2 pieces, not %d", ns);
@@ -611,20 +623,18 @@ int p2s_launch_chain_bf16(const ChainArgs &args, hipStream_t stream) {
         }
         // P2S_F16_PIPE=1: the software-pipelined conv3 schedule (development / A-B; measured equal to the default one)
         static const bool pipe = getenv("P2S_F16_PIPE") && atoi(getenv("P2S_F16_PIPE")) != 0;
-        if (pipe) {
-            (void)hipFuncSetAttribute((const void *)p2s_chain_bf16_kernel<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((p2s_chain_bf16_kernel<2, true, true>), dim3(n), dim3(256), lds, stream, args);
-        } else {
-            (void)hipFuncSetAttribute((const void *)p2s_chain_bf16_kernel<2, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((p2s_chain_bf16_kernel<2, true, false>), dim3(n), dim3(256), lds, stream, args);
-        }
+        if (sum) launch_bf16<2, true, false, true>(args, n, lds, stream);
+        else if (pipe) launch_bf16<2, true, true, false>(args, n, lds, stream);
+        else launch_bf16<2, true, false, false>(args, n, lds, stream);
     } else if (ns == 1) {
-        hipLaunchKernelGGL((p2s_chain_bf16_kernel<1, false>), dim3(n), dim3(256), lds, stream, args);
+        if (sum) launch_bf16<1, false, false, true>(args, n, lds, stream);
+        else launch_bf16<1, false, false, false>(args, n, lds, stream);
     } else if (ns == 2) {
-        hipLaunchKernelGGL((p2s_chain_bf16_kernel<2, false>), dim3(n), dim3(256), lds, stream, args);
+        if (sum) launch_bf16<2, false, false, true>(args, n, lds, stream);
+        else launch_bf16<2, false, false, false>(args, n, lds, stream);
     } else if (ns == 3) {
-        (void)hipFuncSetAttribute((const void *)p2s_chain_bf16_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((p2s_chain_bf16_kernel<3, false>), dim3(n), dim3(256), lds, stream, args);
+        if (sum) launch_bf16<3, false, false, true>(args, n, lds, stream);
+        else launch_bf16<3, false, false, false>(args, n, lds, stream);
     } else {
         p2s_set_error("p2s_launch_chain_bf16: %d pieces unsupported", ns);
         return P2S_EINVAL;
