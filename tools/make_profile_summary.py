@@ -34,9 +34,10 @@ for name in sorted(d for d in os.listdir(src) if d.startswith('pmc') and os.path
         short = k.split('p2s_')[1].split('(')[0]
         if short.startswith('chain_kernel<'):          # r04: template <bool SUM>; <false> = the max-pool kernel of every model
             short = 'chain_kernel' if short == 'chain_kernel<false>' else short
-        short = short.replace('chain_bf16_kernel<2, true, false>', 'chain_bf16_kernel<2, true>') \
-                     .replace('chain_bf16_kernel<3, false, false>', 'chain_bf16_kernel<3, false>') \
-                     .replace('chain_bf16_kernel<1, false, false>', 'chain_bf16_kernel<1>')
+        # r04: template <NS, F16, PIPE, SUM>; the default (max-pool, r03 schedule) instances keep their r03 names
+        short = short.replace('chain_bf16_kernel<2, true, false, false>', 'chain_bf16_kernel<2, true>') \
+                     .replace('chain_bf16_kernel<3, false, false, false>', 'chain_bf16_kernel<3, false>') \
+                     .replace('chain_bf16_kernel<1, false, false, false>', 'chain_bf16_kernel<1>')
         acc[(short, r['Counter_Name'])].append(float(r['Counter_Value']))
         rows.append([name, short, r['Dispatch_Id'], r['Grid_Size'], r['Workgroup_Size'], r['LDS_Block_Size'],
                      r['VGPR_Count'], r['Accum_VGPR_Count'], r['SGPR_Count'], r['Counter_Name'], r['Counter_Value'],
