@@ -160,6 +160,44 @@ def test_no_feat_stn_prefix_matches_reference(golden_dir, fixture_cloud, meta):
     assert np.abs(sdf - ref).max() < 1e-5 and np.array_equal(sdf > 0, ref > 0)
 
 
+@pytest.mark.parametrize('model,nq', [('p2s_max_sum', 48), ('p2s_shared_encoder_sum', 12)])
+def test_sym_op_sum_prefix_matches_reference(golden_dir, fixture_cloud, meta, model, nq):
+    """train --sym_op sum (source/points_to_surf_model.py:170-175, :211-214): the numpy restatement and the torch port
+    against the unmodified reference -- PointNetfeat pools with a sum, its STN / the QSTN keep the max-pool"""
+    from oracle.torch_port import TorchPort
+    g = np.load(os.path.join(golden_dir, 'ref_rec_%s_testset_grid32.npz' % model))
+    w, cfg = synth.make_weights(model)
+    assert cfg['sym_op'] == 'sum'
+    q, sdf = O.infer_shape(w, cfg, fixture_cloud, 32, 3, O.LegacyMT19937(meta['seed_data']), query_range=(0, nq))
+    ref = g['rec_0'][:nq]
+    assert np.abs(sdf - ref).max() < 1e-5 and np.array_equal(sdf > 0, ref > 0)
+    port = TorchPort(w, cfg)
+    sdf_t = port.infer_queries(fixture_cloud, q[:8], np.random.RandomState(meta['seed_data']), batch=8)
+    assert np.abs(sdf_t - ref[:8]).max() < 1e-5
+    # and it is not the max model's answer
+    _, sdf_max = O.infer_shape(w, dict(cfg, sym_op='max'), fixture_cloud, 32, 3, O.LegacyMT19937(meta['seed_data']), query_range=(0, 8))
+    assert np.abs(sdf_max - ref[:8]).max() > 1e-3
+
+
+def test_random_patch_sampler_indices_match_reference(golden_dir):
+    """--sampling sequential_shapes_random_patches: what the drop-in draws on the host -- ``RandomState(seed).choice(
+    range(start, end), min(patches_per_shape, count), replace=False)`` over the data set's global patch indices, shape
+    after shape (reference source/data_loader.py:88-139) -- against the ``<shape>.idx`` files the unmodified reference
+    wrote for the three abc_minimal clouds at grid 32 (150 patches per shape)"""
+    g = np.load(os.path.join(golden_dir, 'ref_recsample_p2s_max_abc3_grid32.npz'))
+    with open(os.path.join(golden_dir, 'meta_sizes.json')) as f:
+        counts = [s['queries'] for s in json.load(f)['ref_rec_p2s_max_abc3_grid64']['shapes']]
+    with open(os.path.join(golden_dir, 'abc_minimal', 'abc3.txt')) as f:
+        names = [x.strip() for x in f if x.strip()]
+    counts = [O.query_grid(np.load(os.path.join(golden_dir, 'abc_minimal', '04_pts', n + '.xyz.npy')), 32, 3)[0].shape[0] for n in names]
+    rs = np.random.RandomState(40938661)
+    start = 0
+    for i, c in enumerate(counts):
+        picked = rs.choice(range(start, start + c), size=min(150, c), replace=False) - start
+        start += c
+        assert np.array_equal(picked, g['idx_%d' % i]), i
+
+
 def test_oracle_permutation_is_numpys():
     for seed, n in ((1, 2), (2, 301), (3, 1025), (4, 3643)):
         r = O.LegacyMT19937(seed)
