@@ -213,7 +213,10 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
     const int k = m->cfg.points_per_patch, n = m->cfg.sub_sample_size;
     // default chunk: 8192 queries for the uniform sub-sample; 4096 for the distance-weighted one, whose generator works in
     // batches of 4096 queries (two batches per chunk of 8192 measured 6 % SLOWER: 102.7 vs 109.8 k queries/s)
-    if (chunk <= 0) chunk = (weighted && !getenv("P2S_MAX_CHUNK")) ? std::min(m->max_chunk, 4096) : m->max_chunk;
+    // r04: with a 16-bit encoder the weighted models run best with 2048 (fp16 pair, test shape at 256^3: 1024 / 2048 / 3072 /
+    // 4096 / 8192 queries: 231.8 / 236.9 / 235.4 / 233.8 / 208.9 k queries/s; fp32: 2048 / 4096: 109.7 / 110.4 k)
+    if (chunk <= 0)
+        chunk = (weighted && !getenv("P2S_MAX_CHUNK")) ? std::min(m->max_chunk, m->cfg.encoder_bf16 ? 2048 : 4096) : m->max_chunk;
     chunk = std::min(chunk, m->max_chunk);
     if (getenv("P2S_NO_OVERLAP")) m->overlap = false;   // development knob: single-stream pipeline
     if (m->overlap && !m->aux) {

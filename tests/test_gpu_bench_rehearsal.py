@@ -103,3 +103,34 @@ def test_golden_check_classifies_a_flipped_sign_with_device_and_cpu_logits(fixtu
     assert abs(rec['max_abs_diff_unmasked'] - 2 * abs(sdfs[1][j])) < 1e-6 and rec['max_abs_dsdf'] < 1e-6
     # the logit the analysis computed belongs to THAT query: its sign is the sign of the device's SDF there
     assert (f['sign_logit_device'] >= 0) == (sdfs[1][j] > 0)
+
+
+@pytest.mark.parametrize('encoder', ['fp32', 'fp16x2'])
+def test_dropin_leg_of_the_bench(encoder, golden_dir):
+    """bench.py's ``secondary.dropin_*`` leg (the hot path measured through boundary B1: the drop-in's
+    points_to_surf_eval + implicit_surface_to_mesh_directory, files in / files out) at grid 32 on the three clouds: every
+    file of the contract is written, the SDF equals the reference's golden, the environment is left as it was"""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location('p2s_bench', os.path.join(REPO, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from points2surf_amd import parity
+    g = np.load(os.path.join(golden_dir, 'ref_fulleval_p2s_max_abc3_grid32.npz'))
+    shapes = [(n, np.ascontiguousarray(np.load(bench.cloud_path(n))[:, :3], dtype=np.float32), g['rec_%d' % i])
+              for i, n in enumerate(bench.ABC3)]
+    before = os.environ.get('P2S_ENCODER')
+    mods = [m for m in sys.modules if m == 'source' or m.startswith('source.')]
+    try:
+        rec = bench.dropin_leg(shapes, 32, encoder, 'tests/golden/ref_fulleval_p2s_max_abc3_grid32.npz', parity)
+    finally:
+        for m in [m for m in sys.modules if (m == 'source' or m.startswith('source.')) and m not in mods]:
+            del sys.modules[m]
+        dropin = os.path.join(REPO, 'points2surf_amd', 'dropin')
+        while dropin in sys.path:
+            sys.path.remove(dropin)
+    assert os.environ.get('P2S_ENCODER') == before
+    assert rec['files_written'] == 7 * 3 and rec['shapes'] == 3 and rec['queries'] == sum(s[2].shape[0] for s in shapes)
+    v = rec['vs_reference_golden']
+    assert v['max_abs_dsdf'] < 1e-5 and v['sign_flips'] == 0
+    assert rec['value'] > 0 and rec['value_shape_loop'] >= rec['value'] and rec['seconds_mesh_directory'] > 0
