@@ -132,6 +132,21 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
             items.push_back({&m->h_qc2, offs->qstn.c2, 64, 128});
             items.push_back({&m->h_qc3, offs->qstn.c3, 128, 1024});
         }
+        // fp16 pair mode: the encoder-side head layers (STN fc1..fc3, QSTN fc1 / fc2) run on fp16-pair MFMAs too
+        // (P2S_HEADS_F16=0: keep them fp32, development / A-B)
+        m->heads_f16 = cfg->encoder_bf16 == 4 && !(getenv("P2S_HEADS_F16") && atoi(getenv("P2S_HEADS_F16")) == 0);
+        if (m->heads_f16) {
+            for (int e = 0; e < 2; ++e) {
+                const p2s_encoder_offsets &eo = offs->enc[e];
+                items.push_back({&m->h_sf1[e], eo.sf1, 1024, 512});
+                items.push_back({&m->h_sf2[e], eo.sf2, 512, 256});
+                items.push_back({&m->h_sf3[e], eo.sf3, 256, 4096});
+            }
+            if (cfg->use_point_stn) {
+                items.push_back({&m->h_qf1, offs->qstn.f1, 1024, 512});
+                items.push_back({&m->h_qf2, offs->qstn.f2, 512, 256});
+            }
+        }
         size_t total = 0;
         for (auto &it : items) {
             *it.dst = total;
@@ -319,9 +334,13 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         memset(&g, 0, sizeof(g));
         g.A = w.qg; g.A2 = qstn_shared ? w.qg2 : nullptr; g.a2_z = 0; g.lda = 1024; g.a_z = 0; g.W[0] = g.W[1] = W + o.qstn.f1; g.bias[0] = g.bias[1] = W + o.qstn.fb1;
         g.C = w.qh1; g.ldc = 512; g.c_z = 0; g.M = C; g.N = 512; g.K = 1024; g.Z = 1; g.relu = 1;
+        if (m->heads_f16) {
+            g.Wh[0] = g.Wh[1] = m->blob_h + m->h_qf1; g.wh_piece = (long long)m->h_total; g.range_flag = m->range_flag;
+        }
         if ((rc = p2s_launch_gemm(g, s))) return rc;
         g.A = w.qh1; g.A2 = nullptr; g.lda = 512; g.W[0] = g.W[1] = W + o.qstn.f2; g.bias[0] = g.bias[1] = W + o.qstn.fb2;
         g.C = w.qh2; g.ldc = 256; g.N = 256; g.K = 512;
+        if (m->heads_f16) g.Wh[0] = g.Wh[1] = m->blob_h + m->h_qf2;
         if ((rc = p2s_launch_gemm(g, s))) return rc;
         if ((rc = p2s_launch_qstn_tail(w.qh2, W + o.qstn.f3, W + o.qstn.fb3, w.rot, C, 256, s))) return rc;
         rot = w.rot;
@@ -369,14 +388,20 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         }
         g.W[0] = W + o.enc[0].sf1; g.W[1] = W + o.enc[1].sf1; g.bias[0] = W + o.enc[0].sfb1; g.bias[1] = W + o.enc[1].sfb1;
         g.C = w.h1; g.ldc = 512; g.c_z = (long long)C * 512; g.N = 512; g.K = 1024;
+        if (m->heads_f16) {
+            g.Wh[0] = m->blob_h + m->h_sf1[0]; g.Wh[1] = m->blob_h + m->h_sf1[1];
+            g.wh_piece = (long long)m->h_total; g.range_flag = m->range_flag;
+        }
         if ((rc = p2s_launch_gemm(g, s))) return rc;
         g.A = w.h1; g.A2 = nullptr; g.lda = 512; g.a_z = (long long)C * 512;
         g.W[0] = W + o.enc[0].sf2; g.W[1] = W + o.enc[1].sf2; g.bias[0] = W + o.enc[0].sfb2; g.bias[1] = W + o.enc[1].sfb2;
         g.C = w.h2; g.ldc = 256; g.c_z = (long long)C * 256; g.N = 256; g.K = 512;
+        if (m->heads_f16) { g.Wh[0] = m->blob_h + m->h_sf2[0]; g.Wh[1] = m->blob_h + m->h_sf2[1]; }
         if ((rc = p2s_launch_gemm(g, s))) return rc;
         g.A = w.h2; g.lda = 256; g.a_z = (long long)C * 256; g.relu = 0;
         g.W[0] = W + o.enc[0].sf3; g.W[1] = W + o.enc[1].sf3; g.bias[0] = W + o.enc[0].sfb3; g.bias[1] = W + o.enc[1].sfb3;
         g.C = w.T; g.ldc = 4096; g.c_z = (long long)C * 4096; g.N = 4096; g.K = 256;
+        if (m->heads_f16) { g.Wh[0] = m->blob_h + m->h_sf3[0]; g.Wh[1] = m->blob_h + m->h_sf3[1]; }
         if ((rc = p2s_launch_gemm(g, s))) return rc;
         FoldArgs f;
         memset(&f, 0, sizeof(f));

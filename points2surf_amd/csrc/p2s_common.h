@@ -107,6 +107,12 @@ struct GemmArgs {
     const float *A2;              // optional: the activation is max(A, A2) element-wise (NaN-propagating) -- two partial max-pools
     long long a2_z;               // stride of A2 per z (may differ from a_z: with a_z = -a2_z both z see the same pair)
     int a2_add;                   // 1: the activation is A + A2 (two partial SUM-pools, sym_op='sum') instead of max(A, A2)
+    // fp16 pair variant (p2s_gemm_f16_kernel; the encoder-side head layers of cfg.encoder_bf16 = 4): Wh[z] != NULL = the
+    // weights as 16-bit B fragments [N/32][K/16][64 lanes][8], piece 1 wh_piece halfs behind piece 0; the activation is
+    // split into its fp16 pair when it is staged.  range_flag: raised when an activation leaves the half range
+    const unsigned short *Wh[2];
+    long long wh_piece;
+    int *range_flag;
     const float *W[2];
     const float *bias[2];
     float *C; long long ldc; long long c_z;

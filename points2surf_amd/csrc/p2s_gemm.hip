@@ -93,6 +93,114 @@ __global__ __launch_bounds__(256) void p2s_gemm_kernel(GemmArgs g) {
     }
 }
 
+// ---- fp16 pair variant (r04): the STN / QSTN head layers of the fp16-pair encoder mode -------------------------------
+// Same decomposition as above; every operand as h0 + h1 * 2^-11 (h0 = fp16(x), h1 = fp16((x - h0) * 2^11)), a product =
+// h0 h0' into one fp32 accumulator and (h1 h0' + h0 h1') into a second one that enters with 2^-11 in the epilogue: three
+// v_mfma_f32_32x32x16_f16 per 16 k instead of eight v_mfma_f32_32x32x2_f32 (22 mantissa bits per operand; the dropped
+// h1 h1' term is below fp32's own rounding) -- the arithmetic of p2s_chain_bf16_kernel<2, true>.  The weights are split
+// once at model creation (p2s_pack_bf16_kernel), the activations when they are staged in LDS.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int HS = GK + 8;       // halfs per LDS row (272 B: 16-byte rows, bank spread)
+
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+
+template <int RT>
+__global__ __launch_bounds__(256) void p2s_gemm_f16_kernel(GemmArgs g) {
+    constexpr int GM = 32 * RT;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][GM * HS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int z = blockIdx.z;
+    const int m0 = blockIdx.x * GM;
+    const int nt = blockIdx.y * 4 + wave;
+    const int KB = g.K / 16;
+    const float *__restrict__ A = g.A + (long long)z * g.a_z;
+    const float *__restrict__ A2 = g.A2 ? g.A2 + (long long)z * g.a2_z : nullptr;
+    const unsigned short *__restrict__ Wp = g.Wh[z] + ((long long)nt * KB * 64 + lane) * 8;
+    const float *__restrict__ bias = g.bias[z];
+    float *__restrict__ C = g.C + (long long)z * g.c_z;
+
+    f32x16 acc[RT][2];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
+    bool range_bad = false;
+    const int aoff = (lane & 31) * HS + 8 * (lane >> 5);
+
+    for (int kc = 0; kc < g.K; kc += GK) {
+        __syncthreads();
+        // stage A[m0:m0+GM][kc:kc+128] as its fp16 pair: 8 rows per pass, 32 lanes x 16 B per row (coalesced)
+#pragma unroll
+        for (int i = 0; i < GM / 8; ++i) {
+            const int r = (tid >> 5) + 8 * i;
+            int m = m0 + r;
+            if (m >= g.M) m = g.M - 1;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(A + (long long)m * g.lda + kc + 4 * (tid & 31));
+            if (A2) {
+                const f32x4 u = *reinterpret_cast<const f32x4 *>(A2 + (long long)m * g.lda + kc + 4 * (tid & 31));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = g.a2_add ? v[t] + u[t] : ((u[t] > v[t] || u[t] != u[t]) ? u[t] : v[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) range_bad = range_bad || fabsf(v[t]) > 6.0e4f;
+            uint2 h0, h1;
+            h0.x = pack_h2(v[0], v[1]);
+            h0.y = pack_h2(v[2], v[3]);
+            const f16x2 a = __builtin_bit_cast(f16x2, h0.x), b = __builtin_bit_cast(f16x2, h0.y);
+            h1.x = pack_h2((v[0] - (float)a[0]) * 2048.0f, (v[1] - (float)a[1]) * 2048.0f);
+            h1.y = pack_h2((v[2] - (float)b[0]) * 2048.0f, (v[3] - (float)b[1]) * 2048.0f);
+            *reinterpret_cast<uint2 *>(&As[0][r * HS + 4 * (tid & 31)]) = h0;
+            *reinterpret_cast<uint2 *>(&As[1][r * HS + 4 * (tid & 31)]) = h1;
+        }
+        __syncthreads();
+        const unsigned short *wk = Wp + (long long)(kc / 16) * 512;
+        u32x4 b0 = *reinterpret_cast<const u32x4 *>(wk), b1 = *reinterpret_cast<const u32x4 *>(wk + g.wh_piece);
+#pragma unroll
+        for (int kb = 0; kb < GK / 16; ++kb) {
+            u32x4 n0 = b0, n1 = b1;
+            if (kb < GK / 16 - 1) {
+                n0 = *reinterpret_cast<const u32x4 *>(wk + (kb + 1) * 512);
+                n1 = *reinterpret_cast<const u32x4 *>(wk + (kb + 1) * 512 + g.wh_piece);
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const u32x4 a0 = *reinterpret_cast<const u32x4 *>(&As[0][aoff + 32 * r * HS + 16 * kb]);
+                const u32x4 a1 = *reinterpret_cast<const u32x4 *>(&As[1][aoff + 32 * r * HS + 16 * kb]);
+                acc[r][1] = mfma16(a1, b0, acc[r][1]);          // small terms first
+                acc[r][1] = mfma16(a0, b1, acc[r][1]);
+                acc[r][0] = mfma16(a0, b0, acc[r][0]);
+            }
+            b0 = n0;
+            b1 = n1;
+        }
+    }
+    if (g.range_flag && __ballot(range_bad) != 0ull && lane == 0) atomicOr(g.range_flag, 1);
+    const int col = nt * 32 + (lane & 31);
+    const float bv = bias[col];
+#pragma unroll
+    for (int r2 = 0; r2 < RT; ++r2)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = 32 * r2 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            float v = (acc[r2][0][reg] + acc[r2][1][reg] * (1.0f / 2048.0f)) + bv;
+            if (g.relu) v = (v < 0.f) ? 0.f : v;                // NaN-propagating ReLU
+            if (m0 + r < g.M) C[(long long)(m0 + r) * g.ldc + col] = v;
+        }
+}
+
 // fc4 (K -> 2, no BN) + post-processing.  One thread per query.
 //   reference: source/points_to_surf_model.py:350, source/sdf_nn.py:11-21,
 //              source/points_to_surf_eval.py:184-196,263-273,205-207
@@ -192,6 +300,12 @@ int p2s_launch_gemm(const GemmArgs &g, hipStream_t stream) {
     const long long wg64 = (long long)((g.M + 63) / 64) * (g.N / 128) * g.Z;
     static const int force_rt = getenv("P2S_GEMM_RT") ? atoi(getenv("P2S_GEMM_RT")) : 0;     // development: 1 / 2
     const bool rt2 = force_rt ? force_rt == 2 : wg64 >= 2048;
+    if (g.Wh[0]) {                   // fp16 pair operands
+        if (rt2) hipLaunchKernelGGL(p2s_gemm_f16_kernel<2>, dim3((g.M + 63) / 64, g.N / 128, g.Z), dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL(p2s_gemm_f16_kernel<1>, dim3((g.M + 31) / 32, g.N / 128, g.Z), dim3(256), 0, stream, g);
+        P2S_LAUNCH_CHECK("p2s_gemm_f16_kernel");
+        return P2S_OK;
+    }
     if (rt2) {
         dim3 grid((g.M + 63) / 64, g.N / 128, g.Z);
         hipLaunchKernelGGL(p2s_gemm_kernel<2>, grid, dim3(256), 0, stream, g);

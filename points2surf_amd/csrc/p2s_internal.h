@@ -33,6 +33,9 @@ struct p2s_model_s {
     unsigned short *blob_h = nullptr;      // [pieces][h_total] (cfg.encoder_bf16 = number of bf16 pieces per operand)
     size_t h_total = 0;
     size_t h_w0b[2] = {}, h_s1[2] = {}, h_s2[2] = {}, h_s3[2] = {}, h_m2[2] = {}, h_m3[2] = {}, h_qc2 = 0, h_qc3 = 0;
+    // fp16 pair mode: the STN / QSTN head layers as 16-bit fragments too (p2s_gemm_f16_kernel); the decoder stays fp32
+    size_t h_sf1[2] = {}, h_sf2[2] = {}, h_sf3[2] = {}, h_qf1 = 0, h_qf2 = 0;
+    bool heads_f16 = false;
     int *range_flag = nullptr;             // device: raised by the fp16 pair mode when an activation leaves the half range
     float *ws = nullptr;      // per-chunk workspace, grown on demand
     int ws_chunk = 0;
