@@ -624,7 +624,7 @@ int p2s_launch_chain_bf16(const ChainArgs &args, hipStream_t stream) {
         // P2S_F16_PIPE=1: the software-pipelined conv3 schedule (development / A-B; measured equal to the default one)
         static const bool pipe = getenv("P2S_F16_PIPE") && atoi(getenv("P2S_F16_PIPE")) != 0;
         if (sum) launch_bf16<2, true, false, true>(args, n, lds, stream);
-        else if (pipe) launch_bf16<2, true, true, false>(args, n, lds, stream);
+        else if (pipe) launch_bf16<2, true, MT == 64, false>(args, n, lds, stream);      // (written for 64-point tiles)
         else launch_bf16<2, true, false, false>(args, n, lds, stream);
     } else if (ns == 1) {
         if (sum) launch_bf16<1, false, false, true>(args, n, lds, stream);
