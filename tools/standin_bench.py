@@ -4,6 +4,11 @@ N clouds = the three abc_minimal clouds under seeded random rotations, re-normal
 optionally sign propagation + iso-surface, download -- with one dataset-wide sub-sample stream.
 
     python tools/standin_bench.py [--shapes 22] [--res 256] [--model p2s_max] [--encoder 0|3|4] [--mesh]
+    python tools/standin_bench.py --dropin [--shapes 22] [--encoder 0|4] [--workers 7]
+
+--dropin: the same data set THROUGH THE BOUNDARY (bench.py's drop-in leg): the clouds as .npy files, the drop-in's
+``points_to_surf_eval(opt)`` (all result files written) then ``implicit_surface_to_mesh_directory`` -- the timed region
+of the reference's full_eval.py:44-64 (p2s_max).
 """
 import argparse
 import json
@@ -24,12 +29,25 @@ def main():
     ap.add_argument('--model', default='p2s_max')
     ap.add_argument('--encoder', type=int, default=0, help='cfg encoder_bf16: 0 fp32, 3 bf16x3, 4 fp16 pair')
     ap.add_argument('--mesh', action='store_true', help='also run sign propagation + iso-surface per shape')
+    ap.add_argument('--dropin', action='store_true', help='through the drop-in API (files in / files out) instead of the engine')
     args = ap.parse_args()
     import torch
     from points2surf_amd import engine, synth
     base_dir = os.path.join(REPO, 'tests', 'golden', 'abc_minimal', '04_pts')
     bases = [np.load(os.path.join(base_dir, f)) for f in sorted(os.listdir(base_dir)) if f.endswith('.xyz.npy')]
     clouds = [synth.standin_cloud(bases[i % 3], i) for i in range(args.shapes)]
+    if args.dropin:
+        import importlib.util
+        from points2surf_amd import parity
+        spec = importlib.util.spec_from_file_location('p2s_bench', os.path.join(REPO, 'bench.py'))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        bench.GRID_RES = args.res
+        shapes = [('standin_%03d' % i, c, None) for i, c in enumerate(clouds)]
+        rec = bench.dropin_leg(shapes, args.res, {0: 'fp32', 3: 'bf16x3', 4: 'fp16x2'}[args.encoder], None, parity)
+        rec.update(model='p2s_max', res=args.res, dataset='%d stand-in clouds (synth.standin_cloud, seeds 0..%d)' % (args.shapes, args.shapes - 1))
+        print(json.dumps(rec))
+        return
     w, cfg = synth.make_weights(args.model)
     model = engine.Model(w, dict(cfg, encoder_bf16=args.encoder))
     rng = engine.Rng(40938661)
