@@ -39,3 +39,30 @@ def test_world_size_mismatch_is_rejected():
     r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '4'], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=2' in (r.stderr + r.stdout)
+
+
+def test_launcher_uses_all_visible_devices_by_default(tmp_path, monkeypatch):
+    """python -m points2surf_amd.dropin.run <script> without a torchrun environment: one rank per visible device, as the
+    reference's DataParallel without device_ids uses all of them (source/points_to_surf_eval.py:168); under torchrun,
+    with one device, or with P2S_GPUS=1 it stays in the process; more ranks than devices is an error"""
+    import pytest
+    from points2surf_amd.dropin import run
+    assert run.ranks_to_spawn({}, 8) == 8
+    assert run.ranks_to_spawn({'P2S_GPUS': '4'}, 8) == 4
+    assert run.ranks_to_spawn({'P2S_GPUS': '1'}, 8) == 0
+    assert run.ranks_to_spawn({'WORLD_SIZE': '8', 'RANK': '3'}, 8) == 0        # already a rank
+    assert run.ranks_to_spawn({}, 1) == 0 and run.ranks_to_spawn({}, 0) == 0
+    with pytest.raises(SystemExit):
+        run.ranks_to_spawn({'P2S_GPUS': '16'}, 8)
+    cmd = run.spawn_command(8, ['/x/full_eval.py', '--indir', 'd'], 4711)
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node' in cmd and '8' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '4711'
+    assert cmd[-5:] == ['-m', 'points2surf_amd.dropin.run', '/x/full_eval.py', '--indir', 'd']
+    # end to end: two ranks (P2S_GPUS=2 with a faked device count) run the SCRIPT, each with its own RANK
+    script = tmp_path / 's.py'
+    script.write_text("import os\nopen(os.path.join(%r, 'rank_' + os.environ['RANK']), 'w').write(os.environ['WORLD_SIZE'])\n" % str(tmp_path))
+    monkeypatch.setattr(run, 'ranks_to_spawn', lambda environ=None, device_count=None: 0 if 'WORLD_SIZE' in os.environ else 2)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        monkeypatch.delenv(k, raising=False)
+    assert run.main([str(script)]) == 0
+    assert (tmp_path / 'rank_0').read_text() == '2' and (tmp_path / 'rank_1').read_text() == '2'
