@@ -58,7 +58,8 @@ def _clouds(dataset):
 
 
 CASES = [('p2s_max', 'standin2', 64), ('p2s_vanilla', 'standin2', 64), ('p2s_max', 'testset', 128), ('p2s_vanilla', 'testset', 128), ('p2s_max', 'testset', 256),
-         ('p2s_vanilla', 'testset', 256), ('p2s_max', 'abc3', 64), ('p2s_vanilla', 'abc3', 64), ('p2s_max', 'abc3', 256)]
+         ('p2s_vanilla', 'testset', 256), ('p2s_max', 'abc3', 64), ('p2s_vanilla', 'abc3', 64), ('p2s_max', 'abc3', 256),
+         ('p2s_vanilla', 'testset', 512), ('p2s_max', 'testset', 512)]      # BASELINE configs[4]'s grid (p2s_max: 2 known fp32 ties)
 
 
 @pytest.mark.parametrize('model_name,dataset,res', CASES)
