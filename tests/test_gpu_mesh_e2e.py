@@ -120,3 +120,27 @@ def test_cloud_to_mesh_equals_scikit_image_on_the_reference_sdf(model_name, data
             assert (v_x.shape[0], f_x.shape[0]) == (m['n_verts'], m['n_faces']) and np.array_equal(f_x, f_r)
         cloud.close()
     model.close()
+
+
+@pytest.mark.parametrize('model_name', ['p2s_max', 'p2s_vanilla'])
+def test_fp16_pair_encoder_gives_the_same_mesh(model_name):
+    """BASELINE configs[3]'s mode (reduced-precision encoder + fp32 decoder, here the fp16 PAIR encoder): cloud -> SDF ->
+    volume -> mesh at 256^3 has scikit-image's vertex / face counts and face array on the reference's SDF too"""
+    import torch
+    from points2surf_amd import engine, synth
+    res = 256
+    ref = np.load(os.path.join(GOLDEN, 'ref_rec_%s_testset_grid%d.npz' % (model_name, res)))['rec_0']
+    m = _meta()['%s_grid%d' % (model_name, res)]
+    w, cfg = synth.make_weights(model_name)
+    model = engine.Model(w, dict(cfg, encoder_bf16=4))
+    cloud = engine.Cloud(_clouds('testset')[0])
+    sdf, q = engine.infer_shape(model, cloud, engine.Rng(SEED), res, 3)
+    c = parity.compare_sdf(sdf.cpu().numpy(), ref)
+    assert c['max_abs_dsdf'] < 1e-4 and c['flipped'].size == 0
+    _, v_r, f_r, _ = _mesh(engine, torch, q, torch.from_numpy(ref).cuda(), res)
+    _, v_d, f_d, _ = _mesh(engine, torch, q, sdf, res)
+    assert (v_d.shape[0], f_d.shape[0]) == (m['n_verts'], m['n_faces']) and np.array_equal(f_d, f_r)
+    print('%s fp16x2 256^3: %d vertices / %d faces == scikit-image on the reference SDF; max|dSDF| %.3g; vertex displacement '
+          'max %.3g voxel' % (model_name, v_d.shape[0], f_d.shape[0], c['max_abs_dsdf'], np.abs(v_d - v_r).max()))
+    model.close()
+    cloud.close()
