@@ -171,7 +171,7 @@ def complete_shape(engine, model, pts_host, rng, res, chunk, ev=None):
     return out, sdf
 
 
-def dropin_leg(shapes, res, encoder, golden, parity):
+def dropin_leg(shapes, res, encoder, golden, parity, model='p2s_max'):
     """The hot path measured THROUGH the boundary the north_star names (B1): the drop-in's
     ``source.points_to_surf_eval.points_to_surf_eval(opt)`` in reconstruction mode over the dataset (files loaded from
     disk, all result files written), followed by ``source.sdf.implicit_surface_to_mesh_directory`` -- the sequence and the
@@ -194,13 +194,13 @@ def dropin_leg(shapes, res, encoder, golden, parity):
         with open(os.path.join(root, 'testset.txt'), 'w') as f:
             f.write('\n'.join(n for n, _, _ in shapes) + '\n')
         modeldir = os.path.join(tmp, 'models')
-        synth.write_model_files(modeldir, 'p2s_max')
+        synth.write_model_files(modeldir, model)
         os.environ['P2S_ENCODER'] = encoder
         stats = {}
 
         def run(outdir, grid):
             opt = ev.parse_arguments(['--indir', root, '--outdir', outdir, '--dataset', 'testset.txt', '--modeldir', modeldir,
-                                      '--models', 'p2s_max', '--query_grid_resolution', str(grid), '--epsilon', str(EPSILON),
+                                      '--models', model, '--query_grid_resolution', str(grid), '--epsilon', str(EPSILON),
                                       '--certainty_threshold', '13', '--sigma', '5', '--workers', '7', '--batchSize', '0'])
             opt.reconstruction = True                          # full_eval.py:45
             t0 = time.time()

@@ -8,7 +8,7 @@ optionally sign propagation + iso-surface, download -- with one dataset-wide sub
 
 --dropin: the same data set THROUGH THE BOUNDARY (bench.py's drop-in leg): the clouds as .npy files, the drop-in's
 ``points_to_surf_eval(opt)`` (all result files written) then ``implicit_surface_to_mesh_directory`` -- the timed region
-of the reference's full_eval.py:44-64 (p2s_max).
+of the reference's full_eval.py:44-64.
 """
 import argparse
 import json
@@ -44,8 +44,8 @@ def main():
         spec.loader.exec_module(bench)
         bench.GRID_RES = args.res
         shapes = [('standin_%03d' % i, c, None) for i, c in enumerate(clouds)]
-        rec = bench.dropin_leg(shapes, args.res, {0: 'fp32', 3: 'bf16x3', 4: 'fp16x2'}[args.encoder], None, parity)
-        rec.update(model='p2s_max', res=args.res, dataset='%d stand-in clouds (synth.standin_cloud, seeds 0..%d)' % (args.shapes, args.shapes - 1))
+        rec = bench.dropin_leg(shapes, args.res, {0: 'fp32', 3: 'bf16x3', 4: 'fp16x2'}[args.encoder], None, parity, model=args.model)
+        rec.update(model=args.model, res=args.res, dataset='%d stand-in clouds (synth.standin_cloud, seeds 0..%d)' % (args.shapes, args.shapes - 1))
         print(json.dumps(rec))
         return
     w, cfg = synth.make_weights(args.model)
