@@ -143,8 +143,16 @@ def merge_vertices(vertices, faces, digits=8):
     referenced = np.zeros(len(v), dtype=bool)
     referenced[f.reshape(-1)] = True
     rows = np.round(v[referenced].astype(np.float64) * 10 ** digits).astype(np.int64)
-    _, first, inv = np.unique(rows, axis=0, return_index=True, return_inverse=True)
+    # group equal rows: through a 64-bit hash of the row (np.unique of a 1-D array is ~10x faster than of rows -- 2 M vertices
+    # per 512^3 shape), verified exactly; a hash collision between different rows falls back to the row-wise unique
+    with np.errstate(over='ignore'):
+        u = rows.astype(np.uint64)
+        h = u[:, 0] * np.uint64(0x9E3779B97F4A7C15) + u[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F) + u[:, 2] * np.uint64(0x165667B19E3779F9)
+    _, first, inv = np.unique(h, return_index=True, return_inverse=True)
     inv = np.asarray(inv).reshape(-1)
+    if not np.array_equal(rows[first[inv]], rows):
+        _, first, inv = np.unique(rows, axis=0, return_index=True, return_inverse=True)
+        inv = np.asarray(inv).reshape(-1)
     order = np.argsort(first, kind='stable')                 # unique rows in order of first occurrence
     rank = np.empty(len(order), dtype=np.int64)
     rank[order] = np.arange(len(order))

@@ -111,3 +111,31 @@ def test_mesh_comparison_pairing_and_csv_equal_the_reference(both_evaluation_mod
             mod.mesh_comparison(new_dir, ref_dir, 1, a, samples_per_model=100, dataset_file_abs=None)
     with pytest.raises(ValueError):
         ours.mesh_comparison(new_dir, ref_dir, 1, a, dataset_file_abs=str(tmp_path / 'nope.txt'))
+
+
+def test_merge_vertices_groups_rows_exactly_like_the_row_wise_unique():
+    """points2surf_amd/ply.py:merge_vertices (what Trimesh(process=True) does before the export, restated): the grouping by a
+    64-bit row hash with exact verification gives the row-wise np.unique's result -- referenced vertices whose coordinates
+    agree after rounding to 1e-8 become one vertex in order of first occurrence, faces re-indexed, none removed"""
+    import numpy as np
+    from points2surf_amd import ply
+    rs = np.random.RandomState(3)
+    n = 20000
+    v = rs.uniform(-1, 1, (n, 3)).astype(np.float32)
+    dup = rs.randint(0, n, 3000)
+    v[dup] = v[(dup * 7) % n]                       # coincident vertices
+    v[::500] = 0.0
+    v[7] = -0.0                                     # -0.0 and 0.0 are the same vertex
+    f = rs.randint(0, n, (30000, 3)).astype(np.int32)
+    mv, mf = ply.merge_vertices(v, f)
+    referenced = np.zeros(n, dtype=bool)
+    referenced[f.reshape(-1)] = True
+    rows = np.round(v[referenced].astype(np.float64) * 1e8).astype(np.int64)
+    uniq, first = np.unique(rows, axis=0, return_index=True)
+    assert mv.shape[0] == uniq.shape[0] and mf.shape == f.shape and mf.dtype == f.dtype
+    # same geometry: every face corner keeps its (rounded) position
+    assert np.array_equal(np.round(mv[mf].astype(np.float64) * 1e8), np.round(v[f].astype(np.float64) * 1e8))
+    # order of first occurrence
+    assert np.array_equal(np.round(mv.astype(np.float64) * 1e8).astype(np.int64), rows[np.sort(first)])
+    # no two kept vertices coincide
+    assert np.unique(np.round(mv.astype(np.float64) * 1e8).astype(np.int64), axis=0).shape[0] == mv.shape[0]
