@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--model', default='p2s_max')
     ap.add_argument('--encoder', default='fp32')
     ap.add_argument('--workers', type=int, default=7)
+    ap.add_argument('--cold', action='store_true', help='no warm-up run: the first call of the process (allocations, tables)')
     args = ap.parse_args()
     os.environ['P2S_ENCODER'] = args.encoder
     import torch
@@ -83,17 +84,18 @@ def main():
                 timers['mesh_comparison'] = time.time() - t0
                 return res_dir_rec
 
-        warm = points_to_surf_eval.parse_arguments(argv)
-        warm.query_grid_resolution = 64
-        warm.outdir = os.path.join(tmp, 'warm')
-        full_eval(warm, {})                                     # warm-up: allocations, generator tables, page cache
-        torch.cuda.synchronize()
+        if not args.cold:
+            warm = points_to_surf_eval.parse_arguments(argv)
+            warm.query_grid_resolution = 64
+            warm.outdir = os.path.join(tmp, 'warm')
+            full_eval(warm, {})                                 # warm-up: allocations, generator tables, page cache
+            torch.cuda.synchronize()
         t0 = time.time()
         rec = full_eval(points_to_surf_eval.parse_arguments(argv), t)
         t['total'] = time.time() - t0
         with open(os.path.join(rec, 'hausdorff_dist_pred_rec.csv')) as f:
             csv = f.read().strip().split('\n')
-        print(json.dumps({'model': args.model, 'encoder': args.encoder, 'res': args.res, 'shapes': 3, 'seconds': t,
+        print(json.dumps({'model': args.model, 'encoder': args.encoder, 'res': args.res, 'shapes': 3, 'cold': bool(args.cold), 'seconds': t,
                           'queries_per_s_reconstruction': t['queries'] / t['reconstruction_pass'],
                           'shapes_per_hour_whole_sequence': 3 / t['total'] * 3600.0,
                           'hausdorff_csv_head': csv[:4]}))
