@@ -46,9 +46,11 @@ __global__ __launch_bounds__(256) void p2s_gemm_kernel(GemmArgs g) {
     const float *a0p = As + (lane & 31) * GS + 4 * (lane >> 5);
     const float *a1p = a0p + 32 * GS;
 
-    for (int kc = 0; kc < g.K; kc += GK) {
-        __syncthreads();
-        // stage A[m0:m0+GM][kc:kc+128]: 8 rows per pass, 32 lanes x 16 B per row (coalesced)
+    // the activation chunk [GM rows][128 k] goes global -> registers -> LDS; r04: the NEXT chunk's loads are issued before
+    // the MFMAs of the current one and land in registers while they run (the kernel used to wait out the load latency
+    // behind every barrier: 55 % of the fp32 MFMA peak).  8 rows per pass, 32 lanes x 16 B per row (coalesced).
+    f32x4 stage[GM / 8];
+    auto fetch = [&](int kc) {
 #pragma unroll
         for (int i = 0; i < GM / 8; ++i) {
             const int r = (tid >> 5) + 8 * i;
@@ -60,9 +62,19 @@ __global__ __launch_bounds__(256) void p2s_gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = g.a2_add ? v[t] + u[t] : ((u[t] > v[t] || u[t] != u[t]) ? u[t] : v[t]);
             }
-            *reinterpret_cast<f32x4 *>(As + r * GS + 4 * (tid & 31)) = v;
+            stage[i] = v;
         }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < GM / 8; ++i) *reinterpret_cast<f32x4 *>(As + ((tid >> 5) + 8 * i) * GS + 4 * (tid & 31)) = stage[i];
+    };
+    fetch(0);
+    for (int kc = 0; kc < g.K; kc += GK) {
+        __syncthreads();              // every wave is done reading the previous chunk
+        commit();
         __syncthreads();
+        if (kc + GK < g.K) fetch(kc + GK);
         const float *wk = Wp + (long long)(kc / 8) * 256;
         f32x4 b = *reinterpret_cast<const f32x4 *>(wk);
 #pragma unroll
@@ -140,9 +152,9 @@ __global__ __launch_bounds__(256) void p2s_gemm_f16_kernel(GemmArgs g) {
     bool range_bad = false;
     const int aoff = (lane & 31) * HS + 8 * (lane >> 5);
 
-    for (int kc = 0; kc < g.K; kc += GK) {
-        __syncthreads();
-        // stage A[m0:m0+GM][kc:kc+128] as its fp16 pair: 8 rows per pass, 32 lanes x 16 B per row (coalesced)
+    // A[m0:m0+GM][kc:kc+128]: global -> registers (the next chunk's loads are in flight during the MFMAs) -> LDS as its fp16 pair
+    f32x4 stage[GM / 8];
+    auto fetch = [&](int kc) {
 #pragma unroll
         for (int i = 0; i < GM / 8; ++i) {
             const int r = (tid >> 5) + 8 * i;
@@ -154,6 +166,14 @@ __global__ __launch_bounds__(256) void p2s_gemm_f16_kernel(GemmArgs g) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = g.a2_add ? v[t] + u[t] : ((u[t] > v[t] || u[t] != u[t]) ? u[t] : v[t]);
             }
+            stage[i] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < GM / 8; ++i) {
+            const int r = (tid >> 5) + 8 * i;
+            const f32x4 v = stage[i];
 #pragma unroll
             for (int t = 0; t < 4; ++t) range_bad = range_bad || fabsf(v[t]) > 6.0e4f;
             uint2 h0, h1;
@@ -165,7 +185,13 @@ __global__ __launch_bounds__(256) void p2s_gemm_f16_kernel(GemmArgs g) {
             *reinterpret_cast<uint2 *>(&As[0][r * HS + 4 * (tid & 31)]) = h0;
             *reinterpret_cast<uint2 *>(&As[1][r * HS + 4 * (tid & 31)]) = h1;
         }
+    };
+    fetch(0);
+    for (int kc = 0; kc < g.K; kc += GK) {
         __syncthreads();
+        commit();
+        __syncthreads();
+        if (kc + GK < g.K) fetch(kc + GK);
         const unsigned short *wk = Wp + (long long)(kc / 16) * 512;
         u32x4 b0 = *reinterpret_cast<const u32x4 *>(wk), b1 = *reinterpret_cast<const u32x4 *>(wk + g.wh_piece);
 #pragma unroll
