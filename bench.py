@@ -214,8 +214,10 @@ def dropin_leg(shapes, res, encoder, golden, parity, model='p2s_max'):
                 os.path.join(rec, 'mesh'), opt.query_grid_resolution, opt.sigma, opt.certainty_threshold, opt.workers)
             return t1 - t0, time.time() - t1, rec
 
-        run(os.path.join(tmp, 'warm'), 64)                      # warm-up (block cache, generator session, page cache)
-        t_eval, t_mesh, rec = run(os.path.join(tmp, 'out'), res)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):            # the drop-in prints what the reference prints; stdout carries
+            run(os.path.join(tmp, 'warm'), 64)                  # the ONE JSON line only.  warm-up: block cache, page cache
+            t_eval, t_mesh, rec = run(os.path.join(tmp, 'out'), res)
         nq, worst, flips, files = 0, 0.0, 0, 0
         for name, _, ref in shapes:
             sdf = np.load(os.path.join(rec, 'dist_ms', name + '.xyz.npy'))

@@ -106,10 +106,11 @@ def test_golden_check_classifies_a_flipped_sign_with_device_and_cpu_logits(fixtu
 
 
 @pytest.mark.parametrize('encoder', ['fp32', 'fp16x2'])
-def test_dropin_leg_of_the_bench(encoder, golden_dir):
+def test_dropin_leg_of_the_bench(encoder, golden_dir, capsys):
     """bench.py's ``secondary.dropin_*`` leg (the hot path measured through boundary B1: the drop-in's
     points_to_surf_eval + implicit_surface_to_mesh_directory, files in / files out) at grid 32 on the three clouds: every
-    file of the contract is written, the SDF equals the reference's golden, the environment is left as it was"""
+    file of the contract is written, the SDF equals the reference's golden, the environment is left as it was, and what the
+    drop-in prints (the reference's progress lines) stays off stdout, which carries the bench's one JSON line"""
     import importlib.util
     import numpy as np
     spec = importlib.util.spec_from_file_location('p2s_bench', os.path.join(REPO, 'bench.py'))
@@ -130,6 +131,8 @@ def test_dropin_leg_of_the_bench(encoder, golden_dir):
         while dropin in sys.path:
             sys.path.remove(dropin)
     assert os.environ.get('P2S_ENCODER') == before
+    cap = capsys.readouterr()
+    assert cap.out == '' and 'evaluated' in cap.err
     assert rec['files_written'] == 7 * 3 and rec['shapes'] == 3 and rec['queries'] == sum(s[2].shape[0] for s in shapes)
     v = rec['vs_reference_golden']
     assert v['max_abs_dsdf'] < 1e-5 and v['sign_flips'] == 0
