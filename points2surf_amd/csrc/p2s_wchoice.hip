@@ -37,7 +37,8 @@
 namespace {
 
 constexpr int WC_MAX_SEL = 1024;     // sub_sample_size limit (LDS arrays)
-constexpr int WC_MAX_NODES = 8192;   // plan nodes held in LDS -> clouds up to ~390k points
+constexpr int WC_MAX_NODES = 8192;   // plan nodes held in LDS -> clouds up to 524,288 points (the found-bitmap of the
+                                     // offsets kernel is the tighter limit: 185,664 points, wc_offsets_lds_bytes)
 constexpr int PW_BLOCK = 128;        // numpy PW_BLOCKSIZE
 constexpr int NP_BUFSIZE = 8192;     // numpy ufunc buffer size (np.getbufsize())
 

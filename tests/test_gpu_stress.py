@@ -67,6 +67,7 @@ def test_knn_selection_kernel_returns_the_same_set_as_the_sorting_kernel(k):
             rb = b[i][np.lexsort(b[i].T[::-1])]
             assert np.array_equal(ra, rb, equal_nan=True), (i, k)
         cloud.close()
+    model.close()
 
 
 def test_query_grid_random_clouds_match_oracle():
@@ -108,3 +109,52 @@ def test_forward_extreme_but_finite_inputs(fixture_cloud):
     logits, _ = m.forward(t(patch), t(sub), t(q))
     err = np.abs(logits.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
     assert err < 1e-5, err
+
+
+@pytest.mark.parametrize('name,n_pts', [('p2s_max', 2000000), ('p2s_vanilla', 185000)])
+def test_scans_beyond_the_reference_cap(name, n_pts):
+    """raw scans larger than what make_pc_dataset.py:39 lets through (150,000 points) -- nothing in points_to_surf_eval /
+    data_loader.py limits the cloud: 2,000,000 points for the uniform sub-sample, 185,000 for the distance-weighted one
+    (its per-query found-bitmap lives in LDS: 185,664 points is the limit, see the next test).  kNN ids, radius, the
+    sub-sample (``randint`` draws / ``choice(p, replace=False)``), generator position and SDF of the GT-query pass
+    against the oracle"""
+    import torch
+    from oracle import p2s_oracle as O
+    from points2surf_amd import engine, synth
+    w, cfg = synth.make_weights(name)
+    model = engine.Model(w, cfg)
+    pts = synth.make_cloud(n_pts, seed=9)
+    rng = np.random.default_rng(3)
+    nq = 48
+    q = (pts[rng.integers(0, pts.shape[0], nq)] + rng.normal(0, 0.004, (nq, 3))).astype(np.float32)
+    cloud = engine.Cloud(pts)
+    ids, _, rad = cloud.knn_patch(torch.from_numpy(q).cuda(), 300)
+    ref_ids = O.knn_ids(pts, q, 300)
+    r_ref, _ = O.patch_radius_and_ps(pts, ref_ids, q)
+    assert np.array_equal(ids.cpu().numpy(), ref_ids) and np.array_equal(rad.cpu().numpy(), r_ref)
+    r_dev, r_cpu = engine.Rng(77), O.LegacyMT19937(77)
+    sdf = engine.infer_queries(model, cloud, r_dev, None, torch.from_numpy(q).cuda()).cpu().numpy()
+    ref = O.infer_queries(w, cfg, pts, q, r_cpu, None)
+    nxt = r_dev.subsample_uniform(cloud, 1, 7, want_pts=False)[0].cpu().numpy().reshape(-1)
+    assert np.array_equal(nxt, r_cpu.randint(pts.shape[0], 7))             # the same number of draws consumed
+    assert np.abs(sdf - ref).max() < 1e-5 and np.array_equal(np.sign(sdf), np.sign(ref))
+    cloud.close()
+    model.close()
+
+
+@pytest.mark.parametrize('n_pts,what', [(186000, 'LDS bitmap'), (2000000, 'summation nodes')])
+def test_weighted_subsample_refuses_clouds_beyond_its_limit_loudly(n_pts, what):
+    """the distance-weighted sub-sample (p2s_vanilla and the ablations with uniform_subsample = 0) keeps one bit per
+    cloud point in LDS: clouds of more than 185,664 points (the reference's tooling stops at 150,000) are refused with
+    an error that names the limit -- before a single random word is consumed -- and never answered approximately"""
+    import torch
+    from points2surf_amd import engine, synth, _lib
+    pts = synth.make_cloud(n_pts, seed=2)
+    cloud = engine.Cloud(pts)
+    r = engine.Rng(5)
+    q = torch.from_numpy(pts[:8].copy()).cuda()
+    with pytest.raises(_lib.P2SError, match=what):
+        r.subsample_weighted(cloud, q, 1000)
+    got = r.subsample_uniform(cloud, 1, 9, want_pts=False)[0].cpu().numpy().reshape(-1)
+    assert np.array_equal(got, np.random.RandomState(5).randint(0, n_pts, 9))      # the stream is where it was
+    cloud.close()
