@@ -37,8 +37,8 @@
 namespace {
 
 constexpr int WC_MAX_SEL = 1024;     // sub_sample_size limit (LDS arrays)
-constexpr int WC_MAX_NODES = 8192;   // plan nodes held in LDS -> clouds up to 524,288 points (the found-bitmap of the
-                                     // offsets kernel is the tighter limit: 185,664 points, wc_offsets_lds_bytes)
+constexpr int WC_MAX_NODES = 8192;   // plan nodes held in LDS -> clouds up to 524,288 points (the found-bitmap next to
+                                     // the chain kernel's arrays is the tighter limit: 475,040 points)
 constexpr int PW_BLOCK = 128;        // numpy PW_BLOCKSIZE
 constexpr int NP_BUFSIZE = 8192;     // numpy ufunc buffer size (np.getbufsize())
 
@@ -1147,6 +1147,60 @@ __global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a_in) {
     if (a.stats && tid < 16) a.stats[tid] = s_stats[tid];
 }
 
+// The same contract as wc_offsets_kernel for clouds whose found-bitmap does not fit next to that kernel's ring and
+// windows (more than 185,664 points): the complete algorithm query by query, in order, with the LDS layout of the ids
+// kernel (bitmaps of up to ~570k points).  80 us per query instead of 8 -- but it only sees what the speculative chain
+// left over (normally nothing), or everything when that chain is switched off.
+__global__ __launch_bounds__(256) void wc_offsets_plain_kernel(WcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
+    __shared__ int wsum[16];
+    __shared__ double wsumd[16];
+    if (a.meta[1] != 0) return;
+    const int tid = threadIdx.x;
+    long long q0 = 0, s = a.meta[0];
+    if (a.ctl) {
+        q0 = a.ctl[0];
+        if (q0 >= a.nq) return;
+        s = a.ctl[1];
+    }
+    const WcLds l = wc_carve(wc_lds, a.n);
+    const int BW = (a.n + 31) >> 5;
+    for (int i = tid; i < BW; i += 256) l.bitmap[i] = 0;
+    __syncthreads();
+    for (long long q = q0; q < a.nq; ++q) {
+        if (s + 2LL * a.nsel > a.cap_words) {
+            if (tid == 0) {
+                a.meta[1] = 2;
+                a.meta[0] = s;
+            }
+            return;
+        }
+        WcQuery qa;
+        qa.Sq = a.S + (size_t)q * a.n;
+        qa.Rq = a.R + (size_t)q * a.K;
+        qa.Stot = a.stot[q];
+        qa.words = a.words + s;
+        qa.words_left = a.cap_words - s;
+        qa.n = a.n;
+        qa.K = a.K;
+        qa.nsel = a.nsel;
+        qa.pre_bin = nullptr;
+        qa.pre_s = nullptr;
+        const long long used = wc_full_query<false>(qa, l, wsum, wsumd, nullptr);
+        if (used < 0) {
+            if (tid == 0) {
+                a.meta[1] = 3;
+                a.meta[0] = s;
+            }
+            return;
+        }
+        if (tid == 0) a.base[q] = s;
+        s += used;
+        __syncthreads();
+    }
+    if (tid == 0) a.meta[0] = s;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // offsets, parallel: speculation tables + a light chain (default; the serial kernel above remains as the fallback).
 //
@@ -1835,11 +1889,16 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     // the offsets kernel is one latency-bound workgroup running next to the MFMA-saturated encoders: give it a CU of
     // its own by claiming most of that CU's LDS (same placement trick as the serial generator)
     const size_t hog = getenv("P2S_RNG_LDS_HOG") ? (size_t)atoi(getenv("P2S_RNG_LDS_HOG")) : 120 * 1024;
-    if (lds_off > 160 * 1024 - 4096) {
-        p2s_set_error("p2s_subsample_weighted: cloud of %d points does not fit the LDS bitmap", n);
+    // clouds beyond 185,664 points: the serial kernel's ring + windows leave no room for the found-bitmap; the plain
+    // kernel (bitmap + the arrays of one query, like the ids kernel) takes its place
+    const bool big = lds_off > 160 * 1024 - 4096;
+    const size_t lds_chain_max = 160 * 1024 - 4096 - SP_B * 8 - SP_B * 4 - 1024;      // the chain kernel's static arrays
+    if (lds_ids > lds_chain_max) {
+        p2s_set_error("p2s_subsample_weighted: cloud of %d points does not fit the LDS bitmap (limit: %d points)", n,
+                      (int)((lds_chain_max - wc_lds_bytes(0) - 16) / 6 * 32));
         return P2S_ECAPACITY;
     }
-    if (nq >= 64) lds_off = std::max(lds_off, hog);
+    if (nq >= 64 && !big) lds_off = std::max(lds_off, hog);
     // the chain workgroup of a full block claims a CU of its own (LDS no encoder workgroup fits next to): sharing a
     // CU with the encoders' MFMA-saturated waves it gets an instruction issued every ~200 cycles (measured: 1.4 us
     // per query of the walk whether the table sits in global memory, LDS or registers; 80 us per fallback instead of
@@ -1848,7 +1907,8 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     {   // per device (a process may drive several); the call is cheap
         (void)hipFuncSetAttribute((const void *)wc_offsets_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         (void)hipFuncSetAttribute((const void *)wc_ids_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)wc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096 - SP_B * 8 - SP_B * 4 - 1024);
+        (void)hipFuncSetAttribute((const void *)wc_offsets_plain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void *)wc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain_max);
         (void)hipFuncSetAttribute((const void *)wc_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NP_BUFSIZE + WC_MAX_NODES) * 4);
     }
     long long *meta = p2s_rng_raw_meta(r);
@@ -1892,7 +1952,10 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
         if (fixed) {
             // no serial dependence between the queries: the ids kernel alone (it reports the last query's consumption)
         } else if (serial_only) {
-            hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(WC_NT), lds_off, s, a);
+            if (big)
+                hipLaunchKernelGGL(wc_offsets_plain_kernel, dim3(1), dim3(256), lds_ids, s, a);
+            else
+                hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(WC_NT), lds_off, s, a);
         } else {
             // speculation tables on all CUs + a light chain per block of SP_B queries; two spare pairs for blocks that
             // end early (start outside the window); whatever is still unresolved then goes through the serial kernel
@@ -1908,7 +1971,10 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
                 hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), pr < (cur + SP_B - 1) / SP_B ? lds_chain : lds_ids, s, a, sp);
             }
             a.ctl = sp.ctl;
-            hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(WC_NT), wc_offsets_lds_bytes(n), s, a);
+            if (big)
+                hipLaunchKernelGGL(wc_offsets_plain_kernel, dim3(1), dim3(256), lds_ids, s, a);
+            else
+                hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(WC_NT), wc_offsets_lds_bytes(n), s, a);
             a.ctl = nullptr;
         }
         if (ids_out_dev) hipLaunchKernelGGL(wc_ids_kernel, dim3(cur), dim3(256), lds_ids, s, a);   // NULL: advance the stream only

@@ -111,11 +111,12 @@ def test_forward_extreme_but_finite_inputs(fixture_cloud):
     assert err < 1e-5, err
 
 
-@pytest.mark.parametrize('name,n_pts', [('p2s_max', 2000000), ('p2s_vanilla', 185000)])
+@pytest.mark.parametrize('name,n_pts', [('p2s_max', 2000000), ('p2s_vanilla', 185000), ('p2s_vanilla', 470000)])
 def test_scans_beyond_the_reference_cap(name, n_pts):
     """raw scans larger than what make_pc_dataset.py:39 lets through (150,000 points) -- nothing in points_to_surf_eval /
-    data_loader.py limits the cloud: 2,000,000 points for the uniform sub-sample, 185,000 for the distance-weighted one
-    (its per-query found-bitmap lives in LDS: 185,664 points is the limit, see the next test).  kNN ids, radius, the
+    data_loader.py limits the cloud: 2,000,000 points for the uniform sub-sample; 185,000 and 470,000 for the
+    distance-weighted one (its per-query found-bitmap lives in LDS: up to 185,664 points next to the serial kernel's ring,
+    beyond that with the plain remainder kernel up to 475,040 points -- see the next tests).  kNN ids, radius, the
     sub-sample (``randint`` draws / ``choice(p, replace=False)``), generator position and SDF of the GT-query pass
     against the oracle"""
     import torch
@@ -142,10 +143,34 @@ def test_scans_beyond_the_reference_cap(name, n_pts):
     model.close()
 
 
-@pytest.mark.parametrize('n_pts,what', [(186000, 'LDS bitmap'), (2000000, 'summation nodes')])
+@pytest.mark.parametrize('serial', [False, True])
+def test_weighted_subsample_of_a_300k_cloud_also_through_the_plain_serial_kernel(serial, monkeypatch):
+    """clouds beyond 185,664 points: the offsets pass behind the speculative chain is wc_offsets_plain_kernel (the whole
+    algorithm per query, in order); ``P2S_WC_SERIAL=1`` sends every query through it.  ids and stream position == numpy's
+    ``choice(N, 1000, replace=False, p)`` as the oracle restates it"""
+    import torch
+    from oracle import p2s_oracle as O
+    from points2surf_amd import engine, synth
+    if serial:
+        monkeypatch.setenv('P2S_WC_SERIAL', '1')
+    pts = synth.make_cloud(300000, seed=12)
+    rng = np.random.default_rng(4)
+    nq = 70                                                            # >= 64: the chain claims its own CU
+    q = (pts[rng.integers(0, pts.shape[0], nq)] + rng.normal(0, 0.01, (nq, 3))).astype(np.float32)
+    cloud = engine.Cloud(pts)
+    r_dev, r_cpu = engine.Rng(21), O.LegacyMT19937(21)
+    ids = r_dev.subsample_weighted(cloud, torch.from_numpy(q).cuda(), 1000, want_pts=False)[0].cpu().numpy()
+    ref = np.stack([O.subsample_ids(r_cpu, pts, q[i], 1000, uniform=False) for i in range(nq)])
+    assert np.array_equal(ids.reshape(nq, 1000), ref)
+    nxt = r_dev.subsample_uniform(cloud, 1, 7, want_pts=False)[0].cpu().numpy().reshape(-1)
+    assert np.array_equal(nxt, r_cpu.randint(pts.shape[0], 7))
+    cloud.close()
+
+
+@pytest.mark.parametrize('n_pts,what', [(476000, 'LDS bitmap'), (2000000, 'summation nodes')])
 def test_weighted_subsample_refuses_clouds_beyond_its_limit_loudly(n_pts, what):
     """the distance-weighted sub-sample (p2s_vanilla and the ablations with uniform_subsample = 0) keeps one bit per
-    cloud point in LDS: clouds of more than 185,664 points (the reference's tooling stops at 150,000) are refused with
+    cloud point in LDS: clouds of more than 475,040 points (the reference's tooling stops at 150,000) are refused with
     an error that names the limit -- before a single random word is consumed -- and never answered approximately"""
     import torch
     from points2surf_amd import engine, synth, _lib
