@@ -254,3 +254,27 @@ def test_ball_patch_on_odd_clouds(n, seed):
         assert np.array_equal(patch.cpu().numpy().view(np.uint32), patch_r.view(np.uint32))
         assert _same_generator(rng, rs)
     cloud.close()
+
+
+def test_ball_patch_on_a_million_point_scan():
+    """a raw scan of 1,000,000 points (the reference's tooling stops at 150,000, make_pc_dataset.py:39; nothing in the
+    fixed-radius path of data_loader.py does): balls of 20,000-80,000 hits, every list through the global-memory shuffle.
+    Counts, ids, patches and generator position == scipy's tree order + numpy's legacy ``choice``"""
+    import torch
+    from points2surf_amd import engine, synth
+    pts = synth.make_cloud(1000000, seed=31)
+    tree = spatial.cKDTree(pts, 1000)
+    cloud = engine.Cloud(pts)
+    q = _queries(pts, 40, 9, spread=0.01)
+    for radius in (0.1, 0.2):
+        ids_r, patch_r, counts, _, rs = _reference_patches(6, pts, tree, q, radius, 300)
+        assert counts.max() > 8192
+        got = engine.ball_count(cloud, torch.from_numpy(q).cuda(), radius).cpu().numpy()
+        assert np.array_equal(got, counts)
+        rng = engine.Rng(6)
+        ids, patch, _, _ = engine.ball_patch(cloud, rng, torch.from_numpy(q).cuda(), radius, 300)
+        rng.check()
+        assert np.array_equal(ids.cpu().numpy(), ids_r), radius
+        assert np.array_equal(patch.cpu().numpy().view(np.uint32), patch_r.view(np.uint32))
+        assert _same_generator(rng, rs)
+    cloud.close()
