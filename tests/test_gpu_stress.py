@@ -67,7 +67,6 @@ def test_knn_selection_kernel_returns_the_same_set_as_the_sorting_kernel(k):
             rb = b[i][np.lexsort(b[i].T[::-1])]
             assert np.array_equal(ra, rb, equal_nan=True), (i, k)
         cloud.close()
-    model.close()
 
 
 def test_query_grid_random_clouds_match_oracle():

@@ -209,8 +209,9 @@ def test_speculative_offsets_across_blocks_match_numpy_and_serial_kernel(fixture
 
 
 def test_weighted_at_the_size_cap(torch_cuda):
-    """the largest clouds the weighted sub-sample takes (LDS bitmap of the in-place algorithm): 170,000
-    points work and match numpy; 260,000 are refused with an error code, not a wrong result"""
+    """the clouds the weighted sub-sample takes (LDS bitmap of the in-place algorithm): 170,000 points work
+    and match numpy, 260,000 too since r04 (the plain remainder kernel behind the speculative chain); 480,000 are refused
+    with an error code, not a wrong result (more sizes: tests/test_gpu_stress.py)"""
     from points2surf_amd import engine, _lib
     g = np.random.default_rng(17)
     pts = g.uniform(-0.7, 0.7, (170000, 3)).astype(np.float32)
@@ -221,6 +222,12 @@ def test_weighted_at_the_size_cap(torch_cuda):
     r.check()
     ref, rs = _numpy_reference(3, pts, q, 1000)
     assert np.array_equal(got, ref)
-    big = engine.Cloud(g.uniform(-0.7, 0.7, (260000, 3)).astype(np.float32))
+    pts2 = g.uniform(-0.7, 0.7, (260000, 3)).astype(np.float32)
+    mid = engine.Cloud(pts2)
+    r2 = engine.Rng(3)
+    got2 = r2.subsample_weighted(mid, torch_cuda.from_numpy(q).cuda(), 1000, want_pts=False)[0].cpu().numpy()
+    r2.check()
+    assert np.array_equal(got2, _numpy_reference(3, pts2, q, 1000)[0])
+    big = engine.Cloud(g.uniform(-0.7, 0.7, (480000, 3)).astype(np.float32))
     with pytest.raises(_lib.P2SError):
         engine.Rng(3).subsample_weighted(big, torch_cuda.from_numpy(q).cuda(), 1000, want_pts=False)
