@@ -31,7 +31,7 @@ extern "C" {
 #define P2S_EINVAL       -1   /* bad argument / unsupported configuration */
 #define P2S_EHIP         -2   /* HIP runtime error (see p2s_last_error) */
 #define P2S_ENOMEM       -3
-#define P2S_ECAPACITY    -4   /* caller-provided output buffer too small */
+#define P2S_ECAPACITY    -4   /* caller-provided output buffer too small, or an input beyond a documented size limit */
 #define P2S_ENODEVICE    -5   /* no gfx950 device visible */
 
 typedef struct p2s_model_s *p2s_model_t;
@@ -219,7 +219,8 @@ int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t n_queries, int n,
  * ids = rng.choice(N, n, replace=False, p=p), consumed in query order from the same continuous stream --
  * bit-identical to numpy's legacy RandomState.  Needs the jump tables (p2s_rng_set_jump_tables).
  * q_dev [Q][3] query points (model space), ids_out_dev [Q][n] int32 (NULL = advance only), pts_out_dev as above.
- * Errors found on the device (degenerate distances) are reported by p2s_rng_check. */
+ * Errors found on the device (degenerate distances) are reported by p2s_rng_check.  n <= 1024; clouds of more than
+ * 475,040 points are refused with P2S_ECAPACITY before the stream is touched (LDS bitmap of the in-place algorithm). */
 int p2s_subsample_weighted(p2s_rng_t r, p2s_cloud_t c, const float *q_dev, int64_t n_queries, int n,
                            int32_t *ids_out_dev, float *pts_out_dev, void *stream);
 /* fixed mode (train --fixed_subsample 1; reference source/base/utils.py:210-211): ``rng.seed(seed)`` before EVERY
