@@ -380,8 +380,9 @@ int p2s_write_coff_samples(const char *path, const float *query_host, const floa
 typedef struct {
     double  ms_chain_stn, ms_stn_head, ms_chain_main, ms_decoder, ms_knn, ms_subsample, ms_grid;
     int64_t queries;
-    int64_t launches_chain;      /* number of point-chain kernel launches (2 per chunk) */
-    double  reserved[8];
+    int64_t launches_chain;      /* number of point-chain kernel launches (2 per chunk; 3 with a QSTN) */
+    double  ms_chain_qstn;       /* QSTN trunk launch (models with use_point_stn); its head layers count under ms_stn_head */
+    double  reserved[7];
 } p2s_counters;
 int p2s_set_profiling(p2s_model_t m, int enabled);
 int p2s_get_counters(p2s_model_t m, p2s_counters *out);

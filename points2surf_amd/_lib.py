@@ -22,7 +22,7 @@ class Counters(ctypes.Structure):
                 ('ms_chain_main', ctypes.c_double), ('ms_decoder', ctypes.c_double),
                 ('ms_knn', ctypes.c_double), ('ms_subsample', ctypes.c_double), ('ms_grid', ctypes.c_double),
                 ('queries', ctypes.c_int64), ('launches_chain', ctypes.c_int64),
-                ('reserved', ctypes.c_double * 8)]
+                ('ms_chain_qstn', ctypes.c_double), ('reserved', ctypes.c_double * 7)]
 
 
 # name -> (restype, argtypes): every symbol include/p2s_hip.h declares

@@ -294,6 +294,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
     int rc;
     const bool bf16 = m->cfg.encoder_bf16 != 0;
     const int ev0 = p2s_prof_mark(m, s);
+    int evq1 = -1, evq2 = -1;                         // QSTN models: behind the QSTN trunk launch / behind its head layers
 
     const float *rot = nullptr;
     if (m->cfg.use_point_stn) {
@@ -330,6 +331,8 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
             a.br[1].n_items = 0;
         }
         if ((rc = bf16 ? p2s_launch_chain_bf16(a, s) : p2s_launch_chain(a, s))) return rc;
+        evq1 = p2s_prof_mark(m, s);
+        m->counters.launches_chain += 1;
         GemmArgs g;
         memset(&g, 0, sizeof(g));
         g.A = w.qg; g.A2 = qstn_shared ? w.qg2 : nullptr; g.a2_z = 0; g.lda = 1024; g.a_z = 0; g.W[0] = g.W[1] = W + o.qstn.f1; g.bias[0] = g.bias[1] = W + o.qstn.fb1;
@@ -344,6 +347,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         if ((rc = p2s_launch_gemm(g, s))) return rc;
         if ((rc = p2s_launch_qstn_tail(w.qh2, W + o.qstn.f3, W + o.qstn.fb3, w.rot, C, 256, s))) return rc;
         rot = w.rot;
+        evq2 = p2s_prof_mark(m, s);
     }
 
     // ---- pass 1: stem + STN trunk + max-pool, both encoders (global items first: longest first) ----
@@ -466,7 +470,13 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         if ((rc = p2s_launch_decoder_tail(w.d3, W + o.d4, W + o.db4, radius, logits_out, sdf_out, C, 128, m->cfg.output_dim, s))) return rc;
     }
     const int ev4 = p2s_prof_mark(m, s);
-    p2s_prof_span(m, ST_CHAIN_STN, ev0, ev1);
+    if (evq1 >= 0 && evq2 >= 0) {
+        p2s_prof_span(m, ST_CHAIN_QSTN, ev0, evq1);
+        p2s_prof_span(m, ST_HEAD, evq1, evq2);
+        p2s_prof_span(m, ST_CHAIN_STN, evq2, ev1);
+    } else {
+        p2s_prof_span(m, ST_CHAIN_STN, ev0, ev1);
+    }
     p2s_prof_span(m, ST_HEAD, ev1, ev2);
     p2s_prof_span(m, ST_CHAIN_MAIN, ev2, ev3);
     p2s_prof_span(m, ST_DECODER, ev3, ev4);
@@ -522,6 +532,7 @@ void p2s_prof_collect(p2s_model_s *m) {
             case ST_KNN: dst = &m->counters.ms_knn; break;
             case ST_SUB: dst = &m->counters.ms_subsample; break;
             case ST_GRID: dst = &m->counters.ms_grid; break;
+            case ST_CHAIN_QSTN: dst = &m->counters.ms_chain_qstn; break;
         }
         if (dst) *dst += ms;
     }

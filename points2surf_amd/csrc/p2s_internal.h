@@ -64,7 +64,7 @@ inline int p2s_enc_f16(const p2s_model_cfg &c) { return c.encoder_bf16 == 4 ? 1 
 // sticky range flag of the fp16 pair mode: P2S_EINVAL (and cleared) if it was raised; synchronises `s`
 int p2s_model_check_range(p2s_model_s *m, hipStream_t s);
 
-enum P2SStage { ST_CHAIN_STN = 0, ST_HEAD, ST_CHAIN_MAIN, ST_DECODER, ST_KNN, ST_SUB, ST_GRID };
+enum P2SStage { ST_CHAIN_STN = 0, ST_HEAD, ST_CHAIN_MAIN, ST_DECODER, ST_KNN, ST_SUB, ST_GRID, ST_CHAIN_QSTN };
 int p2s_prof_mark(p2s_model_s *m, hipStream_t s);                 // event index or -1
 void p2s_prof_span(p2s_model_s *m, int stage, int a, int b);
 void p2s_prof_reset(p2s_model_s *m);
@@ -151,11 +151,15 @@ struct p2s_rng_s {
     int *blk_cum = nullptr;        // [S][B] cumulative accepted count per block
     long long *meta = nullptr;     // [S] offsets + locate record + sticky error flag + raw-request record
     // weighted sub-sample workspace (p2s_wchoice.hip), grown on demand
-    double *wc_S = nullptr;        // [C][n]   exact prefix sums of the probabilities
-    void *wc_T = nullptr;          // [C][K]   guide records of the cdf (32 B each)
-    double *wc_stot = nullptr;     // [C]
-    unsigned short *wc_J = nullptr; // [11][SP_B][SP_W] jump tables of the offsets chain (p2s_wchoice.hip)
+    double *wc_S[2] = {};          // [C][n]   exact prefix sums of the probabilities (second set: stream skipping overlaps
+    void *wc_T[2] = {};            // [C][K]   guide records of the cdf (16 B each)      the tables of the next batch)
+    double *wc_sc[2] = {};         // [C]      per-query scalars (stot, word offset, pmax, dmax + sum, mu)
+    void *wc_spec = nullptr;       // speculation block: ctl, klo [SP_B], rtab [SP_B][SP_W]
+    unsigned short *wc_J = nullptr; // [2 SP_B][SP_W] ruler of jump tables of the offsets chain (p2s_wchoice.hip)
     size_t wc_cap_q = 0, wc_cap_n = 0, wc_cap_k = 0;
+    int wc_bufs = 0;
+    hipStream_t wc_stream2 = nullptr;      // tables of batch b + 1 while the offsets pass of batch b runs (stream skipping)
+    hipEvent_t wc_ev_tab[2] = {}, wc_ev_use[2] = {}, wc_ev_in = nullptr;
     // fixed-radius patches (p2s_ball.hip): hit counts of a shape's queries (device + pinned host), batch work space
     int32_t *ball_counts_dev = nullptr, *ball_counts_host = nullptr;
     size_t ball_counts_cap = 0;

@@ -16,12 +16,13 @@
 //    table over K ~ N buckets, R[b] = (i = #{cdf_i <= b/K}, S_{i-1}, S_i, S_{i+1}), answers most look-ups with one
 //    32-byte load.
 //
-// Three kernels per chunk of queries:
+// Three stages per batch of queries:
 //   wc_tables_kernel   one workgroup per query, fully parallel: distances, max, plan-ordered sum, exact prefix sums
 //                      S[q][N] (float64), guide records R[q][K].  HBM-resident (288 GB: ~1.4 MB per query).
-//   wc_offsets_kernel  ONE workgroup walks the queries in order -- the number of random words a query consumes
-//                      depends on its collisions, so the stream position is a true serial dependence -- and computes
-//                      nothing but that: where every query's draws start.
+//   offsets pass       where every query's draws start in the stream -- the number of random words a query consumes
+//                      depends on its collisions, so the stream position is a true serial dependence: speculation
+//                      tables over candidate starts on all CUs (wc_spec_kernel), jump tables, one light chain
+//                      workgroup (below).
 //   wc_ids_kernel      one workgroup per query again: with the offsets known, the complete algorithm in parallel.
 // The random words come from a raw session of the jump-ahead generator (p2s_rng.hip); the word cursor lives on the
 // device and the generator is advanced to it when the session is closed.
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
                                                         WcPlanDev plan, int K,
                                                         double *__restrict__ S_all, WcRec *__restrict__ R_all,
                                                         double *__restrict__ stot_all, float *__restrict__ pmax_all,
-                                                        float *__restrict__ mu_all, int nsel, long long *__restrict__ err) {
+                                                        float *__restrict__ mu_all, float *__restrict__ dsum_all, int nsel,
+                                                        long long *__restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) float wc_tab_lds[];
     float *pcs = wc_tab_lds;                       // [NP_BUFSIZE] clipped probabilities of one numpy buffer chunk
     float *nodes = wc_tab_lds + NP_BUFSIZE;        // [plan.n_nodes]
@@ -210,6 +212,10 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
         __syncthreads();
     }
     const float sum = nodes[plan.root];
+    if (tid == 0) {                                   // what turns a point into its probability again (wc_spec_kernel)
+        dsum_all[2 * qi] = dmax;
+        dsum_all[2 * qi + 1] = sum;
+    }
 
     // pass 3: p_i = pc_i / sum (float32) -> the total mass S_N (exact in any order), power sums, max
     double acc = 0.0, acc2 = 0.0, acc3 = 0.0;
@@ -256,12 +262,8 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
         mu_all[qi] = (float)(0.5 * ns * (ns - 1.0) * s2 - ns * (ns - 1.0) * (ns - 2.0) / 6.0 * s3);
     }
     if (tid == 0) {
-        // pmax, and the number of cells of the close-pair grid of the serial kernel: pitch 1/G >= pmax / S_N
-        const float pmx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
-        double Gd = floor(Stot / ((double)pmx * (1.0 + 1e-9)));
-        Gd = Gd < 1.0 ? 1.0 : (Gd > 65536.0 ? 65536.0 : Gd);
-        pmax_all[2 * qi] = pmx;
-        pmax_all[2 * qi + 1] = __int_as_float((int)Gd);
+        pmax_all[2 * qi] = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));     // widest bin of the cdf x S_N
+        pmax_all[2 * qi + 1] = 0.0f;
     }
     __syncthreads();                                  // red_d is reused by the scan below
 
@@ -409,9 +411,6 @@ __device__ __forceinline__ WcLoc wc_finish(const double *__restrict__ Sq, int n,
 __device__ __forceinline__ int wc_quick_bin(double c0, int i, int more, double x) {
     return x < c0 ? i : (more ? -1 : i + 1);
 }
-__device__ __forceinline__ int wc_finish_cold(const double *Sq, int n, int i, double Stot, double x) {
-    return wc_finish(Sq, n, i, 0, n, 0.0, Stot, x).bin;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // LDS layout shared by the kernels below
@@ -460,10 +459,6 @@ struct WcQuery {
     const uint32_t *words;       // word o of this query's first draw at words[0]
     long long words_left;        // words available from there
     int n, K, nsel;
-    // optional: the first round's look-ups, already done by the speculation pass for the draws of its window
-    // (bin, S_bin, S_{bin-1} of draw d at pre_bin[d], pre_s[d]); null = look them up here
-    const int *pre_bin;
-    const double2 *pre_s;
 };
 
 template <bool WRITE>
@@ -488,21 +483,7 @@ __device__ __forceinline__ long long wc_full_query(const WcQuery &qa, const WcLd
             bins[j] = 0;
             sb[j] = sp[j] = 0.0;
         }
-        if (m_found == 0 && qa.pre_bin) {
-            // first round from the speculation pass's window: three coalesced loads per draw instead of the guide
-            // record + the S values around the bin (random accesses: most of this function's time under load)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int d = tid * per + j;
-                if (j < per && d < m) {
-                    valid |= 1u << j;
-                    bins[j] = qa.pre_bin[d];
-                    const double2 ss = qa.pre_s[d];
-                    sb[j] = ss.x;
-                    sp[j] = ss.y;
-                }
-            }
-        } else if (m_found == 0) {
+        if (m_found == 0) {
             // first round (nothing found yet, every lane has up to 4 draws): straight-line code, lanes past the last
             // draw repeat it, so that all loads of a phase are in flight together
             uint2 wpair[4];
@@ -690,600 +671,99 @@ struct WcArgs {
     const double *S;          // [nq][n]
     const WcRec *R;           // [nq][K]
     const double *stot;       // [nq]
-    const float *pmax;        // [nq][2] largest probability of the query; cells of its close-pair grid (int bits)
+    const float *pmax;        // [nq][2] largest probability of the query; (unused int)
+    const float *dsum;        // [nq][2] largest distance, np.sum of the clipped probabilities: p_i is re-derived from the cloud
+    const float *pts;         // [n][3] the cloud
+    const float *q;           // [nq][3] the queries of the batch
     const uint32_t *words;    // raw tempered words from the generator's position
     long long cap_words;      // words this request may consume
-    long long alloc_words;    // words readable in the buffer (>= cap_words)
     int n, K, nq, nsel;
-    long long *base;          // [nq] word offset of every query's first draw (offsets kernel -> ids kernel)
+    long long *base;          // [nq] word offset of every query's first draw (offsets pass -> ids kernel)
     int32_t *ids_out;         // [nq][nsel]
     long long *meta;          // [0] words consumed (out), [1] sticky error
-    long long *stats;         // development counters (null = off): [0] fallbacks, [1] window misses
-    const long long *ctl;     // serial kernel: start at query ctl[0], word ctl[1] (null = query 0, word meta[0])
+    long long *stats;         // development counters (null = off)
     int fixed;                // fixed_subsample: every query starts at word 0 of a freshly seeded generator
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// offsets: ONE workgroup walks the queries in order and determines only where each query's draws start.
+// offsets: where every query's draws start.
 //
-// A query consumes 2*nsel words for its first round plus 2 words per redraw.  The number of redraws of round 2 is the
-// number of first-round draws that hit an already taken bin (a bitmap of atomicOr's counts them); further rounds are
-// needed only if two round-2 draws fall into the same bin, which is impossible when they are pairwise farther apart
-// than the widest bin of the modified cdf -- checked on the x values alone.  Only if that test fails (~1 % of the
-// queries) the whole algorithm is run here (wc_full_query) to get the exact count.
-// The look-ups of query q+1's first round are software-pipelined: while query q is processed, the bins of a window
-// of nsel + RMAX consecutive doubles starting where query q+1 would start if query q needed no redraw are computed
-// (its true start is R_q doubles later; R_q <= RMAX, else the window is recomputed).  Random words are staged through
-// an LDS ring two queries ahead.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int WC_RMAX = 128;                         // redraws per query covered by the pipelined windows (x2: two queries ahead)
-constexpr int WC_SLOTS = 1280;                       // window slots: 5 per lane >= nsel + 2 * RMAX
-constexpr int WC_RING = 16384;                       // words
-constexpr int WC_CELLW = 2048;                       // words per cell bitmap (65536 cells)
-constexpr int WC_LIST = 256;                         // look-ups per window that need a second round (one per lane; more are resolved at once)
-
-// window of query t anchored at word `anchor`, synchronously: bins of the doubles anchor + 2e, e < win -> wbin_t[e]
-__device__ __forceinline__ void wc_window_sync(const WcArgs &a, int t, long long anchor, int win, int *wbin_t) {
-    const double *Sq = a.S + (size_t)t * a.n;
-    const WcRec *Rq = a.R + (size_t)t * a.K;
-    const double Stot = a.stot[t];
-    for (int e = threadIdx.x; e < win; e += (int)blockDim.x) {
-        const long long w = anchor + 2LL * e;
-        int bin = 0;
-        if (w + 1 < a.cap_words) {
-            const uint2 wp = *(const uint2 *)(a.words + w);
-            const double x = wc_double(wp.x, wp.y);
-            int bk = (int)(x * (double)a.K);
-            bk = bk > a.K - 1 ? a.K - 1 : bk;
-            const WcRec rec = Rq[bk];
-            bin = wc_quick_bin(rec.c0, rec.i, rec.more, x);
-            if (bin < 0) bin = wc_finish(Sq, a.n, rec.i + 1, 0, a.n, 0.0, Stot, x).bin;
-        }
-        wbin_t[e] = bin;
-    }
-}
-
-#ifndef P2S_WC_NT
-#define P2S_WC_NT 512
-#endif
-constexpr int WC_NT = P2S_WC_NT;                     // lanes of the serial kernel (256..768 measured: 512 is fastest, 7.9 us per query)
-constexpr int WC_SL = (WC_SLOTS + WC_NT - 1) / WC_NT;        // window slots per lane
-constexpr int WC_MD = (WC_MAX_SEL + WC_NT - 1) / WC_NT;      // first-round draws per lane
-static_assert(WC_NT % 64 == 0 && WC_NT >= 256 && WC_NT <= 768, "serial kernel: whole waves, one workgroup");
-struct WSet {                                        // guide records of one window
-    double xs[WC_SL], c0[WC_SL];
-    int ii[WC_SL], mm[WC_SL];
-};
-__device__ __forceinline__ void wc_lds_barrier() {
-    // LDS-only synchronisation: __syncthreads() would add s_waitcnt vmcnt(0) and drain the loads kept in flight
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-
-__host__ __device__ inline size_t wc_offsets_lds_bytes(int n) {
-    return wc_lds_bytes(n) + (size_t)WC_RING * 4 + 2 * WC_SLOTS * 4 + WC_LIST * 16;
-}
-
-__global__ __launch_bounds__(WC_NT) void wc_offsets_kernel(WcArgs a_in) {
-    WcArgs a = a_in;
-    long long ctl_base = -1;
-    if (a.ctl) {
-        // remainder after the speculative passes (normally nothing): continue at query ctl[0], word ctl[1]
-        const long long q0 = a.ctl[0];
-        if (q0 >= a.nq) return;
-        ctl_base = a.ctl[1];
-        a.S += (size_t)q0 * a.n;
-        a.R += (size_t)q0 * a.K;
-        a.stot += q0;
-        a.pmax += 2 * q0;
-        a.base += q0;
-        a.nq -= (int)q0;
-    }
-    extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
-    __shared__ int wsum[16];
-    __shared__ double wsumd[16];
-    __shared__ int s_cnt, s_unsafe, s_nlist;
-    __shared__ long long s_stats[16];
-    __shared__ double s_St[128];                     // per-query scalars, staged 64..128 queries ahead with VECTOR loads
-    __shared__ float2 s_pm[128];                     // (uniform-address loads would be scalar loads: their latency would
-                                                     //  land on the next LDS barrier's lgkmcnt(0))
-    __builtin_amdgcn_s_setprio(3);
-    const int tid = threadIdx.x;
-    const WcLds l = wc_carve(wc_lds, a.n);
-    uint32_t *ring = (uint32_t *)(wc_lds + wc_lds_bytes(a.n));
-    int *wbin = (int *)(ring + WC_RING);             // [2][SLOTS] bins of the windows of queries q, q+1
-    double *list_x = (double *)(wbin + 2 * WC_SLOTS);
-    int *list_e = (int *)(list_x + WC_LIST);
-    int *list_i = list_e + WC_LIST;
-    const int BW = (a.n + 31) >> 5;
-    const int win = a.nsel + 2 * WC_RMAX;            // window length in doubles
-    if (a.meta[1] != 0) return;                      // tables invalid (degenerate input) or an earlier failure
-    for (int i = tid; i < BW; i += WC_NT) l.bitmap[i] = 0;
-    for (int i = tid; i < 2 * WC_CELLW; i += WC_NT) ((uint32_t *)wc_lds)[i] = 0;
-    if (tid == 0) s_cnt = s_unsafe = s_nlist = 0;
-    if (tid < 16) s_stats[tid] = 0;
-    if (tid < 128) {
-        const int qq = tid < a.nq ? tid : a.nq - 1;
-        s_St[tid] = a.stot[qq];
-        s_pm[tid] = ((const float2 *)a.pmax)[qq];
-    }
-
-    // ring: words [.., r_hi) of the request are resident at ring[w & (RING-1)]
-    const long long base0 = ctl_base >= 0 ? ctl_base : a.meta[0];   // word cursor: where this call's first query starts
-    long long r_hi = base0 & ~3LL;
-    auto ring_fill = [&](long long upto) {           // synchronous (prologue / after falling behind)
-        upto = upto < a.cap_words ? upto : a.cap_words;
-        for (long long w = r_hi + 4 * tid; w < upto; w += 4 * WC_NT) {
-            const uint4 v = *(const uint4 *)(a.words + w);
-            *(uint4 *)(ring + (w & (WC_RING - 1))) = v;
-        }
-        if (upto > r_hi) r_hi = (upto + 3) & ~3LL;
-    };
-    // asynchronous part 1: x values from the ring, guide records requested (one 16-byte load per slot)
-    WSet RA, RB;                                     // ping-pong: no register copies of values still in flight
-#pragma unroll
-    for (int j = 0; j < WC_SL; ++j) {
-        RA.xs[j] = RA.c0[j] = RB.xs[j] = RB.c0[j] = 0.0;
-        RA.ii[j] = RA.mm[j] = RB.ii[j] = RB.mm[j] = 0;
-    }
-    // Two draws can only share a bin if their x values are closer than the widest bin of the cdf, pmax / S_N.  On a
-    // grid of G <= S_N / pmax cells such draws sit in the same or in adjacent cells, so a slot whose cell neighbourhood
-    // holds no other slot of the window cannot collide with anything: it needs no look-up at all (ii = -1).  About
-    // 20 % of the slots remain; only those fetch their guide record.
-    uint32_t *cellA = (uint32_t *)wc_lds;            // overlays the arrays of the fallback algorithm: zero on entry
-    uint32_t *cellB = cellA + WC_CELLW;
-    auto issue = [&](int t, long long anchor, float2 pmg, double (&xs)[WC_SL], double (&c0)[WC_SL], int (&ii)[WC_SL],
-                     int (&mm)[WC_SL]) {
-        const WcRec *Rn = a.R + (size_t)t * a.K;
-        const int G = __float_as_int(pmg.y);         // cells of the close-pair grid (tables kernel), <= 32 * WC_CELLW
-        int cell[WC_SL];
-        uint32_t bit[WC_SL];
-#pragma unroll
-        for (int j = 0; j < WC_SL; ++j) {                // straight-line: the LDS round trips of the 5 slots overlap
-            const int e = tid * WC_SL + j;
-            const long long w = anchor + 2LL * (e < win ? e : win - 1);
-            xs[j] = wc_double(ring[w & (WC_RING - 1)], ring[(w + 1) & (WC_RING - 1)]);
-            int c = (int)(xs[j] * (double)G);
-            c = c > G - 1 ? G - 1 : c;
-            cell[j] = c;
-            bit[j] = e < win ? 1u << (c & 31) : 0u;  // slots past the window: no-op atomics
-        }
-        uint32_t dup[WC_SL];
-#pragma unroll
-        for (int j = 0; j < WC_SL; ++j) dup[j] = atomicOr(&cellA[cell[j] >> 5], bit[j]) & bit[j];
-#pragma unroll
-        for (int j = 0; j < WC_SL; ++j) atomicOr(&cellB[cell[j] >> 5], dup[j]);
-        wc_lds_barrier();
-        uint32_t nb[WC_SL];
-#pragma unroll
-        for (int j = 0; j < WC_SL; ++j) {
-            const int c = cell[j];
-            const int cm = c > 0 ? c - 1 : c, cp = c + 1 < G ? c + 1 : c;
-            const uint32_t wB = cellB[c >> 5], wM = cellA[cm >> 5], wP = cellA[cp >> 5];
-            uint32_t near = (wB >> (c & 31)) & 1u;
-            near |= (c > 0) ? (wM >> (cm & 31)) & 1u : 0u;
-            near |= (c + 1 < G) ? (wP >> (cp & 31)) & 1u : 0u;
-            nb[j] = near & (bit[j] != 0u ? 1u : 0u);
-        }
-#pragma unroll
-        for (int j = 0; j < WC_SL; ++j) {
-            c0[j] = 0.0;
-            ii[j] = -1;
-            mm[j] = 0;
-            if (nb[j]) {
-                int bk = (int)(xs[j] * (double)a.K);
-                bk = bk > a.K - 1 ? a.K - 1 : bk;
-                const WcRec rec = Rn[bk];
-                c0[j] = rec.c0;
-                ii[j] = rec.i;
-                mm[j] = rec.more;
-            }
-        }
-        wc_lds_barrier();
-#pragma unroll
-        for (int j = 0; j < WC_SL; ++j) {                // (slots past the window alias the cell of the last slot)
-            cellA[cell[j] >> 5] = 0;
-            cellB[cell[j] >> 5] = 0;
-        }
-    };
-    auto covered = [&](long long anchor) {           // all words of a window staged and inside the request
-        return anchor + 2LL * win <= r_hi && anchor + 2LL * win <= a.cap_words;
-    };
-
-    long long base = base0;                          // word offset of the current query's first draw (uniform)
-    long long anc0 = base0, anc1 = base0 + 2LL * a.nsel;    // anchors of the windows of queries q and q+1
-    bool issued1 = false;
-    ring_fill(base0 + 8LL * a.nsel + 6 * WC_RMAX + 4096);
-    wc_lds_barrier();
-    wc_window_sync(a, 0, base0, win, wbin);
-    // per-query scalars, loaded three queries ahead of their first use
-    double St0 = s_St[0], St1 = s_St[1], St2 = s_St[2];
-    float2 pm0 = s_pm[0], pm1 = s_pm[1], pm2 = s_pm[2];
-    double stage_St = 0.0;                           // values on their way to s_St / s_pm (loaded a step ago)
-    float2 stage_pm = make_float2(0.0f, 0.0f);
-    int stage_q = -1;
-    if (a.nq > 1 && covered(anc1)) {
-        issue(1, anc1, pm1, RA.xs, RA.c0, RA.ii, RA.mm);
-        issued1 = true;
-    }
-    wc_lds_barrier();
-
-    long long t_last = a.stats ? wall_clock64() : 0;
-    const long long wall0 = t_last, clk0 = a.stats ? clock64() : 0;
-#define WC_T(k)                                                     \
-    do {                                                            \
-        if (a.stats && tid == 0) {                                  \
-            const long long t_ = wall_clock64();                    \
-            s_stats[k] += t_ - t_last;                              \
-            t_last = t_;                                            \
-        }                                                           \
-    } while (0)
-    // one query; P = records of the window of query q+1 (requested a step ago), C = set to fill for query q+2
-    auto step = [&](const int q, WSet &P, WSet &C) -> bool {
-        if (tid == 0) a.base[q] = base;
-        if (base + 2LL * a.nsel > a.cap_words) {     // uniform
-            if (tid == 0) {
-                a.meta[1] = 2;
-                a.meta[0] = base;
-            }
-            return false;
-        }
-        const double St3 = s_St[(q + 3) & 127];
-        const float2 pm3 = s_pm[(q + 3) & 127];
-        if (stage_q >= 0 && tid < 64) {              // scalars requested a step ago -> LDS (read >= 60 steps from now)
-            s_St[(stage_q + tid) & 127] = stage_St;
-            s_pm[(stage_q + tid) & 127] = stage_pm;
-        }
-        stage_q = -1;
-        if ((q & 63) == 0 && q + 128 - 64 < a.nq + 64) {
-            // entries [q+64, q+128) replace [q-64, q) of the 128-entry ring
-            stage_q = q + 64;
-            if (tid < 64) {
-                const int qq = q + 64 + tid < a.nq ? q + 64 + tid : a.nq - 1;
-                stage_St = a.stot[qq];
-                stage_pm = ((const float2 *)a.pmax)[qq];
-            }
-        }
-        // ---- stage more words: loads now, LDS stores at the end of the iteration
-        const long long fill_to = base + 8LL * a.nsel + 6 * WC_RMAX;
-        const bool do_fill = r_hi < fill_to && r_hi + 8 * WC_NT <= a.alloc_words;   // uniform: a whole chunk, 8 words per lane
-        const long long f0 = r_hi + 8 * tid;
-        uint4 fill[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) fill[k] = do_fill ? *(const uint4 *)(a.words + f0 + 4 * k) : make_uint4(0, 0, 0, 0);
-
-        // ---- A: window of query q+1 (records requested one iteration ago): most slots are decided by the record,
-        //         the rest goes to a list whose S values are requested now and looked at after the work on query q
-        const double *Sn = a.S + (size_t)(q + 1) * a.n;
-        int *wn = wbin + ((q + 1) & 1) * WC_SLOTS;
-        if (issued1) {
-#pragma unroll
-            for (int j = 0; j < WC_SL; ++j) {
-                const int e = tid * WC_SL + j;
-                if (e < win) {
-                    const int qb = P.ii[j] < 0 ? -2 : wc_quick_bin(P.c0[j], P.ii[j], P.mm[j], P.xs[j]);
-                    if (qb != -1) {
-                        wn[e] = qb;                  // bin, or -2: cannot collide with any other draw
-                    } else {
-                        const int k = atomicAdd(&s_nlist, 1);
-                        if (k < WC_LIST) {
-                            list_e[k] = e;
-                            list_i[k] = P.ii[j] + 1;
-                            list_x[k] = P.xs[j];
-                        } else {
-                            wn[e] = wc_finish_cold(Sn, a.n, P.ii[j] + 1, St1, P.xs[j]);
-                        }
-                    }
-                }
-            }
-        }
-        wc_lds_barrier();
-        const int nl = s_nlist < WC_LIST ? s_nlist : WC_LIST;
-        double sl[1][8];
-        int le[1], li[1];
-        double lx[1];
-#pragma unroll
-        for (int u = 0; u < 1; ++u) {
-            const int k = tid;                       // WC_LIST <= WC_NT: one entry per lane
-            le[u] = -1;
-            li[u] = 0;
-            lx[u] = 0.0;
-#pragma unroll
-            for (int v = 0; v < 8; ++v) sl[u][v] = 0.0;
-            if (k < nl) {
-                le[u] = list_e[k];
-                li[u] = list_i[k];
-                lx[u] = list_x[k];
-#pragma unroll
-                for (int v = 0; v < 8; ++v) sl[u][v] = Sn[li[u] + v < a.n ? li[u] + v : a.n - 1];
-            }
-        }
-        WC_T(2);
-        // ---- I: request the records of the window of query q+2 (anchor: no redraws in q and q+1)
-        const long long anc2 = base + 4LL * a.nsel;
-        const bool issued2 = (q + 2 < a.nq) && covered(anc2);
-        if (issued2) issue(q + 2, anc2, pm2, C.xs, C.c0, C.ii, C.mm);
-        WC_T(3);
-
-        // ---- Q: query q itself: number of distinct bins of its first round
-        const int rho = (int)((base - anc0) >> 1);                       // redraw doubles skipped in the window
-        const int *wb = wbin + (q & 1) * WC_SLOTS;
-        int events = 0;
-        int mbin[WC_MD];
-#pragma unroll
-        for (int k = 0; k < WC_MD; ++k) {            // nsel <= 1024 <= WC_MD * WC_NT, straight-line
-            const int d = tid + WC_NT * k;
-            const int bin = wb[rho + (d < a.nsel ? d : 0)];
-            mbin[k] = d < a.nsel ? bin : -1;
-        }
-#pragma unroll
-        for (int k = 0; k < WC_MD; ++k) {
-            const uint32_t bit = mbin[k] >= 0 ? 1u << (mbin[k] & 31) : 0u;
-            events += (atomicOr(&l.bitmap[mbin[k] >= 0 ? mbin[k] >> 5 : 0], bit) & bit) ? 1 : 0;
-        }
-        if (events) atomicAdd(&s_cnt, events);
-        wc_lds_barrier();
-        const int m2 = s_cnt;
-        WC_T(4);
-        long long used = 2LL * a.nsel + 2LL * m2;
-        bool fallback = false;
-        if (m2 > 0) {
-            // round 2 draws m2 doubles right behind the first round; they are distinct for sure if pairwise farther
-            // apart than the widest possible bin of the modified cdf
-            const double pm = (double)pm0.x;
-            const double denom = St0 - (double)a.nsel * pm;
-            if (m2 > 64 || !(denom > 0.25 * St0) || base + used > r_hi) {
-                fallback = true;
-            } else {
-                const double wmax = (pm / denom) * (1.0 + 1e-9);     // widest bin of the modified cdf (+ rounding slack)
-                if (tid < 64) {                      // wave 0: lane e holds draw e, compared against all through readlane
-                    const long long w = base + 2LL * a.nsel + 2LL * (tid < m2 ? tid : 0);
-                    const double x = wc_double(ring[w & (WC_RING - 1)], ring[(w + 1) & (WC_RING - 1)]);
-                    const int xl = __double2loint(x), xh = __double2hiint(x);
-                    bool bad = false;
-                    for (int e = 0; e < m2; ++e) {
-                        const double y = __hiloint2double(__builtin_amdgcn_readlane(xh, e), __builtin_amdgcn_readlane(xl, e));
-                        bad |= (e != tid) && (fabs(x - y) <= wmax);
-                    }
-                    if (bad && tid < m2) s_unsafe = 1;
-                }
-                wc_lds_barrier();
-                fallback = s_unsafe != 0;
-            }
-        }
-        WC_T(5);
-        // clear the bits of this query (every set bit belongs to one of its bins)
-#pragma unroll
-        for (int k = 0; k < WC_MD; ++k)
-            if (mbin[k] >= 0) l.bitmap[mbin[k] >> 5] = 0;
-        wc_lds_barrier();
-        if (tid == 0) s_cnt = s_unsafe = 0;
-        if (fallback) {
-            WcQuery qa;
-            qa.Sq = a.S + (size_t)q * a.n;
-            qa.Rq = a.R + (size_t)q * a.K;
-            qa.Stot = St0;
-            qa.words = a.words + base;
-            qa.words_left = a.cap_words - base;
-            qa.n = a.n;
-            qa.K = a.K;
-            qa.nsel = a.nsel;
-            qa.pre_bin = nullptr;
-            qa.pre_s = nullptr;
-            used = wc_full_query<false>(qa, l, wsum, wsumd, nullptr);
-            for (int i = tid; i < 2 * WC_CELLW; i += WC_NT) ((uint32_t *)wc_lds)[i] = 0;    // cell maps overlay its arrays
-            wc_lds_barrier();
-            if (tid == 0 && a.stats) s_stats[0] += 1;
-            if (used < 0) {
-                if (tid == 0) {
-                    a.meta[1] = 3;
-                    a.meta[0] = base;
-                }
-                return false;
-            }
-        }
-        WC_T(6);
-        // ---- B: second round of the window of query q+1
-#pragma unroll
-        for (int u = 0; u < 1; ++u) {
-            if (le[u] >= 0) {
-                int bin = -1;
-#pragma unroll
-                for (int v = 0; v < 8; ++v)
-                    if (bin < 0 && li[u] + v < a.n && wc_gt(sl[u][v], St1, lx[u])) bin = li[u] + v;
-                if (bin < 0) bin = wc_finish_cold(Sn, a.n, li[u] + 8, St1, lx[u]);
-                wn[le[u]] = bin;
-            }
-        }
-        const long long base_next = base + used;
-        if (q + 1 < a.nq) {
-            const long long rho1 = (base_next - anc1) >> 1;
-            if (!issued1 || rho1 > 2 * WC_RMAX) {
-                // window miss (more redraws than the window covers, or its words were not staged in time)
-                wc_lds_barrier();
-                wc_window_sync(a, q + 1, base_next, win, wbin + ((q + 1) & 1) * WC_SLOTS);
-                anc1 = base_next;
-                if (tid == 0 && a.stats) s_stats[1] += 1;
-            }
-        }
-        WC_T(7);
-        // ---- ring: store the words loaded at the top; refill synchronously if the pipeline fell behind
-        if (do_fill) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) *(uint4 *)(ring + ((f0 + 4 * k) & (WC_RING - 1))) = fill[k];
-            r_hi += 8 * WC_NT;
-        }
-        if (tid == 0) s_nlist = 0;
-        wc_lds_barrier();
-        if (r_hi < base_next + 6LL * a.nsel + 4 * WC_RMAX && r_hi < a.cap_words) {
-            ring_fill(base_next + 8LL * a.nsel + 6 * WC_RMAX);
-            wc_lds_barrier();
-        }
-        // rotate the pipeline
-        base = base_next;
-        anc0 = anc1;
-        anc1 = anc2;
-        issued1 = issued2;
-        St0 = St1;
-        St1 = St2;
-        St2 = St3;
-        pm0 = pm1;
-        pm1 = pm2;
-        pm2 = pm3;
-        WC_T(8);
-        return true;
-    };
-    for (int q = 0; q < a.nq; q += 2) {
-        if (!step(q, RA, RB)) return;
-        if (q + 1 < a.nq && !step(q + 1, RB, RA)) return;
-    }
-#undef WC_T
-    if (tid == 0) a.meta[0] = base;
-    if (a.stats && tid == 0) {
-        s_stats[9] = wall_clock64() - wall0;
-        s_stats[10] = clock64() - clk0;
-    }
-    wc_lds_barrier();
-    if (a.stats && tid < 16) a.stats[tid] = s_stats[tid];
-}
-
-// The same contract as wc_offsets_kernel for clouds whose found-bitmap does not fit next to that kernel's ring and
-// windows (more than 185,664 points): the complete algorithm query by query, in order, with the LDS layout of the ids
-// kernel (bitmaps of up to ~570k points).  80 us per query instead of 8 -- but it only sees what the speculative chain
-// left over (normally nothing), or everything when that chain is switched off.
-__global__ __launch_bounds__(256) void wc_offsets_plain_kernel(WcArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
-    __shared__ int wsum[16];
-    __shared__ double wsumd[16];
-    if (a.meta[1] != 0) return;
-    const int tid = threadIdx.x;
-    long long q0 = 0, s = a.meta[0];
-    if (a.ctl) {
-        q0 = a.ctl[0];
-        if (q0 >= a.nq) return;
-        s = a.ctl[1];
-    }
-    const WcLds l = wc_carve(wc_lds, a.n);
-    const int BW = (a.n + 31) >> 5;
-    for (int i = tid; i < BW; i += 256) l.bitmap[i] = 0;
-    __syncthreads();
-    for (long long q = q0; q < a.nq; ++q) {
-        if (s + 2LL * a.nsel > a.cap_words) {
-            if (tid == 0) {
-                a.meta[1] = 2;
-                a.meta[0] = s;
-            }
-            return;
-        }
-        WcQuery qa;
-        qa.Sq = a.S + (size_t)q * a.n;
-        qa.Rq = a.R + (size_t)q * a.K;
-        qa.Stot = a.stot[q];
-        qa.words = a.words + s;
-        qa.words_left = a.cap_words - s;
-        qa.n = a.n;
-        qa.K = a.K;
-        qa.nsel = a.nsel;
-        qa.pre_bin = nullptr;
-        qa.pre_s = nullptr;
-        const long long used = wc_full_query<false>(qa, l, wsum, wsumd, nullptr);
-        if (used < 0) {
-            if (tid == 0) {
-                a.meta[1] = 3;
-                a.meta[0] = s;
-            }
-            return;
-        }
-        if (tid == 0) a.base[q] = s;
-        s += used;
-        __syncthreads();
-    }
-    if (tid == 0) a.meta[0] = s;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// offsets, parallel: speculation tables + a light chain (default; the serial kernel above remains as the fallback).
-//
-// The only serial dependence is the word offset: query q starts at s_q = s_{q-1} + 2 (nsel + R_{q-1}), R = redraws.
-// R_q is a function of the start alone: with X_k the k-th double of the stream and bin_q() the query's cdf look-up,
+// A query consumes 2*nsel words for its first round plus 2 words per redraw, so the only serial dependence is the word
+// offset: query q starts at s_q = s_{q-1} + 2 (nsel + R_{q-1}), R = redraws.  R_q is a function of the start alone.  With
+// X_k the k-th double of the stream and bin_q() the query's cdf look-up,
 //     m2(s) = nsel - #distinct{ bin_q(X_k) : s <= k < s + nsel }          (first-round draws hitting a taken bin)
-// and round 3 is impossible when the m2 redraws X_{s+nsel} .. X_{s+nsel+m2-1} are pairwise farther apart than the
-// widest bin of the modified cdf (same tests as the serial kernel), so R(s) = m2(s) for such s.
+// is what round 2 draws.  Round 2 draws from the MODIFIED cdf (found ids carry no mass), so its draws can only collide
+// with each other, and only if two of them are closer than the widest bin of any modified cdf, wmax.  r05: such close
+// pairs are no longer left to the complete algorithm -- the spec kernel looks their bins up EXACTLY in the cdf modified
+// by the candidate's own found set (wc_wave_bin), which decides every candidate but the very few whose THIRD round has
+// two draws within wmax of each other:
+//     m3 = round-2 draws that hit a bin another round-2 draw took first;  R = m2 + m3 when m3 <= 1 or the m3 draws of
+//     round 3 are pairwise farther apart than wmax.
 //   wc_spec_kernel   one workgroup per query of a block of SP_B queries, all CUs: R_q(s) for the SP_W candidate
 //                    starts around the predicted one (block start, exact, + sum of the expected collision counts mu
 //                    of the queries before it, from the tables kernel).  m2 over a sliding window: every draw e with
 //                    an earlier draw prev(e) in the same bin adds 1 to the starts in (e - nsel, prev(e)] -- a difference
-//                    array + scan; draws sharing a bin are found through an LDS hash.  255 = undecided here.
-//   wc_chain_kernel  one workgroup: s -> s + 2 (nsel + R_q(s)) is a table look-up per query; undecided candidates
-//                    (~1-5 % of the queries) run the complete algorithm in place (wc_full_query); a start outside the
-//                    window ends the block early, the next (spec, chain) pair resumes there.
+//                    array + scan; draws sharing a bin are found through an LDS hash.  255 = undecided.  It also writes
+//                    level 0 of the jump tables.
+//   wc_jumpk_kernel  levels 1.. of the jump tables (below)
+//   wc_chain_kernel  one workgroup: the walk s -> s + 2 (nsel + R_q(s)) through the tables; the (now very rare) undecided
+//                    candidate runs the complete algorithm in place (wc_full_query); a start outside the window ends the
+//                    block early, the next (spec, chain) pair resumes there; the LAST launch of a request takes whatever
+//                    is still unresolved through the complete algorithm, query by query (normally nothing).
 // The ids kernel re-derives every query's consumption and flags any disagreement (meta[1] = 4).
 // ---------------------------------------------------------------------------------------------------------------
-#ifndef P2S_SP_B
-#define P2S_SP_B 2048
-#endif
-constexpr int SP_B = P2S_SP_B;                       // queries per speculation block
+constexpr int SP_B = 2048;                           // queries per speculation block
 constexpr int SP_W = 1024;                           // candidate starts per query
-constexpr int SP_LOOK = 64;                          // round-2 draws decided by the distance test
+constexpr int SP_LOOK = 64;                          // round-2 draws per candidate the spec kernel handles
 constexpr int SP_NB = SP_W + WC_MAX_SEL;             // draws whose bin is needed
 constexpr int SP_NX = SP_NB + 2 * SP_LOOK;           // doubles held
 constexpr int SP_HASH = 4096;
-constexpr int SP_DMAX = 1024;                        // draws that share their bin with another draw of the window
+constexpr int SP_DMAX = 1024;                        // draws that share their bin with another draw of the window (more: undecided)
+constexpr int SP_XL = 384;                           // candidates per query whose close pairs are looked up exactly (more stay undecided)
+constexpr int SP_PAIRS = 256;                        // close pairs among the round-2 positions of a window (more: those candidates stay undecided)
+constexpr int SP_TASKS = 768;                        // exact look-ups per query (pairs of neighbouring close round-2 draws of those candidates)
+
+// ---- the walk s -> s + 2 (nsel + R_q(s)) without walking --------------------------------------------------------------
+// In window coordinates (d = (s - klo[q]) / 2, candidate d of query q) one step is
+//     next(q, d) = d + R_q(d) + nsel + (klo[q] - klo[q + 1]) / 2        if R_q(d) is decided and the result is a candidate of q + 1
+// -- a table look-up.  2^k steps at once are the look-up J_k[q][d] with J_k[q] = J_{k-1}[q + 2^(k-1)] o J_{k-1}[q].  r05: level
+// k is only kept for the queries q = 0 mod 2^k (a "ruler": 2 SP_B rows in all instead of SP_LEV x SP_B) -- the walk takes the
+// largest aligned jump that is valid, i.e. ~2 log2(SP_B) look-ups per SEGMENT between two queries it has to resolve
+// itself, and the word offsets of the queries inside a segment are filled in by all lanes afterwards (binary lifting
+// from the segment start, whose alignment covers every level the fill needs).
+constexpr int SP_LEV = 11;
+static_assert((1 << SP_LEV) >= SP_B, "jump levels cover a block");
+constexpr unsigned short SP_INV = 0xffffu;
+__host__ __device__ inline size_t sp_lev_row(int k, int i) {         // row of level k, query i (i = 0 mod 2^k)
+    return (size_t)(2 * SP_B - ((2 * SP_B) >> k)) + (size_t)(i >> k);
+}
+constexpr size_t SP_JUMP_ROWS = 2 * SP_B;
+
 struct WcSpec {
     unsigned char *rtab;      // [SP_B][SP_W] redraws for candidate start klo + 2 d; 255 = undecided
     long long *klo;           // [SP_B] word offset of candidate 0
     long long *ctl;           // [0] first unresolved query, [1] its word offset
     const float *mu;          // [nq] expected first-round collisions
-    int *win_bin;             // [SP_B][SP_NB] first-round bin of every draw of the window (-1: past the request)
-    double2 *win_s;           // [SP_B][SP_NB] (S_bin, S_{bin-1}) of it: what the complete algorithm needs of round 1
-    unsigned short *jump;     // [SP_LEV][SP_B][SP_W] jump tables (below); nullptr = walk query by query
+    unsigned short *jump;     // [SP_JUMP_ROWS][SP_W] ruler of jump tables
 };
 
-// ---- the walk s -> s + 2 (nsel + R_q(s)) without walking --------------------------------------------------------------
-// In window coordinates (d = (s - klo[q]) / 2, candidate d of query q) one step is
-//     next(q, d) = d + R_q(d) + nsel + (klo[q] - klo[q + 1]) / 2        if R_q(d) is decided and the result is a candidate of q + 1
-// -- a table look-up.  2^k steps at once are the look-up J_k[q][d] with J_k = J_{k-1} o J_{k-1} (all CUs, 2 M entries
-// per level, 11 levels for a block of 2048 queries), so the one workgroup that owns the serial dependence no longer pays
-// one dependent L2 round trip per QUERY (1.4 us each, 2.9 ms per block) but ~11 per SEGMENT between two queries it has
-// to resolve itself (undecided candidates: ~5 % of the queries), and the word offsets of the queries inside a segment
-// are filled in by all its lanes afterwards (binary lifting from the segment start).
-constexpr int SP_LEV = 11;
-static_assert((1 << SP_LEV) >= SP_B, "jump levels cover a block");
-constexpr unsigned short SP_INV = 0xffffu;
-
-__global__ __launch_bounds__(256) void wc_jump0_kernel(WcArgs a, WcSpec sp) {
-    if (a.meta[1] != 0) return;
-    const long long qb = sp.ctl[0];
-    if (qb >= a.nq) return;
-    const int lim = (int)(a.nq - qb < SP_B ? a.nq - qb : SP_B);
-    const int i = blockIdx.x;
-    unsigned short *J0 = sp.jump + (size_t)i * SP_W;
-    if (i >= lim) return;
-    const bool last = i + 1 >= lim;                      // the step of the block's last query leaves the block: not a jump
-    const int delta = last ? 0 : a.nsel + (int)((sp.klo[i] - sp.klo[i + 1]) >> 1);
-    for (int d = threadIdx.x; d < SP_W; d += 256) {
-        const unsigned r = sp.rtab[(size_t)i * SP_W + d];
-        const int nd = d + (int)r + delta;
-        J0[d] = (last || r == 255u || nd < 0 || nd >= SP_W) ? SP_INV : (unsigned short)nd;
-    }
-}
-
-// level k from level k - 1: 2^k steps = 2^(k-1) steps twice
+// level k from level k - 1, rows i = 0 mod 2^k
 __global__ __launch_bounds__(256) void wc_jumpk_kernel(WcArgs a, WcSpec sp, int k) {
     if (a.meta[1] != 0) return;
     const long long qb = sp.ctl[0];
     if (qb >= a.nq) return;
     const int lim = (int)(a.nq - qb < SP_B ? a.nq - qb : SP_B);
-    const int i = blockIdx.x, half = 1 << (k - 1);
+    const int i = (int)blockIdx.x << k, half = 1 << (k - 1);
     if (i >= lim) return;
-    const unsigned short *Jp = sp.jump + (size_t)(k - 1) * SP_B * SP_W;
-    unsigned short *Jk = sp.jump + (size_t)k * SP_B * SP_W + (size_t)i * SP_W;
+    const unsigned short *Ja = sp.jump + sp_lev_row(k - 1, i) * SP_W;
+    const unsigned short *Jb = sp.jump + sp_lev_row(k - 1, i + half) * SP_W;
+    unsigned short *Jk = sp.jump + sp_lev_row(k, i) * SP_W;
     const bool reach = i + 2 * half <= lim - 1;          // lands on a query of the block
     for (int d = threadIdx.x; d < SP_W; d += 256) {
         unsigned short v = SP_INV;
         if (reach) {
-            const unsigned short m = Jp[(size_t)i * SP_W + d];
-            if (m != SP_INV) v = Jp[(size_t)(i + half) * SP_W + m];
+            const unsigned short m = Ja[d];
+            if (m != SP_INV) v = Jb[m];
         }
         Jk[d] = v;
     }
@@ -1294,37 +774,224 @@ __global__ void wc_ctl_init_kernel(long long *ctl, const long long *meta) {
     ctl[1] = meta[0];
 }
 
+// ---- exact look-up in a candidate's own modified cdf, by a group of 8 lanes ------------------------------------------
+// All look-ups of a query run side by side (64 groups per workgroup): the kernel is bound by the latency of its random
+// table reads (~10 us each under load), so what counts is how many of them are in flight, not the instructions per look-up.
+constexpr int WC_G = 4;                               // lanes per group
+constexpr int WC_GS = 8;                              // S values per lane and round trip: WC_G * WC_GS = 32 ids
+__device__ __forceinline__ double wc_grp_sum(double v) {
+#pragma unroll
+    for (int off = WC_G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ int wc_grp_max(int v) {
+#pragma unroll
+    for (int off = WC_G / 2; off >= 1; off >>= 1) {
+        const int u = __shfl_xor(v, off);
+        v = u > v ? u : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wc_grp_min(int v) {
+#pragma unroll
+    for (int off = WC_G / 2; off >= 1; off >>= 1) {
+        const int u = __shfl_xor(v, off);
+        v = u < v ? u : v;
+    }
+    return v;
+}
+
+// The found set F of candidate start d = distinct first-round bins of the draws [d, d + nsel).
+struct WcCand {
+    const int *bins;          // LDS [SP_NB] first-round bin of every draw of the window
+    const float *pw;          // LDS [SP_NB] its probability (float32 value, exact)
+    const int *dl;            // LDS [ndup] draw | (previous draw of the same bin + 1) << 11
+    int ndup, d, nsel;
+};
+// found mass at or below id i (Cle) and in all (Ctot), largest found id <= i (-1: none), smallest found id > i (n: none);
+// every lane of the group gets the result.  Exact in any order: every partial sum is a multiple of the probabilities'
+// last place below 2 (see the file header).
+__device__ __forceinline__ void wc_grp_pass(const WcCand &c, int n, int i, int gl, double &Cle, double &Ctot, int &lo, int &hi) {
+    double s = 0.0, st = 0.0;
+    int l = -1, h = n;
+    // (8 draws per lane in flight: one at a time the loop runs at the latency of its two LDS reads, 23 us per pass)
+    for (int e0 = c.d + gl; e0 < c.d + c.nsel; e0 += 8 * WC_G) {
+        int b[8];
+        float pf[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + WC_G * u;
+            const bool in = e < c.d + c.nsel;
+            b[u] = in ? c.bins[e] : n;                   // past the window: above every id, no mass
+            pf[u] = in ? c.pw[e] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double p = (double)pf[u];
+            st += p;
+            if (b[u] <= i) {
+                s += p;
+                l = b[u] > l ? b[u] : l;
+            } else {
+                h = b[u] < h ? b[u] : h;
+            }
+        }
+    }
+    for (int t = gl; t < c.ndup; t += WC_G) {            // a bin drawn more than once inside the window counts once
+        const int e = c.dl[t] & 2047, pv = (c.dl[t] >> 11) - 1;
+        if (e >= c.d && e < c.d + c.nsel && pv >= c.d) {
+            const double p = (double)c.pw[e];
+            st -= p;
+            if (c.bins[e] <= i) s -= p;
+        }
+    }
+    Cle = wc_grp_sum(s);
+    Ctot = wc_grp_sum(st);
+    lo = wc_grp_max(l);
+    hi = wc_grp_min(h);
+}
+// searchsorted(cdf', x, 'right') for the cdf modified by the found set of a candidate: smallest i with
+// fl((S_i - C(i)) / St_cur) > x, C(i) = found mass at or below i.  The predicate is monotone in i and every decision below
+// is taken with the exact predicate (wc_gt on exact S, C values); approximations only choose where to look.  One group of
+// WC_G lanes (gl = lane in the group, gsh = bit position of the group's lane 0 in the wave); i0 = first guess (the bin of x
+// in the unmodified cdf); -1 = gave up (the caller leaves the candidate undecided).
+// x2 >= x (a close round-2 draw): *same = it falls into the same bin, i.e. fl(V_bin / St_cur) > x2 as well.
+__device__ __forceinline__ int wc_grp_bin(const WcCand &c, const double *__restrict__ Sq, int n, double Stot, double x, double x2,
+                                          int i0, int gl, int gsh, int *same, long long *dbg = nullptr) {
+    constexpr unsigned GM = (1u << WC_G) - 1u;
+    int i = i0 > n - 1 ? n - 1 : (i0 < 0 ? 0 : i0);
+    for (int it = 0; it < 12; ++it) {
+        double Cle, Ctot;
+        int lo, hi;
+        const long long tp0 = dbg ? wall_clock64() : 0;
+        wc_grp_pass(c, n, i, gl, Cle, Ctot, lo, hi);
+        if (dbg) {
+            atomicAdd((unsigned long long *)&dbg[16], 1ull);
+            atomicAdd((unsigned long long *)&dbg[18], (unsigned long long)(wall_clock64() - tp0));
+        }
+        const double St_cur = Stot - Ctot;
+        // the found-free gap (lo, hi) around i: pred(lo) must be false and pred(hi - 1) true for the answer to lie in it;
+        // 32 ids of it in the same round trip (id k0 + WC_G j + gl in slot j), centred where the found mass below i says
+        // the answer is: the first guess assumed the proportional share x Ctot
+        const double s_lo = Sq[lo > 0 ? lo : 0], s_hm = Sq[hi - 1 > 0 ? hi - 1 : 0];
+        int k0;
+        {
+            double sh = (Cle - x * Ctot) * (double)n / Stot;              // mass -> ids at the mean bin width
+            sh = sh > 64.0 ? 64.0 : (sh < -64.0 ? -64.0 : sh);
+            k0 = i + (it == 0 ? (int)sh : 0) - WC_G * WC_GS / 2 + 4;
+        }
+        k0 = k0 > hi - WC_G * WC_GS ? hi - WC_G * WC_GS : k0;
+        k0 = k0 < lo + 1 ? lo + 1 : k0;
+        double sk[WC_GS];
+#pragma unroll
+        for (int j = 0; j < WC_GS; ++j) sk[j] = (k0 + WC_G * j + gl < hi) ? Sq[k0 + WC_G * j + gl] : 0.0;
+        if (dbg) {
+            const long long tl0 = wall_clock64();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            atomicAdd((unsigned long long *)&dbg[19], (unsigned long long)(wall_clock64() - tl0));
+        }
+        if (lo >= 0 && wc_gt(s_lo - Cle, St_cur, x)) {          // V_lo = S_lo - C(lo), C(lo) = Cle: the answer is below lo
+            i = lo - 1;
+            if (i < 0) return -1;
+            continue;
+        }
+        if (hi < n && !wc_gt(s_hm - Cle, St_cur, x)) {          // V_(hi-1) still <= target (and V_hi = V_(hi-1)): above hi
+            i = hi + 1;
+            if (i >= n) return -1;
+            continue;
+        }
+        if (hi - lo < 2) return -1;                              // (cannot happen: the predicate changes inside the gap)
+        // inside the gap C is constant
+        for (int w = 0; w < 96; ++w) {
+            if (dbg) atomicAdd((unsigned long long *)&dbg[17], 1ull);
+            int first = -1;
+            double sv = 0.0;
+#pragma unroll
+            for (int j = WC_GS - 1; j >= 0; --j) {
+                const bool pr = (k0 + WC_G * j + gl >= hi) || wc_gt(sk[j] - Cle, St_cur, x);
+                const unsigned m = (unsigned)(__ballot(pr) >> gsh) & GM;
+                if (m) {
+                    first = WC_G * j + __builtin_ctz(m);
+                    sv = sk[j];
+                }
+            }
+            if (first < 0) {
+                k0 += WC_G * WC_GS;                               // all <= target: further right (k0 < hi: pred(hi-1) holds)
+            } else if (first == 0 && k0 > lo + 1) {
+                k0 = k0 - (WC_G * WC_GS - 1) < lo + 1 ? lo + 1 : k0 - (WC_G * WC_GS - 1);     // the first id already beyond: further left
+            } else {
+                // the lane that holds the answer's S value also answers for x2
+                const bool mine = (first & (WC_G - 1)) == gl;
+                *same = ((unsigned)(__ballot(mine && wc_gt(sv - Cle, St_cur, x2)) >> gsh) & GM) ? 1 : 0;
+                return k0 + first;
+            }
+#pragma unroll
+            for (int j = 0; j < WC_GS; ++j) sk[j] = (k0 + WC_G * j + gl < hi) ? Sq[k0 + WC_G * j + gl] : 0.0;
+        }
+        return -1;
+    }
+    return -1;
+}
+
 __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
     __shared__ double xs[SP_NX];
     __shared__ int bins[SP_NB];
-    __shared__ __attribute__((aligned(16))) uint32_t hkey[SP_HASH];      // later: diff[SP_W + 1] and nd[SP_W + SP_LOOK]
-    __shared__ int2 dl[SP_DMAX];
-    __shared__ int s_ndup, wsum[4];
-    __shared__ float redf[4];
+    __shared__ __attribute__((aligned(16))) uint32_t hkey[SP_HASH];      // later: diff, nd, pw, rt, xl (offsets below)
+    __shared__ int dl[SP_DMAX];                      // draw | bin << 11, later draw | (previous draw of the same bin + 1) << 11
+    __shared__ int task[SP_TASKS];                   // listed candidate t | round-2 draw j << 10 | its neighbour j2 << 16
+    static_assert(SP_XL <= 1024 && SP_LOOK <= 64, "task encoding");
+    __shared__ int cres[SP_XL];                      // listed candidate t: neighbours in the same bin (m3) | gave up << 16
+    __shared__ int xl[SP_XL];                        // listed candidate d | m2 << 16
+    __shared__ int s_ndup, s_nxl, s_ntask, s_npair, wsum[4];
+    __shared__ float redf[2][4];
     if (a.meta[1] != 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long qb = sp.ctl[0], sb = sp.ctl[1];
     const int i = blockIdx.x;
     const long long q = qb + i;
     if (q >= a.nq) return;
-    // predicted start: the block start (exact) + the expected redraws of the queries before this one
-    float part = 0.0f;
-    for (int j = tid; j < i; j += 256) part += sp.mu[qb + j];
+    const int lim = (int)(a.nq - qb < SP_B ? a.nq - qb : SP_B);
+    long long t_ph = a.stats ? wall_clock64() : 0;
+#define SP_T(k)                                                                                   \
+    do {                                                                                          \
+        if (a.stats && tid == 0) {                                                                \
+            const long long t_ = wall_clock64();                                                  \
+            atomicAdd((unsigned long long *)&a.stats[k], (unsigned long long)(t_ - t_ph));        \
+            t_ph = t_;                                                                            \
+        }                                                                                         \
+    } while (0)
+    // predicted start: the block start (exact) + the expected redraws of the queries before this one; the same for the
+    // next query (its workgroup sums in exactly this order), whose window origin level 0 of the jump tables refers to
+    float part = 0.0f, part1 = 0.0f;
+    for (int j = tid; j <= i; j += 256) {
+        const float m = sp.mu[qb + j];
+        if (j < i) part += m;
+        part1 += m;
+    }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
-    if (lane == 0) redf[wave] = part;
-    if (tid == 0) s_ndup = 0;
+    for (int off = 32; off >= 1; off >>= 1) {
+        part += __shfl_xor(part, off);
+        part1 += __shfl_xor(part1, off);
+    }
+    if (lane == 0) {
+        redf[0][wave] = part;
+        redf[1][wave] = part1;
+    }
+    if (tid == 0) s_ndup = s_nxl = s_ntask = s_npair = 0;
     for (int h = tid; h < SP_HASH; h += 256) hkey[h] = 0xffffffffu;
     __syncthreads();
-    long long dpre = (long long)((redf[0] + redf[1]) + (redf[2] + redf[3]) + 0.5f) - SP_W / 2;
+    long long dpre = (long long)((redf[0][0] + redf[0][1]) + (redf[0][2] + redf[0][3]) + 0.5f) - SP_W / 2;
     dpre = dpre < 0 ? 0 : dpre;
+    long long dpre1 = (long long)((redf[1][0] + redf[1][1]) + (redf[1][2] + redf[1][3]) + 0.5f) - SP_W / 2;
+    dpre1 = dpre1 < 0 ? 0 : dpre1;
     const long long klo = sb + 2 * ((long long)i * a.nsel + dpre);
+    const long long klo1 = sb + 2 * ((long long)(i + 1) * a.nsel + dpre1);
     if (tid == 0) sp.klo[i] = klo;
     const int nsel = a.nsel, nb = SP_W + nsel, nx = nb + 2 * SP_LOOK;
     const double *Sq = a.S + (size_t)q * a.n;
     const WcRec *Rq = a.R + (size_t)q * a.K;
     const double Stot = a.stot[q];
-    // ---- doubles of the window and their bins (first-round look-up, as wc_window_sync)
+    // ---- doubles of the window and their bins (first-round look-up)
     for (int e = tid; e < nx; e += 256) {
         const long long w = klo + 2LL * e;
         double x = 2.0;                               // past the request: never "far" from anything -> undecided
@@ -1337,24 +1004,14 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
                 bk = bk > a.K - 1 ? a.K - 1 : bk;
                 const WcRec rec = Rq[bk];
                 bin = wc_quick_bin(rec.c0, rec.i, rec.more, x);
-                double2 ss;
-                if (bin < 0) {
-                    const WcLoc L = wc_finish(Sq, a.n, rec.i + 1, 0, a.n, 0.0, Stot, x);
-                    bin = L.bin;
-                    ss = make_double2(L.s, L.sprev);
-                } else {
-                    ss = make_double2(Sq[bin], bin > 0 ? Sq[bin - 1] : 0.0);
-                }
-                sp.win_s[(size_t)i * SP_NB + e] = ss;
+                if (bin < 0) bin = wc_finish(Sq, a.n, rec.i + 1, 0, a.n, 0.0, Stot, x).bin;
             }
         }
         xs[e] = x;
-        if (e < nb) {
-            bins[e] = bin;
-            sp.win_bin[(size_t)i * SP_NB + e] = bin;
-        }
+        if (e < nb) bins[e] = bin;
     }
     __syncthreads();
+    SP_T(0);
     // ---- draws that share their bin with another draw of the window: hash bin -> count
     constexpr int PER = (SP_NB + 255) / 256;
     int slot[PER];
@@ -1387,34 +1044,55 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
     for (int j = 0; j < PER; ++j) {
         if (slot[j] >= 0 && (hkey[slot[j]] & 1023u) >= 2u) {
             const int k = atomicAdd(&s_ndup, 1);
-            if (k < SP_DMAX) dl[k] = make_int2(tid + 256 * j, bins[tid + 256 * j]);
+            if (k < SP_DMAX) dl[k] = (tid + 256 * j) | (bins[tid + 256 * j] << 11);
         }
     }
     const bool any_over = __syncthreads_or(overflow ? 1 : 0) != 0;
     const bool undecidable = any_over || s_ndup > SP_DMAX;
     const int ndup = s_ndup < SP_DMAX ? s_ndup : SP_DMAX;
-    int *diff = (int *)hkey;                                       // [SP_W + 1]
-    unsigned char *nd = (unsigned char *)(diff + SP_W + 4);        // [SP_W + SP_LOOK]
+    // the hash is dead: its 16 KB now hold
+    int *diff = (int *)hkey;                                              // [SP_W + 1]              0 .. 4100
+    unsigned char *nd = (unsigned char *)hkey + 4112;                     // [SP_W + SP_LOOK]     4112 .. 5200
+    int *pl = (int *)((unsigned char *)hkey + 5200);                      // [SP_PAIRS]           5200 .. 6224
+    float *pw = (float *)((unsigned char *)hkey + 6336);                  // [SP_NB]              6336 .. 14528
+    unsigned char *rt = (unsigned char *)hkey + 14528;                    // [SP_W]              14528 .. 15552
+    static_assert(14528 + SP_W <= SP_HASH * 4 && 6336 + SP_NB * 4 <= 14528 && 5200 + SP_PAIRS * 4 <= 6336, "overlay");
     for (int d = tid; d <= SP_W; d += 256) diff[d] = 0;
-    __syncthreads();
-    // ---- m2(d): draw e with an earlier same-bin draw prev counts for the starts d in (e - nsel, prev]
-    for (int t = tid; t < ndup; t += 256) {
-        const int e = dl[t].x, b = dl[t].y;
-        int prev = -1;
-        for (int u = 0; u < ndup; ++u) {
-            const int2 o = dl[u];
-            if (o.y == b && o.x < e && o.x > prev) prev = o.x;
+    // ---- previous draw of the same bin for every listed draw (registers; written back behind the barrier)
+    int pv[SP_DMAX / 256];
+#pragma unroll
+    for (int j = 0; j < SP_DMAX / 256; ++j) {
+        const int t = tid + 256 * j;
+        pv[j] = -1;
+        if (t < ndup) {
+            const int e = dl[t] & 2047, b = dl[t] >> 11;
+            int prev = -1;
+            for (int u = 0; u < ndup; ++u) {
+                const int oe = dl[u] & 2047, ob = dl[u] >> 11;
+                if (ob == b && oe < e && oe > prev) prev = oe;
+            }
+            pv[j] = prev;
         }
-        if (prev >= 0) {
-            const int lo = e - nsel + 1 > 0 ? e - nsel + 1 : 0;
-            const int hi = prev < SP_W - 1 ? prev : SP_W - 1;
-            if (lo <= hi) {
-                atomicAdd(&diff[lo], 1);
-                atomicAdd(&diff[hi + 1], -1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SP_DMAX / 256; ++j) {
+        const int t = tid + 256 * j;
+        if (t < ndup) {
+            const int e = dl[t] & 2047, prev = pv[j];
+            dl[t] = e | ((prev + 1) << 11);
+            // ---- m2(d): draw e with an earlier same-bin draw prev counts for the starts d in (e - nsel, prev]
+            if (prev >= 0) {
+                const int lo = e - nsel + 1 > 0 ? e - nsel + 1 : 0;
+                const int hi = prev < SP_W - 1 ? prev : SP_W - 1;
+                if (lo <= hi) {
+                    atomicAdd(&diff[lo], 1);
+                    atomicAdd(&diff[hi + 1], -1);
+                }
             }
         }
     }
-    // ---- nd[e - nsel]: distance to the first later draw within reach of the widest bin of the modified cdf
+    // ---- nd[e - nsel]: distance to the first later draw within reach of the widest bin of any modified cdf
     const double pm = (double)a.pmax[2 * q];
     const double denom = Stot - (double)nsel * pm;
     const bool dist_ok = denom > 0.25 * Stot;
@@ -1422,16 +1100,26 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
     for (int r = tid; r < SP_W + SP_LOOK; r += 256) {
         const int e = nsel + r;
         const double x = xs[e];
-        int best = 255;
-        for (int j = 1; j < SP_LOOK; ++j) {
-            if (fabs(x - xs[e + j]) <= wmax) {
-                best = j;
-                break;
-            }
+        unsigned long long cm = 0ull;                    // bit j: draw e + j lies within wmax (all 63 reads in flight: no early exit)
+#pragma unroll 9
+        for (int j = 1; j < SP_LOOK; ++j) cm |= (unsigned long long)(fabs(x - xs[e + j]) <= wmax) << j;
+        nd[r] = (unsigned char)(cm ? __builtin_ctzll(cm) : 255);
+        for (; cm; cm &= cm - 1) {                       // the close pairs themselves (rare): what the exact pass works on
+            const int k = atomicAdd(&s_npair, 1);
+            if (k < SP_PAIRS) pl[k] = r | ((r + __builtin_ctzll(cm)) << 16);
         }
-        nd[r] = (unsigned char)best;
+    }
+    // ---- probability of every draw's bin, re-derived from the L2-resident cloud exactly as the tables kernel did
+    {
+        const float qx = a.q[3 * q], qy = a.q[3 * q + 1], qz = a.q[3 * q + 2];
+        const float dmax = a.dsum[2 * q], sum = a.dsum[2 * q + 1];
+        for (int e = tid; e < nb; e += 256) {
+            const int b = bins[e];
+            pw[e] = b >= 0 ? wc_clip_prob(wc_dist1(a.pts, b, qx, qy, qz), dmax) / sum : 0.0f;
+        }
     }
     __syncthreads();
+    SP_T(1);
     // ---- scan of the difference array (4 candidates per lane) and the verdict per candidate
     const int d0 = 4 * tid;
     int c[4];
@@ -1451,14 +1139,14 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
 #pragma unroll
     for (int w = 0; w < 4; ++w)
         if (w < wave) run += wsum[w];
-    uint32_t packed = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int d = d0 + j;
         const int m2 = run + c[j];
         unsigned r = 255u;
         const long long s = klo + 2LL * d;
-        if (!undecidable && s + 2LL * (nsel + m2) <= a.cap_words) {
+        // (room for the third round of an exactly resolved candidate: m3 <= m2)
+        if (!undecidable && s + 2LL * (nsel + 2 * m2) <= a.cap_words) {
             if (m2 == 0) {
                 r = 0u;
             } else if (m2 <= SP_LOOK && dist_ok) {
@@ -1467,20 +1155,150 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
                     const int reach = nd[d + e];
                     bad |= (reach != 255) && (e + reach < m2);
                 }
-                if (!bad) r = (unsigned)m2;
+                if (!bad) {
+                    r = (unsigned)m2;
+                } else {
+                    const int k = atomicAdd(&s_nxl, 1);
+                    if (k < SP_XL) xl[k] = d | (m2 << 16);
+                }
             }
         }
-        packed |= r << (8 * j);
+        rt[d] = (unsigned char)r;
     }
-    ((uint32_t *)(sp.rtab + (size_t)i * SP_W))[tid] = packed;
+    __syncthreads();
+    // ---- close pairs among the round-2 draws of a candidate, decided exactly in the candidate's own modified cdf.
+    // Bins are monotone in x: with the close draws of a candidate sorted by value, m3 = the neighbours (next larger close
+    // draw within wmax) that fall into the same bin as their predecessor -- ONE look-up per such pair.
+    // (1) one thread per listed candidate: its pairs -> look-up tasks
+    SP_T(2);
+    const int nxl = s_nxl < SP_XL ? s_nxl : SP_XL;
+    if (a.stats && tid == 0) {
+        atomicAdd((unsigned long long *)&a.stats[6], (unsigned long long)s_nxl);
+        atomicAdd((unsigned long long *)&a.stats[8], 1ull);
+        atomicAdd((unsigned long long *)&a.stats[9], (unsigned long long)ndup);
+    }
+    const int npair = s_npair < SP_PAIRS ? s_npair : SP_PAIRS;
+    for (int t = tid; t < nxl; t += 256) cres[t] = s_npair > SP_PAIRS ? 0x10000 : 0;       // pair list overflow: undecided
+    __syncthreads();
+    // 8 lanes per listed candidate over the window's close pairs: a pair inside the candidate's round-2 range [d, d + m2) is a
+    // task if its upper draw u2 (larger x; ties: the later draw) is the NEIGHBOUR of the lower one u1 -- no third draw of the
+    // range lies between them (it would be within wmax of both, i.e. be listed with u1)
+    for (int t = tid >> 3; t < nxl; t += 32) {
+        const int d = xl[t] & 0xffff, m2 = xl[t] >> 16;
+        for (int k = tid & 7; k < npair; k += 8) {
+            const int r1 = pl[k] & 0xffff, r2 = pl[k] >> 16;
+            if (r1 < d || r2 >= d + m2) continue;
+            const double xa = xs[nsel + r1], xb = xs[nsel + r2];
+            const bool up = xb > xa || (xb == xa);                   // r2 > r1: a tie counts the later draw as the larger
+            const int u1 = up ? r1 : r2, u2 = up ? r2 : r1;
+            const double x1 = up ? xa : xb, x2 = up ? xb : xa;
+            bool between = false;
+            for (int k2 = 0; k2 < npair; ++k2) {
+                const int q1 = pl[k2] & 0xffff, q2 = pl[k2] >> 16;
+                if (q1 != u1 && q2 != u1) continue;
+                const int z = q1 == u1 ? q2 : q1;
+                if (z == u2 || z < d || z >= d + m2) continue;
+                const double xz = xs[nsel + z];
+                const bool above = xz > x1 || (xz == x1 && z > u1);
+                const bool below = xz < x2 || (xz == x2 && z < u2);
+                between |= above && below;
+            }
+            if (!between) {
+                const int kk = atomicAdd(&s_ntask, 1);
+                if (kk < SP_TASKS) task[kk] = t | ((u1 - d) << 10) | ((u2 - d) << 16);
+                else atomicOr(&cres[t], 0x10000);               // no room: stays undecided
+            }
+        }
+    }
+    __syncthreads();
+    SP_T(3);
+    if (a.stats && tid == 0) atomicAdd((unsigned long long *)&a.stats[7], (unsigned long long)s_ntask);
+    // (2) the look-ups, 64 at a time
+    {
+        const int ntask = s_ntask < SP_TASKS ? s_ntask : SP_TASKS;
+        const int grp = tid / WC_G, gl = tid & (WC_G - 1), gsh = lane & ~(WC_G - 1);
+        WcCand cd;
+        cd.bins = bins;
+        cd.pw = pw;
+        cd.dl = dl;
+        cd.ndup = ndup;
+        cd.nsel = nsel;
+        for (int k = grp; k < ntask; k += 256 / WC_G) {
+            const int t = task[k] & 1023, j = (task[k] >> 10) & 63, j2 = task[k] >> 16;
+            const int d = xl[t] & 0xffff;
+            cd.d = d;
+            const int e = d + nsel + j;
+            // first guess: the bin of x in the unmodified cdf -- known for the draws that are first-round draws of later
+            // candidates (all but the last few of the window), else one guide look-up
+            int i0;
+            if (e < nb) {
+                i0 = bins[e];
+            } else {
+                int bk = (int)(xs[e] * (double)a.K);
+                bk = bk > a.K - 1 ? a.K - 1 : bk;
+                i0 = Rq[bk].i;
+            }
+            int same = 0;
+            if (a.stats && tid == 0) atomicAdd((unsigned long long *)&a.stats[20], 1ull);
+            const int b = wc_grp_bin(cd, Sq, a.n, Stot, xs[e], xs[d + nsel + j2], i0, gl, gsh, &same, (a.stats && tid == 0) ? a.stats : nullptr);
+            if (gl == 0) {
+                if (b < 0) atomicOr(&cres[t], 0x10000);
+                else if (same) atomicAdd(&cres[t], 1);
+            }
+        }
+    }
+    __syncthreads();
+    SP_T(4);
+    // (3) one thread per listed candidate: R = m2 + m3 if m3 <= 1 or the m3 draws of round 3, right behind round 2, are
+    // pairwise farther apart than wmax
+    for (int t = tid; t < nxl; t += 256) {
+        const int d = xl[t] & 0xffff, m2 = xl[t] >> 16;
+        const int m3 = cres[t] & 0xffff;
+        unsigned r = 255u;
+        if (!(cres[t] >> 16)) {
+            if (m3 <= 1) {
+                r = (unsigned)(m2 + m3);
+            } else {
+                bool close = false;
+                for (int u = 0; u < m3; ++u)
+                    for (int v2 = 0; v2 < u; ++v2) close |= fabs(xs[d + nsel + m2 + u] - xs[d + nsel + m2 + v2]) <= wmax;
+                if (!close) r = (unsigned)(m2 + m3);
+            }
+        }
+        rt[d] = (unsigned char)(r > 254u ? 255u : r);
+    }
+    __syncthreads();
+    // ---- out: the verdicts and level 0 of the jump tables (step of candidate d into the window of the next query)
+    ((uint32_t *)(sp.rtab + (size_t)i * SP_W))[tid] = ((const uint32_t *)rt)[tid];
+    {
+        const bool lastq = i + 1 >= lim;                     // the step of the block's last query leaves the block: not a jump
+        const int delta = nsel + (int)((klo - klo1) >> 1);
+        unsigned short *J0 = sp.jump + sp_lev_row(0, i) * SP_W;
+        ushort4 o;
+        unsigned short *ov = (unsigned short *)&o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned r = rt[d0 + j];
+            const int ndq = d0 + j + (int)r + delta;
+            ov[j] = (lastq || r == 255u || ndq < 0 || ndq >= SP_W) ? SP_INV : (unsigned short)ndq;
+        }
+        *(ushort4 *)(J0 + d0) = o;
+    }
+    SP_T(5);
+#undef SP_T
 }
 
-__global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp) {
+// last != 0: the final launch of a request -- whatever is unresolved behind its block goes through the complete algorithm,
+// query by query.  serial != 0 (development / tests: P2S_WC_SERIAL): no speculation at all, every query that way.
+__global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp, int last, int serial) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
     __shared__ int wsum[16];
     __shared__ double wsumd[16];
     __shared__ long long s_klo[SP_B];
     __shared__ long long s_ev[3];
+    __shared__ unsigned short s_mark[SP_B];          // window coordinate of query j where the walk KNEW it; SP_INV = jumped over
+    __shared__ short s_from[SP_B];
+    __shared__ short s_lane[256];
     if (a.meta[1] != 0) return;
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
@@ -1489,73 +1307,121 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp) {
     const WcLds l = wc_carve(wc_lds, a.n);
     const int BW = (a.n + 31) >> 5;
     for (int i = tid; i < BW; i += 256) l.bitmap[i] = 0;
-    const int lim = (int)(a.nq - qb < SP_B ? a.nq - qb : SP_B);
+    const int lim = serial ? 0 : (int)(a.nq - qb < SP_B ? a.nq - qb : SP_B);
     for (int i = tid; i < lim; i += 256) s_klo[i] = sp.klo[i];
+    for (int j = tid; j < SP_B; j += 256) s_mark[j] = SP_INV;
     long long s = sp.ctl[1];
     int i = 0;
     long long t_fb = 0, n_fb = 0;
     const long long t_start = a.stats ? wall_clock64() : 0;
-    // jump mode: s_mark[j] = window coordinate of query j where the walk KNEW it (block start, after a query it resolved
-    // itself); the queries in between are filled in at the end
-    __shared__ unsigned short s_mark[SP_B];
-    const bool jumping = sp.jump != nullptr;
-    if (jumping)
-        for (int j = tid; j < SP_B; j += 256) s_mark[j] = SP_INV;
     __syncthreads();
+    bool in_block = lim > 0;
     for (;;) {
-        if (tid == 0) {
-            int ev = 2;                               // 1 undecided candidate, 2 end of block / outside the window, 3 words exhausted
-            while (i < lim) {
-                if (s + 2LL * a.nsel > a.cap_words) {
-                    ev = 3;
-                    break;
-                }
-                long long d = (s - s_klo[i]) >> 1;
-                if (d < 0 || d >= SP_W) break;
-                if (jumping) {
-                    // as far as whole jumps go (validity of a jump = validity of every step in it, so the greedy
-                    // descent through the levels ends on the last query before an undecided / outside step)
-                    s_mark[i] = (unsigned short)d;
-                    for (int k = SP_LEV - 1; k >= 0; --k) {
-                        if (i + (1 << k) > lim - 1) continue;
-                        const unsigned short v = sp.jump[((size_t)k * SP_B + i) * SP_W + d];
-                        if (v != SP_INV) {
-                            i += 1 << k;
-                            d = v;
+        int ev = 2;                                   // 1 undecided candidate, 2 end of block / outside the window, 3 words exhausted
+        if (in_block) {
+            if (tid == 0) {
+                while (i < lim) {
+                    if (s + 2LL * a.nsel > a.cap_words) {
+                        ev = 3;
+                        break;
+                    }
+                    long long d = (s - s_klo[i]) >> 1;
+                    if (d < 0 || d >= SP_W) break;
+                    // as far as aligned jumps go: the largest level whose jump from here is valid (validity of a jump =
+                    // validity of every step in it), again from where it lands, until not even one step is
+                    for (;;) {
+                        s_mark[i] = (unsigned short)d;
+                        int k = i ? __builtin_ctz(i) : SP_LEV - 1;
+                        k = k > SP_LEV - 1 ? SP_LEV - 1 : k;
+                        bool moved = false;
+                        for (; k >= 0; --k) {
+                            if (i + (1 << k) > lim - 1) continue;
+                            const unsigned short v = sp.jump[sp_lev_row(k, i) * SP_W + d];
+                            if (v != SP_INV) {
+                                i += 1 << k;
+                                d = v;
+                                moved = true;
+                                break;
+                            }
                         }
+                        if (!moved) break;
                     }
                     s = s_klo[i] + 2 * d;
                     if (s + 2LL * a.nsel > a.cap_words) {
                         ev = 3;
                         break;
                     }
+                    const unsigned r = sp.rtab[(size_t)i * SP_W + d];
+                    if (r == 255u) {
+                        ev = 1;
+                        break;
+                    }
+                    a.base[qb + i] = s;
+                    s += 2LL * (a.nsel + (int)r);
+                    ++i;
                 }
-                const unsigned r = sp.rtab[(size_t)i * SP_W + d];
-                if (r == 255u) {
-                    ev = 1;
-                    break;
-                }
-                a.base[qb + i] = s;
-                s += 2LL * (a.nsel + (int)r);
-                ++i;
+                s_ev[0] = ev;
+                s_ev[1] = i;
+                s_ev[2] = s;
             }
-            s_ev[0] = ev;
-            s_ev[1] = i;
-            s_ev[2] = s;
+            __syncthreads();
+            ev = (int)s_ev[0];
+            i = (int)s_ev[1];
+            s = s_ev[2];
+            __syncthreads();
         }
-        __syncthreads();
-        const int ev = (int)s_ev[0];
-        i = (int)s_ev[1];
-        s = s_ev[2];
-        __syncthreads();
-        if (ev == 3) {
+        if (ev == 2 && in_block) {
+            in_block = false;
+            // word offsets of the queries the walk jumped over: nearest known start at or below j (prefix maximum over the
+            // marks), then j - start steps by binary lifting (the start's alignment covers every level needed: the jump
+            // that passed over j left from it).  Queries >= i were not reached.
+            for (int j0 = tid * (SP_B / 256); j0 < (tid + 1) * (SP_B / 256); ++j0) s_from[j0] = s_mark[j0] != SP_INV ? (short)j0 : (short)-1;
+            __syncthreads();
+            {   // prefix maximum: 8 consecutive entries per lane, then across lanes
+                const int b0 = tid * (SP_B / 256);
+                short run = -1;
+                for (int j0 = b0; j0 < b0 + SP_B / 256; ++j0) {
+                    run = s_from[j0] > run ? s_from[j0] : run;
+                    s_from[j0] = run;
+                }
+                s_lane[tid] = run;
+                __syncthreads();
+                short before = -1;
+                for (int t = 0; t < tid; ++t) before = s_lane[t] > before ? s_lane[t] : before;
+                for (int j0 = b0; j0 < b0 + SP_B / 256; ++j0)
+                    if (s_from[j0] < before) s_from[j0] = before;
+                __syncthreads();
+            }
+            for (int j = tid; j < i; j += 256) {
+                int ii = s_from[j];
+                if (ii < 0) continue;                         // (cannot happen: query 0 of the block is always a start)
+                int dd = s_mark[ii];
+                int m = j - ii;
+                for (int k = SP_LEV - 1; k >= 0 && m > 0 && dd != SP_INV; --k) {
+                    if (m >= (1 << k)) {
+                        dd = (ii & ((1 << k) - 1)) ? SP_INV : sp.jump[sp_lev_row(k, ii) * SP_W + dd];
+                        ii += 1 << k;
+                        m -= 1 << k;
+                    }
+                }
+                // (a start itself: m = 0 from the beginning.  The ids kernel re-derives every query's consumption and
+                //  flags any disagreement, so a wrong offset cannot pass silently.)
+                if (m == 0 && dd != SP_INV) a.base[qb + j] = s_klo[j] + 2LL * dd;
+                else a.meta[1] = 4;
+            }
+        }
+        // words exhausted: in the block (the walk found out) or for the next query of the remainder
+        if (ev == 3 || (ev == 2 && (last || serial) && qb + i < a.nq && s + 2LL * a.nsel > a.cap_words)) {
             if (tid == 0) {
                 a.meta[1] = 2;
                 a.meta[0] = s;
             }
             return;
         }
-        if (ev != 1) break;
+        // remainder (last launch of a request, or P2S_WC_SERIAL): in order, the whole algorithm per query (80 us each) --
+        // after the spare (spec, chain) pairs normally nothing
+        if (ev == 2 && !((last || serial) && qb + i < a.nq)) break;
+        // the complete algorithm for query qb + i at word s: an undecided candidate of the block, or the remainder
         const long long t0 = a.stats ? wall_clock64() : 0;
         WcQuery qa;
         qa.Sq = a.S + (size_t)(qb + i) * a.n;
@@ -1566,11 +1432,6 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp) {
         qa.n = a.n;
         qa.K = a.K;
         qa.nsel = a.nsel;
-        {
-            const long long d = (s - s_klo[i]) >> 1;          // inside the window (checked by the walk above)
-            qa.pre_bin = sp.win_bin + ((size_t)i * SP_NB + d);
-            qa.pre_s = sp.win_s + ((size_t)i * SP_NB + d);
-        }
         const long long used = wc_full_query<false>(qa, l, wsum, wsumd, nullptr);
         if (used < 0) {
             if (tid == 0) {
@@ -1588,59 +1449,17 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp) {
         }
         __syncthreads();
     }
-    if (jumping) {
-        // word offsets of the queries the walk jumped over: nearest known start at or below j (prefix maximum over the
-        // marks), then j - start steps by binary lifting.  Queries >= i were not reached.
-        __shared__ short s_from[SP_B];
-        __syncthreads();
-        for (int j0 = tid * (SP_B / 256); j0 < (tid + 1) * (SP_B / 256); ++j0) s_from[j0] = s_mark[j0] != SP_INV ? (short)j0 : (short)-1;
-        __syncthreads();
-        {   // prefix maximum: 8 consecutive entries per lane, then across lanes
-            __shared__ short s_lane[256];
-            const int b0 = tid * (SP_B / 256);
-            short run = -1;
-            for (int j0 = b0; j0 < b0 + SP_B / 256; ++j0) {
-                run = s_from[j0] > run ? s_from[j0] : run;
-                s_from[j0] = run;
-            }
-            s_lane[tid] = run;
-            __syncthreads();
-            short before = -1;
-            for (int t = 0; t < tid; ++t) before = s_lane[t] > before ? s_lane[t] : before;
-            for (int j0 = b0; j0 < b0 + SP_B / 256; ++j0)
-                if (s_from[j0] < before) s_from[j0] = before;
-            __syncthreads();
-        }
-        for (int j = tid; j < i; j += 256) {
-            int ii = s_from[j];
-            if (ii < 0) continue;                         // (cannot happen: query 0 of the block is always a start)
-            int dd = s_mark[ii];
-            int m = j - ii;
-            for (int k = SP_LEV - 1; k >= 0 && m > 0 && dd != SP_INV; --k) {
-                if (m >= (1 << k)) {
-                    dd = sp.jump[((size_t)k * SP_B + ii) * SP_W + dd];
-                    ii += 1 << k;
-                    m -= 1 << k;
-                }
-            }
-            // (a start itself: m = 0 from the beginning.  The ids kernel re-derives every query's consumption and flags
-            //  any disagreement, so a wrong offset cannot pass silently.)
-            if (m == 0 && dd != SP_INV) a.base[qb + j] = s_klo[j] + 2LL * dd;
-            else if (j < i) a.meta[1] = 4;
-        }
-    }
+    const long long qn = qb + i;
     if (tid == 0) {
         if (a.stats) {
             atomicAdd((unsigned long long *)&a.stats[12], (unsigned long long)n_fb);
             atomicAdd((unsigned long long *)&a.stats[13], (unsigned long long)t_fb);
             atomicAdd((unsigned long long *)&a.stats[14], (unsigned long long)(wall_clock64() - t_start));
+            atomicAdd((unsigned long long *)&a.stats[11], 1ull);            // chain launches that did work
         }
-        sp.ctl[0] = qb + i;
+        sp.ctl[0] = qn;
         sp.ctl[1] = s;
-        if (qb + i >= a.nq) a.meta[0] = s;
-        if (a.stats) {
-            atomicAdd((unsigned long long *)&a.stats[11], 1ull);            // (spec, chain) pairs that did work
-        }
+        if (qn >= a.nq) a.meta[0] = s;
     }
 }
 
@@ -1666,8 +1485,6 @@ __global__ __launch_bounds__(256) void wc_ids_kernel(WcArgs a) {
     qa.n = a.n;
     qa.K = a.K;
     qa.nsel = a.nsel;
-    qa.pre_bin = nullptr;
-    qa.pre_s = nullptr;
     const long long used = wc_full_query<true>(qa, l, wsum, wsumd, a.ids_out + (size_t)q * a.nsel);
     if (a.fixed) {
         // rng.seed(42) before every query: the generator ends where the LAST query of the call left it
@@ -1773,36 +1590,83 @@ int wc_build_plan(p2s_cloud_s *c) {
     return P2S_OK;
 }
 
-int wc_reserve(p2s_rng_s *r, size_t nq, size_t n, size_t K) {
-    if (nq <= r->wc_cap_q && n <= r->wc_cap_n && K <= r->wc_cap_k) return P2S_OK;
-    if (r->wc_S) (void)hipFree(r->wc_S);
-    if (r->wc_T) (void)hipFree(r->wc_T);
-    if (r->wc_stot) (void)hipFree(r->wc_stot);
+// per-query tables of one batch: S, guide records, scalars [stot f64][base i64][pmax f32 x 2][dsum f32 x 2][mu f32 + pad]
+struct WcBatchMem {
+    double *S;
+    WcRec *R;
+    double *stot;
+    long long *base;
+    float *pmax, *dsum, *mu;
+};
+WcBatchMem wc_batch_mem(p2s_rng_s *r, int b) {
+    WcBatchMem m;
+    m.S = r->wc_S[b];
+    m.R = (WcRec *)r->wc_T[b];
+    m.stot = r->wc_sc[b];
+    m.base = (long long *)(m.stot + r->wc_cap_q);
+    m.pmax = (float *)(m.base + r->wc_cap_q);
+    m.dsum = m.pmax + 2 * r->wc_cap_q;
+    m.mu = m.dsum + 2 * r->wc_cap_q;
+    return m;
+}
+
+void wc_free(p2s_rng_s *r) {
+    for (int b = 0; b < 2; ++b) {
+        if (r->wc_S[b]) (void)hipFree(r->wc_S[b]);
+        if (r->wc_T[b]) (void)hipFree(r->wc_T[b]);
+        if (r->wc_sc[b]) (void)hipFree(r->wc_sc[b]);
+        r->wc_S[b] = nullptr;
+        r->wc_T[b] = nullptr;
+        r->wc_sc[b] = nullptr;
+    }
+    if (r->wc_spec) (void)hipFree(r->wc_spec);
     if (r->wc_J) (void)hipFree(r->wc_J);
-    r->wc_S = nullptr; r->wc_T = nullptr; r->wc_stot = nullptr; r->wc_J = nullptr;
+    r->wc_spec = nullptr;
+    r->wc_J = nullptr;
     r->wc_cap_q = r->wc_cap_n = r->wc_cap_k = 0;
+    r->wc_bufs = 0;
+}
+
+// bufs = 2: a second set of tables, so that the tables of batch b + 1 are built (second stream) while the offsets pass of
+// batch b runs -- used when a call holds more than one batch and wants no ids (stream skipping: the chip is idle otherwise)
+int wc_reserve(p2s_rng_s *r, size_t nq, size_t n, size_t K, int bufs) {
+    if (nq <= r->wc_cap_q && n <= r->wc_cap_n && K <= r->wc_cap_k && bufs <= r->wc_bufs) return P2S_OK;
     nq = std::max(nq, r->wc_cap_q);
-    if (hipMalloc(&r->wc_S, nq * n * 8) != hipSuccess ||
-        hipMalloc(&r->wc_T, nq * K * sizeof(WcRec)) != hipSuccess ||
-        hipMalloc(&r->wc_J, (size_t)SP_LEV * SP_B * SP_W * 2) != hipSuccess ||
-        hipMalloc(&r->wc_stot, nq * 32 + (size_t)SP_B * SP_W + (size_t)SP_B * 8 + 64 + (size_t)SP_B * SP_NB * 20 + 64) != hipSuccess) {
+    n = std::max(n, r->wc_cap_n);
+    K = std::max(K, r->wc_cap_k);
+    bufs = std::max(bufs, r->wc_bufs);
+    wc_free(r);
+    bool ok = hipMalloc(&r->wc_J, SP_JUMP_ROWS * SP_W * 2) == hipSuccess &&
+              hipMalloc(&r->wc_spec, 64 + (size_t)SP_B * 8 + (size_t)SP_B * SP_W) == hipSuccess;
+    for (int b = 0; b < bufs && ok; ++b)
+        ok = hipMalloc(&r->wc_S[b], nq * n * 8) == hipSuccess && hipMalloc(&r->wc_T[b], nq * K * sizeof(WcRec)) == hipSuccess &&
+             hipMalloc(&r->wc_sc[b], nq * 40) == hipSuccess;
+    if (!ok) {
         (void)hipGetLastError();
-        p2s_set_error("weighted sub-sample: hipMalloc of the per-query tables failed (%zu queries x %zu points)", nq, n);
+        wc_free(r);
+        p2s_set_error("weighted sub-sample: hipMalloc of the per-query tables failed (%zu queries x %zu points x %d)", nq, n, bufs);
         return P2S_ENOMEM;
     }
     r->wc_cap_q = nq;
     r->wc_cap_n = n;
     r->wc_cap_k = K;
+    r->wc_bufs = bufs;
     return P2S_OK;
 }
 
 }  // namespace
 
 void p2s_wc_free_rng(p2s_rng_s *r) {
-    if (r->wc_S) (void)hipFree(r->wc_S);
-    if (r->wc_T) (void)hipFree(r->wc_T);
-    if (r->wc_stot) (void)hipFree(r->wc_stot);
-    if (r->wc_J) (void)hipFree(r->wc_J);
+    wc_free(r);
+    for (int b = 0; b < 2; ++b) {
+        if (r->wc_ev_tab[b]) (void)hipEventDestroy(r->wc_ev_tab[b]);
+        if (r->wc_ev_use[b]) (void)hipEventDestroy(r->wc_ev_use[b]);
+        r->wc_ev_tab[b] = r->wc_ev_use[b] = nullptr;
+    }
+    if (r->wc_ev_in) (void)hipEventDestroy(r->wc_ev_in);
+    if (r->wc_stream2) (void)hipStreamDestroy(r->wc_stream2);
+    r->wc_ev_in = nullptr;
+    r->wc_stream2 = nullptr;
 }
 
 static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_t nq, int n_sel, int32_t *ids_out_dev,
@@ -1852,15 +1716,32 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     if (req_env > 0) per_req = std::min<long long>(req_env, 16384);
     per_req = std::min<long long>(per_req, nq);
     const long long cap = p2s_rng_session_words(r);
-    // numpy draws 2 words per double, n_sel doubles + a few % redraws per query; the serial kernel stages words
-    // a few queries ahead of the one it works on
+    // numpy draws 2 words per double, n_sel doubles + a few % redraws per query
     const long long margin = 8LL * n_sel + 6 * 128 + 8192;
     if ((long long)(2.0 * n_sel * 1.15) + margin > cap) {
         p2s_set_error("p2s_subsample_weighted: jump tables too small for one query");
         return P2S_EINVAL;
     }
-    rc = wc_reserve(r, (size_t)per_req, (size_t)n, (size_t)K);
+    const size_t lds_ids = wc_lds_bytes(n);
+    const size_t lds_chain_max = 160 * 1024 - 4096 - SP_B * 8 - SP_B * 4 - 1024;      // the chain kernel's static arrays
+    if (lds_ids > lds_chain_max) {
+        p2s_set_error("p2s_subsample_weighted: cloud of %d points does not fit the LDS bitmap (limit: %d points)", n,
+                      (int)((lds_chain_max - wc_lds_bytes(0) - 16) / 6 * 32));
+        return P2S_ECAPACITY;
+    }
+    // stream skipping (no ids wanted) over several batches: the tables of batch b + 1 on a second stream while the offsets
+    // pass of batch b runs (the chip is idle otherwise: 9.1 -> ms per 4096 queries)
+    const bool overlap = !ids_out_dev && !fixed && nq > per_req && !getenv("P2S_WC_NO_OVERLAP");
+    rc = wc_reserve(r, (size_t)per_req, (size_t)n, (size_t)K, overlap ? 2 : 1);
     if (rc) return rc;
+    if (overlap && !r->wc_stream2) {
+        P2S_HIP_CHECK(hipStreamCreateWithFlags(&r->wc_stream2, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            P2S_HIP_CHECK(hipEventCreateWithFlags(&r->wc_ev_tab[b], hipEventDisableTiming));
+            P2S_HIP_CHECK(hipEventCreateWithFlags(&r->wc_ev_use[b], hipEventDisableTiming));
+        }
+        P2S_HIP_CHECK(hipEventCreateWithFlags(&r->wc_ev_in, hipEventDisableTiming));
+    }
     WcPlanDev plan;
     plan.leaf = c->wc_plan;
     plan.ops = c->wc_plan + c->wc_ops_at;
@@ -1869,54 +1750,40 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     plan.n_levels = c->wc_levels;
     plan.root = c->wc_root;
     plan.n_nodes = c->wc_nodes;
-    // per-query scalars share one allocation: [stot f64][base i64][pmax f32, cells i32][mu f32, pad], followed by the
-    // speculation block: [ctl i64 x 8][klo i64 x SP_B][rtab u8 x SP_B x SP_W]
-    double *stot = r->wc_stot;
-    long long *base = (long long *)(stot + r->wc_cap_q);
-    float *pmax = (float *)(base + r->wc_cap_q);
-    float *mu = pmax + 2 * r->wc_cap_q;
     WcSpec sp;
-    sp.ctl = (long long *)(mu + 2 * r->wc_cap_q);
+    sp.ctl = (long long *)r->wc_spec;
     sp.klo = sp.ctl + 8;
     sp.rtab = (unsigned char *)(sp.klo + SP_B);
-    sp.mu = mu;
-    sp.win_s = (double2 *)(((uintptr_t)(sp.rtab + (size_t)SP_B * SP_W) + 15) & ~(uintptr_t)15);
-    sp.win_bin = (int *)(sp.win_s + (size_t)SP_B * SP_NB);
-    sp.jump = getenv("P2S_WC_NO_JUMP") ? nullptr : r->wc_J;                 // development / A-B: walk query by query
-    const bool serial_only = getenv("P2S_WC_SERIAL") != nullptr;            // development / A-B: the serial kernel alone
-    const size_t lds_ids = wc_lds_bytes(n);
-    size_t lds_off = wc_offsets_lds_bytes(n);
-    // the offsets kernel is one latency-bound workgroup running next to the MFMA-saturated encoders: give it a CU of
-    // its own by claiming most of that CU's LDS (same placement trick as the serial generator)
-    const size_t hog = getenv("P2S_RNG_LDS_HOG") ? (size_t)atoi(getenv("P2S_RNG_LDS_HOG")) : 120 * 1024;
-    // clouds beyond 185,664 points: the serial kernel's ring + windows leave no room for the found-bitmap; the plain
-    // kernel (bitmap + the arrays of one query, like the ids kernel) takes its place
-    const bool big = lds_off > 160 * 1024 - 4096;
-    const size_t lds_chain_max = 160 * 1024 - 4096 - SP_B * 8 - SP_B * 4 - 1024;      // the chain kernel's static arrays
-    if (lds_ids > lds_chain_max) {
-        p2s_set_error("p2s_subsample_weighted: cloud of %d points does not fit the LDS bitmap (limit: %d points)", n,
-                      (int)((lds_chain_max - wc_lds_bytes(0) - 16) / 6 * 32));
-        return P2S_ECAPACITY;
-    }
-    if (nq >= 64 && !big) lds_off = std::max(lds_off, hog);
-    // the chain workgroup of a full block claims a CU of its own (LDS no encoder workgroup fits next to): sharing a
-    // CU with the encoders' MFMA-saturated waves it gets an instruction issued every ~200 cycles (measured: 1.4 us
-    // per query of the walk whether the table sits in global memory, LDS or registers; 80 us per fallback instead of
-    // 14.5) -- with blocks of 2048 queries the wait for a drained CU is paid twice per chunk
-    const size_t lds_chain = nq >= 64 ? std::max(lds_ids, getenv("P2S_WC_CHAIN_LDS") ? (size_t)atoi(getenv("P2S_WC_CHAIN_LDS")) : (size_t)100000) : lds_ids;
+    sp.jump = r->wc_J;
+    const bool serial_only = getenv("P2S_WC_SERIAL") != nullptr;   // development / tests: every query through the in-order remainder path
+    // the chain workgroup of a full block claims a CU of its own (LDS no encoder workgroup fits next to): sharing a CU
+    // with the encoders' MFMA-saturated waves it gets an instruction issued every ~200 cycles
+    const size_t lds_chain = nq >= 64 ? std::max(lds_ids, (size_t)100000) : lds_ids;
     {   // per device (a process may drive several); the call is cheap
-        (void)hipFuncSetAttribute((const void *)wc_offsets_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         (void)hipFuncSetAttribute((const void *)wc_ids_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)wc_offsets_plain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute((const void *)wc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain_max);
         (void)hipFuncSetAttribute((const void *)wc_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NP_BUFSIZE + WC_MAX_NODES) * 4);
     }
     long long *meta = p2s_rng_raw_meta(r);
     static long long *stats_dev = nullptr;
     const bool want_stats = getenv("P2S_WC_STATS") != nullptr;
-    if (want_stats && !stats_dev) (void)hipMalloc(&stats_dev, 16 * 8);
-    for (int64_t done = 0; done < nq;) {
+    if (want_stats && !stats_dev) (void)hipMalloc(&stats_dev, 32 * 8);
+    auto launch_tables = [&](int64_t done, int cur, int b, hipStream_t st) {
+        const WcBatchMem m = wc_batch_mem(r, b);
+        hipLaunchKernelGGL(wc_tables_kernel, dim3(cur), dim3(256), (size_t)(NP_BUFSIZE + ((plan.n_nodes + 3) & ~3)) * 4, st, c->d.pts, n,
+                           q_dev + (size_t)done * 3, plan, K, m.S, m.R, m.stot, m.pmax, m.mu, m.dsum, n_sel, meta);
+    };
+    if (overlap) {
+        // the second stream starts behind everything the caller queued (the queries, the cloud)
+        P2S_HIP_CHECK(hipEventRecord(r->wc_ev_in, s));
+        P2S_HIP_CHECK(hipStreamWaitEvent(r->wc_stream2, r->wc_ev_in, 0));
+        launch_tables(0, (int)std::min<int64_t>(per_req, nq), 0, r->wc_stream2);
+        P2S_HIP_CHECK(hipEventRecord(r->wc_ev_tab[0], r->wc_stream2));
+    }
+    int bi = 0;
+    for (int64_t done = 0; done < nq; bi ^= 1) {
         const int cur = (int)std::min<int64_t>(per_req, nq - done);
+        const int b = overlap ? bi : 0;
         if (fixed) {
             // a fresh generator per batch: every query of the batch reads the same words from its start
             if ((rc = p2s_rng_reseed(r, fixed_seed, s))) return rc;
@@ -1925,67 +1792,78 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
             rc = p2s_rng_session_raw(r, (long long)(2.0 * n_sel * 1.15 * cur) + margin, s);
         }
         if (rc) return rc;
-        hipLaunchKernelGGL(wc_tables_kernel, dim3(cur), dim3(256), (size_t)(NP_BUFSIZE + ((plan.n_nodes + 3) & ~3)) * 4, s, c->d.pts, n,
-                           q_dev + (size_t)done * 3, plan, K, r->wc_S, (WcRec *)r->wc_T, stot, pmax, mu, n_sel, meta);
+        if (overlap) {
+            const int64_t nxt = done + cur;
+            if (nxt < nq) {
+                // tables of the next batch into the other buffer, once the offsets pass two batches back has left it
+                if (nxt >= 2 * per_req) P2S_HIP_CHECK(hipStreamWaitEvent(r->wc_stream2, r->wc_ev_use[b ^ 1], 0));
+                launch_tables(nxt, (int)std::min<int64_t>(per_req, nq - nxt), b ^ 1, r->wc_stream2);
+                P2S_HIP_CHECK(hipEventRecord(r->wc_ev_tab[b ^ 1], r->wc_stream2));
+            }
+            P2S_HIP_CHECK(hipStreamWaitEvent(s, r->wc_ev_tab[b], 0));
+        } else {
+            launch_tables(done, cur, 0, s);
+        }
+        const WcBatchMem m = wc_batch_mem(r, b);
         WcArgs a;
-        a.S = r->wc_S;
-        a.R = (const WcRec *)r->wc_T;
-        a.stot = stot;
-        a.pmax = pmax;
+        a.S = m.S;
+        a.R = m.R;
+        a.stot = m.stot;
+        a.pmax = m.pmax;
+        a.dsum = m.dsum;
+        a.pts = c->d.pts;
+        a.q = q_dev + (size_t)done * 3;
         a.words = r->tmp;
         a.cap_words = cap;
-        a.alloc_words = cap + 624;
         a.n = n;
         a.K = K;
         a.nq = cur;
         a.nsel = n_sel;
-        a.base = base;
+        a.base = m.base;
         a.ids_out = ids_out_dev ? ids_out_dev + (size_t)done * n_sel : nullptr;
         a.meta = meta;
         a.stats = nullptr;
-        a.ctl = nullptr;
         a.fixed = fixed ? 1 : 0;
+        sp.mu = m.mu;
         if (want_stats) {
-            (void)hipMemsetAsync(stats_dev, 0, 16 * 8, s);
+            (void)hipMemsetAsync(stats_dev, 0, 32 * 8, s);
             a.stats = stats_dev;
         }
         if (fixed) {
             // no serial dependence between the queries: the ids kernel alone (it reports the last query's consumption)
         } else if (serial_only) {
-            if (big)
-                hipLaunchKernelGGL(wc_offsets_plain_kernel, dim3(1), dim3(256), lds_ids, s, a);
-            else
-                hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(WC_NT), lds_off, s, a);
+            hipLaunchKernelGGL(wc_ctl_init_kernel, dim3(1), dim3(1), 0, s, sp.ctl, meta);
+            hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), lds_ids, s, a, sp, 1, 1);
         } else {
             // speculation tables on all CUs + a light chain per block of SP_B queries; two spare pairs for blocks that
-            // end early (start outside the window); whatever is still unresolved then goes through the serial kernel
+            // end early (start outside the window); the last chain launch also takes whatever is still unresolved
             hipLaunchKernelGGL(wc_ctl_init_kernel, dim3(1), dim3(1), 0, s, sp.ctl, meta);
+            const int blk = std::min(cur, SP_B);
             const int pairs = (cur + SP_B - 1) / SP_B + (cur > SP_B / 2 ? 2 : 0);
             for (int pr = 0; pr < pairs; ++pr) {
-                hipLaunchKernelGGL(wc_spec_kernel, dim3(std::min(cur, SP_B)), dim3(256), 0, s, a, sp);
-                if (sp.jump) {
-                    hipLaunchKernelGGL(wc_jump0_kernel, dim3(std::min(cur, SP_B)), dim3(256), 0, s, a, sp);
-                    for (int k = 1; k < SP_LEV && (1 << k) < std::min(cur, SP_B); ++k)
-                        hipLaunchKernelGGL(wc_jumpk_kernel, dim3(std::min(cur, SP_B)), dim3(256), 0, s, a, sp, k);
-                }
-                hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), pr < (cur + SP_B - 1) / SP_B ? lds_chain : lds_ids, s, a, sp);
+                hipLaunchKernelGGL(wc_spec_kernel, dim3(blk), dim3(256), 0, s, a, sp);
+                for (int k = 1; k < SP_LEV && (1 << k) < blk; ++k)
+                    hipLaunchKernelGGL(wc_jumpk_kernel, dim3((blk + (1 << k) - 1) >> k), dim3(256), 0, s, a, sp, k);
+                hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), pr < (cur + SP_B - 1) / SP_B ? lds_chain : lds_ids, s, a, sp,
+                                   pr == pairs - 1 ? 1 : 0, 0);
             }
-            a.ctl = sp.ctl;
-            if (big)
-                hipLaunchKernelGGL(wc_offsets_plain_kernel, dim3(1), dim3(256), lds_ids, s, a);
-            else
-                hipLaunchKernelGGL(wc_offsets_kernel, dim3(1), dim3(WC_NT), wc_offsets_lds_bytes(n), s, a);
-            a.ctl = nullptr;
         }
         if (ids_out_dev) hipLaunchKernelGGL(wc_ids_kernel, dim3(cur), dim3(256), lds_ids, s, a);   // NULL: advance the stream only
+        if (overlap) P2S_HIP_CHECK(hipEventRecord(r->wc_ev_use[b], s));
         P2S_LAUNCH_CHECK("weighted sub-sample kernels");
         if (want_stats) {
-            long long h[16];
+            long long h[32];
             (void)hipMemcpyAsync(h, stats_dev, sizeof(h), hipMemcpyDeviceToHost, s);
             (void)hipStreamSynchronize(s);
-            fprintf(stderr, "[wc stats] %d queries: %lld full-algorithm fallbacks, %lld window misses; 10-ns ticks: "
-                            "A %lld issue %lld mark %lld sepcheck %lld clear+fallback %lld B %lld ring %lld; kernel %lld ticks = "
-                            "%lld shader clocks; chain passes that did work %lld, in-place fallbacks %lld taking %lld of %lld 10-ns ticks\n", cur, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14]);
+            fprintf(stderr, "[wc stats] %d queries: chain launches that did work %lld, queries through the complete algorithm %lld "
+                            "taking %lld of %lld 10-ns ticks; spec workgroups %lld: 10-ns ticks per workgroup in window %lld, dups+nd+pw %lld, "
+                            "verdict %lld, task list %lld, look-ups %lld, out %lld; listed candidates %.1f, tasks %.1f, dup draws %.1f per query\n",
+                    cur, h[11], h[12], h[13], h[14], h[8], h[0] / std::max(h[8], 1LL), h[1] / std::max(h[8], 1LL), h[2] / std::max(h[8], 1LL),
+                    h[3] / std::max(h[8], 1LL), h[4] / std::max(h[8], 1LL), h[5] / std::max(h[8], 1LL), (double)h[6] / std::max(h[8], 1LL),
+                    (double)h[7] / std::max(h[8], 1LL), (double)h[9] / std::max(h[8], 1LL));
+            fprintf(stderr, "[wc stats]   look-ups of lane 0: %lld tasks, %.2f passes and %.2f window steps per task, %.1f ticks per pass, %.1f ticks "
+                            "waiting for the loads per pass\n", h[20], (double)h[16] / std::max(h[20], 1LL), (double)h[17] / std::max(h[20], 1LL),
+                    (double)h[18] / std::max(h[16], 1LL), (double)h[19] / std::max(h[16], 1LL));
         }
         done += cur;
     }

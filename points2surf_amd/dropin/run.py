@@ -5,12 +5,16 @@ drop-in's ``source`` package in front of the reference's.
     python -m points2surf_amd.dropin.run full_eval.py --indir datasets --outdir results ...
     torchrun --nproc-per-node 8 -m points2surf_amd.dropin.run full_eval.py ...
 
-**All visible GPUs by default.**  The reference wraps its model in ``torch.nn.DataParallel`` without ``device_ids``
-(source/points_to_surf_eval.py:168): ``python full_eval.py`` on an 8-GPU node uses all 8.  The launcher keeps that:
-started WITHOUT a torchrun environment (no ``WORLD_SIZE``) on a node with more than one visible device it re-executes
-itself under ``torch.distributed.run`` with one rank per device (127.0.0.1 rendezvous, a free port); the ranks shard the
-shapes (points2surf_amd/sharding.py).  ``P2S_GPUS=<n>`` picks the number of ranks (``P2S_GPUS=1``: stay in this
-process; more than the visible devices is an error), ``HIP_VISIBLE_DEVICES`` the devices.
+**All visible GPUs by default -- for ``full_eval.py``.**  The reference wraps its model in ``torch.nn.DataParallel``
+without ``device_ids`` (source/points_to_surf_eval.py:168): ``python full_eval.py`` on an 8-GPU node uses all 8.  The
+launcher keeps that: started WITHOUT a torchrun environment (no ``WORLD_SIZE``) on a node with more than one visible
+device it re-executes itself under ``torch.distributed.run`` with one rank per device (127.0.0.1 rendezvous, a free
+port); the ranks shard the shapes (points2surf_amd/sharding.py).  ``P2S_GPUS=<n>`` picks the number of ranks
+(``P2S_GPUS=1``: stay in this process; more than the visible devices is an error), ``HIP_VISIBLE_DEVICES`` the devices.
+Only scripts whose every stage is rank-aware are ever started as several ranks (``RANK_AWARE_SCRIPTS``: ``full_eval.py``
+-- the drop-in's eval, mesh and comparison stages shard or run on rank 0).  Anything else -- ``full_run.py`` calls the
+reference's own ``points_to_surf_train``, ``make_dataset.py`` writes a data set -- runs in ONE process: N copies of a
+training would all write ``models/<name>_model.pth`` and the logs.  ``P2S_GPUS=<n>`` with such a script is refused.
 
 Why a launcher: ``python full_eval.py`` puts the script's directory at ``sys.path[0]``, i.e. BEFORE anything on
 ``PYTHONPATH``, so ``from source import points_to_surf_eval`` would find the reference's own ``source`` package first.
@@ -22,14 +26,24 @@ import runpy
 import sys
 
 
-def ranks_to_spawn(environ=None, device_count=None):
+RANK_AWARE_SCRIPTS = ('full_eval.py',)      # every stage shards over the ranks or runs on rank 0 only
+
+
+def ranks_to_spawn(environ=None, device_count=None, script=None):
     """how many ranks the launcher starts by itself: 0 = run in this process.  Under torchrun (WORLD_SIZE set) never;
-    otherwise one per visible device, or P2S_GPUS of them."""
+    otherwise, for a rank-aware script, one per visible device, or P2S_GPUS of them.  ``script`` None: treated as
+    rank-aware (callers that only ask about the environment)."""
     environ = os.environ if environ is None else environ
     if 'WORLD_SIZE' in environ:
         return 0
     want = environ.get('P2S_GPUS')
     if want is not None and int(want) <= 1:
+        return 0
+    if script is not None and os.path.basename(script) not in RANK_AWARE_SCRIPTS:
+        if want is not None:
+            raise SystemExit('points2surf_amd.dropin.run: P2S_GPUS=%s, but %s is not rank-aware (only %s are): its stages '
+                             'would run once per rank and overwrite each other\'s files'
+                             % (want, os.path.basename(script), ', '.join(RANK_AWARE_SCRIPTS)))
         return 0
     if device_count is None:
         import torch
@@ -53,7 +67,7 @@ def main(argv=None):
     script = os.path.abspath(argv[0])
     if not os.path.isfile(script):
         raise SystemExit('points2surf_amd.dropin.run: no such script: %s' % argv[0])
-    n = ranks_to_spawn()
+    n = ranks_to_spawn(script=script)
     if n:
         import socket
         import subprocess

@@ -27,6 +27,7 @@ Deliberate differences (documented in INTEGRATION.md):
 """
 import argparse
 import concurrent.futures
+import contextlib
 import os
 import random
 import time
@@ -391,29 +392,32 @@ def points_to_surf_eval(eval_opt):
                 finally:
                     cloud.close()
                 continue
-            if handoff is not None:
-                rngs = [rng_dev] + ([rng_rot] if rng_rot is not None else [])
-                handoff.begin(shape_ind, rngs)             # blocks until the owner of the shape before has published
-                if handoff.must_publish(shape_ind):
-                    def _advance():
-                        # on a handle of its own: a cloud smaller than the sub-sample is shuffled in place by its draws
-                        c2 = _engine.Cloud(pts_np, device=device)
-                        try:
-                            _sharding.skip_shape_stream(c2, rng_dev, cfg, eval_opt.query_grid_resolution,
-                                                        eval_opt.epsilon, model.sub_sample_size, rng_patch=rng_rot)
-                        finally:
-                            c2.close()
-                    handoff.publish_after(shape_ind, rngs, _advance)
-            cloud = _engine.Cloud(pts_np, device=device)
-            sdf, q = _infer_one_shape(model, cloud, rng_dev, eval_opt.query_grid_resolution, eval_opt.epsilon, chunk,
-                                      rng_patch=rng_rot)
-            sdf_np = sdf.cpu().numpy()
-            q_np = q.cpu().numpy()
-            total_q += sdf_np.shape[0]
-            pending.append(writers.submit(_save_shape, model_out_dir, shape_name, sdf_np, q_np))
-            cloud.close()
-            if handoff is not None:
-                handoff.done(shape_ind)
+            guard = handoff.guard(shape_ind) if handoff is not None else contextlib.nullcontext()
+            with guard:                    # an exception here leaves a 'failed' record: waiting ranks raise, not hang
+                if handoff is not None:
+                    rngs = [rng_dev] + ([rng_rot] if rng_rot is not None else [])
+                    handoff.begin(shape_ind, rngs)         # waits until the owner of the shape before has published
+                    if handoff.must_publish(shape_ind):
+                        def _advance(k):
+                            # on a handle of its own: a cloud smaller than the sub-sample is shuffled in place by its draws
+                            c2 = _engine.Cloud(pts_np if k == shape_ind else _load_points(eval_opt.indir, shape_names[k]),
+                                               device=device)
+                            try:
+                                _sharding.skip_shape_stream(c2, rng_dev, cfg, eval_opt.query_grid_resolution,
+                                                            eval_opt.epsilon, model.sub_sample_size, rng_patch=rng_rot)
+                            finally:
+                                c2.close()
+                        handoff.publish_after(shape_ind, rngs, _advance)
+                cloud = _engine.Cloud(pts_np, device=device)
+                sdf, q = _infer_one_shape(model, cloud, rng_dev, eval_opt.query_grid_resolution, eval_opt.epsilon, chunk,
+                                          rng_patch=rng_rot)
+                sdf_np = sdf.cpu().numpy()
+                q_np = q.cpu().numpy()
+                total_q += sdf_np.shape[0]
+                pending.append(writers.submit(_save_shape, model_out_dir, shape_name, sdf_np, q_np))
+                cloud.close()
+                if handoff is not None:
+                    handoff.done(shape_ind)
         for f in pending:
             f.result()                     # re-raise writer errors; everything is on disk when we return
         writers.shutdown(wait=True)

@@ -7,8 +7,19 @@ queries are compared by magnitude and reported separately; whether a flip really
 caller from the device's own sign logit (engine.query_logits)."""
 import numpy as np
 
-TIE_LOGIT = 2e-5       # |sign logit| below which a flipped sign counts as an fp32 tie (largest tie observed: 8e-6;
-                       # logit accuracy of the fp32 path ~1.5e-5)
+# |sign logit| below which a flipped sign counts as a tie of the sign decision, per encoder arithmetic:
+#  * IEEE fp32 encoder (cfg.encoder_bf16 = 0): the largest ties seen are 4.0e-6 on the device (p2s_max, 512^3) and 5.0e-6
+#    between two runs of the reference itself on the same inputs (other batch composition / thread count); at 256^3 the
+#    one known tie sits at 2.4e-7.  6e-6 covers those and nothing else.
+#  * split-precision encoders (3 bf16 pieces / fp16 pair, 22-24 mantissa bits per operand and another summation order):
+#    largest tie seen 8e-6 -> 2e-5, the logit accuracy of those modes.
+TIE_LOGIT_FP32 = 6e-6
+TIE_LOGIT_SPLIT = 2e-5
+
+
+def tie_logit(encoder_bf16=0):
+    """the tie threshold of an encoder mode (cfg.encoder_bf16: 0 fp32, 3 bf16x3, 4 fp16 pair)"""
+    return TIE_LOGIT_FP32 if not encoder_bf16 else TIE_LOGIT_SPLIT
 
 
 def compare_sdf(sdf, ref):
@@ -23,6 +34,7 @@ def compare_sdf(sdf, ref):
     return {'max_abs_dsdf': float(d.max()) if d.size else 0.0, 'flipped': flipped}
 
 
-def not_ties(sign_logits):
-    """how many of the flipped queries are NOT fp32 ties, given the device's sign logits for them"""
-    return int(sum(abs(float(x)) >= TIE_LOGIT for x in sign_logits))
+def not_ties(sign_logits, encoder_bf16=0):
+    """how many of the flipped queries are NOT ties, given the device's sign logits for them and the encoder mode"""
+    t = tie_logit(encoder_bf16)
+    return int(sum(abs(float(x)) >= t for x in sign_logits))

@@ -161,8 +161,9 @@ def skip_queries(cloud, rng_dev, cfg, queries, sub_sample_size, chunk=4096, rng_
     if cfg.get('uniform_subsample'):
         rng_dev.skip(cloud, sub_sample_size, n_queries=m)
     else:
-        for s in range(0, m, chunk):
-            rng_dev.skip(cloud, sub_sample_size, query_ms=queries[s:s + chunk])
+        # ONE call: the library walks the queries in batches of 4096 and builds the tables of the next batch on a second
+        # stream while the offsets pass of the current one runs (p2s_wchoice.hip)
+        rng_dev.skip(cloud, sub_sample_size, query_ms=queries)
 
 
 def skip_shape_stream(cloud, rng_dev, cfg, grid_resolution, epsilon, sub_sample_size, chunk=4096, rng_patch=None):
@@ -181,20 +182,25 @@ def skip_shape_stream(cloud, rng_dev, cfg, grid_resolution, epsilon, sub_sample_
 
 class StreamHandoff:
     """The dataset-wide generator state(s) handed from the owner of shape i to the owner of shape i+1 through the
-    process group's rendezvous store (TCPStore; keys are written once, ``get`` blocks until the key exists): the exact
-    single-process stream without any rank consuming the draws of a foreign shape.
+    process group's rendezvous store (TCPStore; keys are written once): the exact single-process stream without any
+    rank consuming the draws of a foreign shape.
 
         h = StreamHandoff('rec/p2s_max', owner)              # owner[i] = rank of shape i, same list on every rank
         for i in my shapes, ascending:
-            h.begin(i, rngs)                                 # my generators -> start of shape i (blocks for the token)
-            if h.must_publish(i):                            # the next shape belongs to another rank
-                h.publish_after(i, rngs, advance)            # advance(): consume shape i's draws (skip_shape_stream)
-            ... infer shape i with rngs ...
-            h.done(i)
+            with h.guard(i):                                 # any exception -> the 'failed' key: peers raise, not hang
+                h.begin(i, rngs)                             # my generators -> start of shape i (waits for the token)
+                if h.must_publish(i):                        # a later shape belongs to another rank, not yet served
+                    h.publish_after(i, rngs, advance)        # advance(k): consume shape k's draws (skip_shape_stream)
+                ... infer shape i with rngs ...
+                h.done(i)
 
-    ``rngs``: list of engine.Rng (the sub-sample generator; fixed-radius models add the patch-choice generator)."""
+    ``rngs``: list of engine.Rng (the sub-sample generator; fixed-radius models add the patch-choice generator).
+    Consecutive shapes of one owner: the token for the next FOREIGN shape j is published as soon as the first of them
+    is reached (``advance`` runs for i .. j-1), not after their inferences -- the ring never waits for an inference.
+    Failure: the owner of a shape that raises writes ``p2s/stream/<tag>/failed`` (rank, shape, message); ``begin``
+    polls its key and that one (slices of at most ``poll_s`` seconds) and raises, naming the failed shape and rank."""
 
-    def __init__(self, tag, owner, rank=None, store=None, timeout_s=7200.0):
+    def __init__(self, tag, owner, rank=None, store=None, timeout_s=7200.0, poll_s=0.05):
         import torch.distributed as dist
         self.owner = list(owner)
         self.rank = dist.get_rank() if rank is None else int(rank)
@@ -204,11 +210,16 @@ class StreamHandoff:
         self.store = store
         self.tag = str(tag)
         self.timeout_s = float(timeout_s)
+        self.poll_s = min(float(poll_s), 5.0)
         self.at = 0                     # my generators are positioned at the start of this shape
+        self.published = 0              # the start of every shape <= this index is known to its owner (as far as I know)
         self.waited_s = 0.0
 
     def _key(self, i):
         return 'p2s/stream/%s/%d' % (self.tag, i)
+
+    def _failed_key(self):
+        return 'p2s/stream/%s/failed' % self.tag
 
     @staticmethod
     def pack(rngs):
@@ -226,9 +237,36 @@ class StreamHandoff:
         for k, r in enumerate(rngs):
             r.set_state(a[625 * k:625 * k + 624].copy(), int(a[625 * k + 624]))
 
+    def failed(self):
+        """the failure record a rank left (str), or None"""
+        if self.store.check([self._failed_key()]):
+            return self.store.get(self._failed_key()).decode('utf-8', 'replace')
+        return None
+
+    def fail(self, i, exc):
+        """tell the ring that shape ``i`` of this rank raised: every rank waiting in ``begin`` raises instead of hanging"""
+        try:
+            if not self.store.check([self._failed_key()]):          # the first failure stays on record
+                self.store.set(self._failed_key(), ('rank %d failed at shape %d: %s: %s'
+                                                    % (self.rank, i, type(exc).__name__, exc))[:2000])
+        except Exception:
+            pass                         # the store itself is gone: the process group's own timeout takes over
+
+    def guard(self, i):
+        """context manager around everything a rank does for its shape ``i``"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _g():
+            try:
+                yield self
+            except BaseException as e:
+                self.fail(i, e)
+                raise
+        return _g()
+
     def begin(self, i, rngs):
         """position ``rngs`` at the first draw of shape ``i`` (which this rank owns)"""
-        import datetime
         import time
         if self.owner[i] != self.rank:
             raise ValueError('shape %d belongs to rank %d' % (i, self.owner[i]))
@@ -236,20 +274,44 @@ class StreamHandoff:
             self.at = i
             return
         t0 = time.time()
-        self.store.wait([self._key(i)], datetime.timedelta(seconds=self.timeout_s))
-        self.unpack(self.store.get(self._key(i)), rngs)
+        key, nap = self._key(i), 0.001
+        while not self.store.check([key]):
+            why = self.failed()
+            if why is not None:
+                raise RuntimeError('stream hand-off (%s): waiting for the start of shape %d on rank %d, but %s'
+                                   % (self.tag, i, self.rank, why))
+            if time.time() - t0 > self.timeout_s:
+                raise TimeoutError('stream hand-off (%s): the start of shape %d (owner of shape %d: rank %d) did not arrive '
+                                   'within %.0f s' % (self.tag, i, i - 1, self.owner[i - 1], self.timeout_s))
+            time.sleep(nap)
+            nap = min(nap * 1.5, self.poll_s)
+        self.unpack(self.store.get(key), rngs)
         self.waited_s += time.time() - t0
         self.at = i
+        self.published = max(self.published, i)
+
+    def next_foreign(self, i):
+        """the first shape after ``i`` that belongs to another rank (None: the rest of the dataset is mine)"""
+        for j in range(i + 1, len(self.owner)):
+            if self.owner[j] != self.rank:
+                return j
+        return None
 
     def must_publish(self, i):
-        return i + 1 < len(self.owner) and self.owner[i + 1] != self.rank
+        j = self.next_foreign(i)
+        return j is not None and j > self.published
 
     def publish_after(self, i, rngs, advance):
-        """run ``advance()`` (consume the draws of shape i), publish the state as the start of shape i+1, then put the
-        generators back to the start of shape i"""
+        """``advance(k)`` consumes the draws of my shape k: run it for k = i .. j-1 (j = the next foreign shape), publish the
+        state as the start of shape j, then put the generators back to the start of shape i"""
+        j = self.next_foreign(i)
+        if j is None or j <= self.published:
+            return
         snap = [r.get_state() for r in rngs]
-        advance()
-        self.store.set(self._key(i + 1), self.pack(rngs))
+        for k in range(i, j):
+            advance(k)
+        self.store.set(self._key(j), self.pack(rngs))
+        self.published = j
         for r, (mt, pos) in zip(rngs, snap):
             r.set_state(mt, pos)
 

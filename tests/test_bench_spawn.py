@@ -54,6 +54,13 @@ def test_launcher_uses_all_visible_devices_by_default(tmp_path, monkeypatch):
     assert run.ranks_to_spawn({}, 1) == 0 and run.ranks_to_spawn({}, 0) == 0
     with pytest.raises(SystemExit):
         run.ranks_to_spawn({'P2S_GPUS': '16'}, 8)
+    # only rank-aware scripts are ever started as several ranks -- full_run.py calls the reference's own
+    # training, which N ranks would run N times into the same model files
+    assert run.ranks_to_spawn({}, 8, script='/x/full_eval.py') == 8
+    assert run.ranks_to_spawn({}, 8, script='/x/full_run.py') == 0 and run.ranks_to_spawn({}, 8, script='make_dataset.py') == 0
+    assert run.ranks_to_spawn({'P2S_GPUS': '1'}, 8, script='/x/full_run.py') == 0
+    with pytest.raises(SystemExit, match='not rank-aware'):
+        run.ranks_to_spawn({'P2S_GPUS': '4'}, 8, script='/x/full_run.py')
     cmd = run.spawn_command(8, ['/x/full_eval.py', '--indir', 'd'], 4711)
     assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node' in cmd and '8' in cmd
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '4711'
@@ -61,7 +68,7 @@ def test_launcher_uses_all_visible_devices_by_default(tmp_path, monkeypatch):
     # end to end: two ranks (P2S_GPUS=2 with a faked device count) run the SCRIPT, each with its own RANK
     script = tmp_path / 's.py'
     script.write_text("import os\nopen(os.path.join(%r, 'rank_' + os.environ['RANK']), 'w').write(os.environ['WORLD_SIZE'])\n" % str(tmp_path))
-    monkeypatch.setattr(run, 'ranks_to_spawn', lambda environ=None, device_count=None: 0 if 'WORLD_SIZE' in os.environ else 2)
+    monkeypatch.setattr(run, 'ranks_to_spawn', lambda environ=None, device_count=None, script=None: 0 if 'WORLD_SIZE' in os.environ else 2)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
         monkeypatch.delenv(k, raising=False)
     assert run.main([str(script)]) == 0

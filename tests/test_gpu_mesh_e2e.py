@@ -11,7 +11,7 @@ oracle/make_golden_volumes.py, meshed by skimage 0.18.3's marching_cubes_lewiner
   (2) the mesh of the DEVICE-inferred SDF has the same vertex and face COUNTS, the same face index array (same cells,
       same tilings, same emission order) and vertex positions that differ only by what 2e-6 of SDF moves them.
 
-A sign that differs from the reference's is only ever an fp32 tie of ``sign logit >= 0`` (|logit| < 2e-5, proven in
+A sign that differs from the reference's is only ever an fp32 tie of ``sign logit >= 0`` (|logit| < parity.TIE_LOGIT_FP32 for the fp32 encoder, TIE_LOGIT_SPLIT for the fp16 pair, proven in
 tests/test_gpu_sizes.py; one such query among the 1.38 M of the three clouds at 256^3): for that cloud the test reports
 exactly what the flipped voxel does to the mesh (dV, dF) and bounds it."""
 import hashlib

@@ -17,6 +17,10 @@ def test_compare_sdf_reports_flips_and_compares_their_magnitudes():
 
 
 def test_tie_threshold():
-    assert parity.not_ties([-4.0e-6, -2.2e-6]) == 0       # the two ties of the 512^3 grid
+    assert parity.not_ties([-4.0e-6, -2.2e-6]) == 0       # the two ties of the 512^3 grid (fp32 encoder)
     assert parity.not_ties([6e-5, -1e-6, -3e-3]) == 2
     assert parity.not_ties([]) == 0
+    # the fp32 encoder has its own, tighter threshold than the split-precision modes
+    assert parity.tie_logit(0) == parity.TIE_LOGIT_FP32 < parity.TIE_LOGIT_SPLIT == parity.tie_logit(4) == parity.tie_logit(3)
+    assert parity.not_ties([8e-6]) == 1 and parity.not_ties([8e-6], encoder_bf16=4) == 0
+    assert parity.not_ties([2.4e-7, -1.4e-7]) == 0        # the one tie of the 256^3 three-cloud dataset

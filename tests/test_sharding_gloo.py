@@ -1,5 +1,6 @@
 """N > 1 path on CPU: world_size-2 gloo process group (LPT assignment + variable-length gather)."""
 import os
+import time
 import socket
 
 import numpy as np
@@ -120,20 +121,23 @@ def _handoff_worker(rank, world, port, outdir):
     assert sharding.stream_handoff_enabled()
     a, b = _FakeRng(40938661), _FakeRng(99)       # two generators (fixed-radius models hand over both)
     h = sharding.StreamHandoff('test', OWNER, rank=rank)
-    seen = {}
+    seen, published_at = {}, {}
     for i in [k for k, o in enumerate(OWNER) if o == rank]:
-        h.begin(i, [a, b])
-        seen[i] = (int(a.mt[0]), a.pos, int(b.mt[0]), b.pos)
-        if h.must_publish(i):
-            def advance():
-                a.consume(DRAWS[i])
-                b.consume(2 * DRAWS[i])
-            h.publish_after(i, [a, b], advance)
-            assert (int(a.mt[0]), a.pos, int(b.mt[0]), b.pos) == seen[i]     # put back to the start of shape i
-        a.consume(DRAWS[i])                       # "inference" of shape i
-        b.consume(2 * DRAWS[i])
-        h.done(i)
+        with h.guard(i):
+            h.begin(i, [a, b])
+            seen[i] = (int(a.mt[0]), a.pos, int(b.mt[0]), b.pos)
+            if h.must_publish(i):
+                def advance(k):
+                    a.consume(DRAWS[k])
+                    b.consume(2 * DRAWS[k])
+                h.publish_after(i, [a, b], advance)
+                published_at[h.published] = i
+                assert (int(a.mt[0]), a.pos, int(b.mt[0]), b.pos) == seen[i]     # put back to the start of shape i
+            a.consume(DRAWS[i])                       # "inference" of shape i
+            b.consume(2 * DRAWS[i])
+            h.done(i)
     np.save(os.path.join(outdir, 'seen_%d.npy' % rank), np.array([[k] + list(v) for k, v in seen.items()], dtype=np.int64))
+    np.save(os.path.join(outdir, 'pub_%d.npy' % rank), np.array(sorted(published_at.items()), dtype=np.int64).reshape(-1, 2))
     sharding.barrier()
     dist.destroy_process_group()
 
@@ -155,3 +159,54 @@ def test_stream_handoff_gives_every_owner_the_single_process_state(tmp_path):
         for row in np.load(os.path.join(str(tmp_path), 'seen_%d.npy' % r)):
             got[int(row[0])] = tuple(int(x) for x in row[1:])
     assert got == want
+    # consecutive shapes of one owner: the start of the next FOREIGN shape is published when the FIRST of them is
+    # reached, not after their inferences (OWNER = [0, 1, 1, 2, 0, 0, 2, 1, 0]: rank 1 publishes shape 3 at shape 1,
+    # rank 0 publishes shape 6 at shape 4)
+    pub = {r: {int(j): int(i) for j, i in np.load(os.path.join(str(tmp_path), 'pub_%d.npy' % r))} for r in range(3)}
+    assert pub[1][3] == 1 and pub[0][6] == 4 and pub[0][1] == 0 and pub[2][4] == 3 and pub[2][7] == 6 and pub[1][8] == 7
+
+
+def _handoff_failing_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    sharding.init_process_group('gloo')
+    a = _FakeRng(40938661)
+    h = sharding.StreamHandoff('failing', [0, 1, 2, 0, 1, 2], rank=rank, timeout_s=120.0)
+    t0 = time.time()
+    what = 'finished'
+    try:
+        for i in [k for k, o in enumerate(h.owner) if o == rank]:
+            with h.guard(i):
+                h.begin(i, [a])
+                if rank == 1 and i == 1:
+                    raise ValueError('injected failure of shape 1')          # BEFORE publishing the start of shape 2
+                if h.must_publish(i):
+                    h.publish_after(i, [a], lambda k: a.consume(DRAWS[k]))
+                a.consume(DRAWS[i])
+                h.done(i)
+    except ValueError as e:
+        what = 'raised ValueError: %s' % e
+    except RuntimeError as e:
+        what = 'raised RuntimeError: %s' % e
+    with open(os.path.join(outdir, 'out_%d.txt' % rank), 'w') as f:
+        f.write('%.2f\n%s\n' % (time.time() - t0, what))
+    # no barrier: a crashed rank would not reach it either
+    dist.destroy_process_group()
+
+
+def test_stream_handoff_failure_reaches_the_waiting_ranks(tmp_path):
+    """a rank that raises while it holds the token leaves a 'failed' record in the store; the ranks
+    waiting for a later token raise within seconds, naming the failed shape and rank, instead of blocking for the 7200 s
+    time-out"""
+    port = _free_port()
+    mp.spawn(_handoff_failing_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    out = {}
+    for r in range(3):
+        with open(os.path.join(str(tmp_path), 'out_%d.txt' % r)) as f:
+            secs, what = f.read().split('\n')[:2]
+        out[r] = (float(secs), what)
+    assert out[1][1].startswith('raised ValueError: injected failure')
+    for r in (0, 2):       # rank 2 waits for shape 2, rank 0 for shape 3: both learn of rank 1's failure
+        assert out[r][1].startswith('raised RuntimeError: stream hand-off (failing)'), out[r]
+        assert 'rank 1 failed at shape 1' in out[r][1] and 'injected failure' in out[r][1]
+        assert out[r][0] < 30.0, out[r]

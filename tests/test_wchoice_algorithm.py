@@ -66,3 +66,48 @@ def test_speculation_table_equals_actual_redraws(n_pts, seed):
         else:
             assert actual > 0
     assert decided > 0 or n_pts < 10000
+
+
+@pytest.mark.parametrize('n_pts,seed', [(20000, 5), (34693, 6), (13000, 9)])
+def test_exact_resolution_of_close_redraws_decides_nearly_every_candidate(n_pts, seed):
+    """r05 (wc_wave_bin in wc_spec_kernel): the candidates the distance test leaves open are decided by looking the close
+    round-2 draws up in the candidate's own modified cdf -- every decision equals what the complete algorithm consumes
+    from that start, and (nearly) nothing stays undecided even for small clouds with many collisions"""
+    rs = np.random.RandomState(seed)
+    pts = rs.uniform(-0.7, 0.7, (n_pts, 3)).astype(np.float32)
+    q = rs.uniform(-0.5, 0.5, 3).astype(np.float32)
+    tb = wm.Tables(orc.dist_prob(pts, q))
+    nsel, W = 1000, 160
+    xs = orc.LegacyMT19937(seed).rand(W + 5 * nsel)
+    before = wm.spec_redraws(tb, xs, nsel, W)
+    table = wm.spec_redraws_exact(tb, xs, nsel, W)
+    newly = np.nonzero((before == 255) & (table != 255))[0]
+    check = sorted(set(newly.tolist()) | set(range(0, W, 16)))
+    for d in check:
+        pos = [d]
+
+        def rand(m):
+            out = xs[pos[0]:pos[0] + m]
+            pos[0] += m
+            return out
+        wm.choice_noreplace(tb, rand, nsel)
+        actual = pos[0] - d - nsel
+        if table[d] != 255:
+            assert table[d] == actual, (d, before[d], table[d], actual)
+    assert (before == 255).sum() == 0 or newly.size > 0
+    assert (table == 255).mean() <= 0.25 * max((before == 255).mean(), 0.04), ((before == 255).mean(), (table == 255).mean())
+
+
+def test_modified_bin_equals_numpy_searchsorted_on_the_zeroed_cdf():
+    rs = np.random.RandomState(3)
+    pts = rs.uniform(-0.7, 0.7, (5000, 3)).astype(np.float32)
+    tb = wm.Tables(orc.dist_prob(pts, rs.uniform(-0.5, 0.5, 3).astype(np.float32)))
+    p = np.diff(np.concatenate([[0.0], tb.S]))
+    for t in range(6):
+        found = np.unique(np.searchsorted(tb.S / tb.Stot, rs.rand(1000), side='right'))
+        p2 = p.copy()
+        p2[found] = 0.0
+        cdf = np.cumsum(p2)
+        cdf /= cdf[-1]
+        for x in np.concatenate([rs.rand(40), cdf[rs.randint(0, 5000, 10)], [0.0, 1.0 - 2.0 ** -53]]):
+            assert wm.modified_bin(tb, float(x), found, p) == int(np.searchsorted(cdf, x, side='right')), (t, x)

@@ -216,3 +216,90 @@ def spec_redraws(tb, xs, nsel, W, look=64):
             if not bad:
                 out[d] = m
     return out
+
+
+def modified_bin(tb, x, found_ids, p):
+    """Model of wc_wave_bin (r05): searchsorted(cdf', x, 'right') for the cdf modified by a candidate's found set,
+    located gap by gap with the exact predicate only -- smallest i with fl((S_i - C(i)) / St_cur) > x,
+    C(i) = mass of the found ids <= i.  ``found_ids``: the distinct first-round bins; ``p``: float64 probabilities."""
+    found = np.unique(np.asarray(found_ids, dtype=np.int64))
+    Ctot = float(np.sum(p[found]))
+    St_cur = tb.Stot - Ctot
+    n = tb.n
+
+    def gt(S):
+        return S / St_cur > x
+    t = x * St_cur + x * Ctot
+    b = min(tb.K - 1, max(0, int((t / tb.Stot) * tb.K)))
+    i = min(int(tb.T[b]), n - 1)
+    for _ in range(12):
+        below = found[found <= i]
+        Cle = float(np.sum(p[below]))
+        lo = int(below.max()) if below.size else -1
+        above = found[found > i]
+        hi = int(above.min()) if above.size else n
+        if lo >= 0 and gt(tb.S[lo] - Cle):
+            i = lo - 1
+            assert i >= 0
+            continue
+        if hi < n and not gt(tb.S[hi - 1] - Cle):
+            i = hi + 1
+            assert i < n
+            continue
+        k0 = max(lo + 1, min(i - 24, hi - 64))
+        for _w in range(64):
+            ks = np.arange(k0, k0 + 64)
+            pr = np.array([(k >= hi) or gt(tb.S[k] - Cle) for k in ks])
+            if not pr.any():
+                k0 += 64
+            elif pr[0] and k0 > lo + 1:
+                k0 = max(lo + 1, k0 - 63)
+            else:
+                return int(k0 + np.argmax(pr))
+        return -1
+    return -1
+
+
+def spec_redraws_exact(tb, xs, nsel, W, look=64):
+    """Model of wc_spec_kernel since r05: as spec_redraws, but a candidate whose round-2 draws hold close pairs is decided
+    by looking the bins of those draws up exactly in the candidate's own modified cdf (modified_bin): m3 = round-2 draws
+    that hit a bin another round-2 draw took first; R = m2 + m3 if m3 <= 1 or the m3 draws of round 3 are pairwise farther
+    apart than the widest bin of any modified cdf."""
+    out = spec_redraws(tb, xs, nsel, W, look)
+    cdf = tb.S / tb.Stot
+    nb = W + nsel
+    bins = np.searchsorted(cdf, xs[:nb], side='right')
+    p = np.diff(np.concatenate([[0.0], tb.S]))
+    pm = float(p.max())
+    denom = tb.Stot - nsel * pm
+    if not denom > 0.25 * tb.Stot:
+        return out
+    wmax = (pm / denom) * (1.0 + 1e-9)
+    for d in np.nonzero(out == 255)[0]:
+        found = bins[d:d + nsel]
+        m2 = nsel - np.unique(found).size
+        if m2 == 0 or m2 > look:
+            continue
+        x2 = xs[d + nsel:d + nsel + m2]
+        flagged = [j for j in range(m2) if any(j2 != j and abs(x2[j] - x2[j2]) <= wmax for j2 in range(m2))]
+        b2 = {j: modified_bin(tb, float(x2[j]), found, p) for j in flagged}
+        if any(v < 0 for v in b2.values()):
+            continue
+        m3 = len(flagged) - len(set(b2.values()))
+        # what the kernel does: bins are monotone in x, so with the close draws sorted by value m3 = the neighbours (next
+        # larger close draw within wmax; ties: the later draw) that share the bin of their predecessor -- one look-up per pair
+        m3_pairs = 0
+        for j in flagged:
+            above = [(x2[e], e) for e in range(m2) if e != j and (x2[e] > x2[j] or (x2[e] == x2[j] and e > j))]
+            if above:
+                xe, e = min(above)
+                if xe - x2[j] <= wmax:
+                    m3_pairs += int(b2[j] == modified_bin(tb, float(xe), found, p))
+        assert m3_pairs == m3, (d, m3_pairs, m3)
+        if m3 <= 1:
+            out[d] = m2 + m3
+        else:
+            x3 = xs[d + nsel + m2:d + nsel + m2 + m3]
+            if all(abs(x3[j] - x3[j2]) > wmax for j in range(m3) for j2 in range(j)):
+                out[d] = m2 + m3
+    return out
