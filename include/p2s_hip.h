@@ -33,6 +33,7 @@ extern "C" {
 #define P2S_ENOMEM       -3
 #define P2S_ECAPACITY    -4   /* caller-provided output buffer too small, or an input beyond a documented size limit */
 #define P2S_ENODEVICE    -5   /* no gfx950 device visible */
+#define P2S_EIO          -6   /* host file could not be opened / written / closed (the p2s_write_* functions) */
 
 typedef struct p2s_model_s *p2s_model_t;
 typedef struct p2s_cloud_s *p2s_cloud_t;

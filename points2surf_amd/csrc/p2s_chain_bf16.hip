@@ -52,12 +52,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef P2S_F16_WG
 #define P2S_F16_WG 3
 #endif
-// development only (timing, WRONG results): bit mask of work to leave out -- tools/f16_variants.sh
-//   1 tile write-back (combine / bias / ReLU / split / LDS stores)   2 conv3 weight stream (one k-block per column tile)
-//   4 conv3 A fragments (one k-block per column tile)                 8 first layer   16 conv0b / conv1 / conv2
-#ifndef P2S_F16_ABL
-#define P2S_F16_ABL 0
-#endif
 constexpr int MT = P2S_BF16_MT;  // points per tile (64 or 128: larger tiles halve the L2 weight stream of conv3)
 constexpr int NB = MT / 32;      // 32-row blocks per tile
 constexpr int PPL = MT / 64;     // points per lane in the first layer
@@ -131,13 +125,6 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[F16 ? 2 : 1], uns
     const int c = col0 + (lane & 31);
     const float b = bias[c];
     unsigned short *dst = buf + (row0 + 4 * (lane >> 5)) * H + c;
-    if (P2S_F16_ABL & 1) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s += acc[0][i] + acc[F16 ? 1 : 0][i];
-        if (s == 12345.678f) dst[0] = 1;
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
         const int r = (i & 3) + 8 * (i >> 2);             // rows r and r + 1
@@ -159,18 +146,13 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[F16 ? 2 : 1], uns
     }
 }
 
-// PIPE (fp16 pair only, r04): conv3 as ONE software pipeline over its 8 column tiles x 8 k-blocks with rotating operand
-// registers -- weight fragments fetched three k-steps ahead of their use (4 sets, also across column tiles and across
-// the point tiles of the workgroup), A fragments one k-step ahead (2 sets), one memory instruction in every MFMA shadow
-// (sched_group_barrier) -- and the small layers' weights fetched before the barrier that guards their input.  The
-// non-PIPE schedule (r03) issued every weight load one or two MFMAs before its use: each wave sat out the L2 latency
-// once per k-step and only the other two waves of its SIMD kept the matrix pipe at 71 %.
 // SUM: sym_op='sum' -- the pool over the points is a masked sum instead of the max (a compile-time variant: as a run-time
 // branch inside the unrolled column-tile loop it cost the max kernels 40 VGPRs and pushed the fp16 pair kernel into scratch)
-template <int NS, bool F16, bool PIPE = false, bool SUM = false>
-__global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 : 2)) void p2s_chain_bf16_kernel(ChainArgs args) {
-    static_assert(!PIPE || (F16 && NS == 2 && MT == 64), "the pipelined schedule is written for the fp16 pair mode");
-    static_assert(!(PIPE && SUM), "the sum pool is built into the default schedule only");
+// Register budgets (workgroups per CU the compiler allocates for): fp16 pair 3 (127 VGPRs; sum pool 153); plain bf16 4 (127;
+// its sum pool 3 -- at 128 VGPRs it spilled 15); split bf16 2 (144 / 164 VGPRs, sum pool 173 / 187: their 53 / 80 KB of LDS
+// allow 3 / 2 workgroups anyway, and the three-piece mode is the one inside the accuracy contract).  No scratch in any of them.
+template <int NS, bool F16, bool SUM = false>
+__global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? (SUM ? 3 : 4) : 2)) void p2s_chain_bf16_kernel(ChainArgs args) {
     constexpr int NA = F16 ? 2 : 1;                       // accumulators per tile (fp16 pair: second one scaled by 2^-11)
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_bf16[];
     constexpr int SA = MT * HA, SB = MT * HB;             // halfs per piece
@@ -226,34 +208,8 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 
     bool bad = false;       // non-finite input poisons the item (torch propagates NaN through conv / ReLU / max)
     bool range_bad = false; // fp16 pair mode: an activation beyond the half range
 
-    // PIPE: weight fragments in flight.  bq: conv3, sets (step & 3), [piece]; wq: the next small layer, [k-block][piece]
-    u32x4 bq[4][NS], wq[4][NS];
-    int wbase = wave * 65536;                              // conv3: byte offset of step j = 8 ct + kb is wbase + 1024 j
     const int ntiles = (P + MT - 1) / MT;
-    if (PIPE) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int q = 0; q < NS; ++q) bq[j][q] = bufld(rs3, lane16, q * pb + wbase + j * 1024);
-    }
     for (int tile = 0; tile < ntiles; ++tile) {
-        if (PIPE) {
-            // keep the conv3 offsets loop-variant: hoisted out of the tile loop they are 128 live SGPRs, which the compiler
-            // parks in VGPR lanes and fetches back with v_readlane + 4 wait states in front of every load
-            asm volatile("" : "+s"(wbase));
-            if (!short_chain) {
-                const int nt = wave & 1;
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) wq[kb][q] = bufld(rs0b, lane16, q * pb + (nt * 4 + kb) * 1024);
-            } else {
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) wq[kb][q] = bufld(rs2, lane16, q * pb + (wave * 4 + kb) * 1024);
-            }
-        }
         // ---- this lane's point(s) (all 4 waves load the same points; past the end: the last point again) ----
 #pragma unroll
         for (int pp = 0; pp < PPL; ++pp) {
@@ -281,10 +237,6 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 
 #pragma unroll
             for (int c = 0; c < 16; c += 2) {
                 float sv[2];
-                if (P2S_F16_ABL & 8) {
-                    sv[0] = x0;
-                    sv[1] = x1 + x2;
-                } else
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int o = 16 * wave + c + u;     // wave-uniform -> scalar loads
@@ -303,7 +255,7 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 
         }
         __syncthreads();          // bufA ready; every wave is past its conv3 reads of bufB (previous tile)
 
-        if (!short_chain && !(P2S_F16_ABL & 16)) {
+        if (!short_chain) {
             // ---- conv0b: bufA -> bufB[:, 0:64]; wave = (row block, column tile) ----
             {
                 const int rt = wave >> 1, nt = wave & 1;          // row blocks rt, rt + 2, ...; column tile nt
@@ -316,7 +268,7 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 
                 for (int kb = 0; kb < 4; ++kb) {
                     u32x4 b[NS];
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) b[q] = PIPE ? wq[kb][q] : bufld(rs0b, lane16, q * pb + (nt * 4 + kb) * 1024);
+                    for (int q = 0; q < NS; ++q) b[q] = bufld(rs0b, lane16, q * pb + (nt * 4 + kb) * 1024);
 #pragma unroll
                     for (int r = 0; r < NB / 2; ++r)
 #pragma unroll
@@ -326,12 +278,6 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 
                             for (int q = NS - 1 - p; q >= 0; --q)
                                 acc[r][F16 ? p + q : 0] = mfma_bf16<F16>(a, b[q], acc[r][F16 ? p + q : 0]);
                         }
-                }
-                if (PIPE) {                                  // conv1's weights: in flight across the write-back and the barrier
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                        for (int q = 0; q < NS; ++q) wq[kb][q] = bufld(rs1, lane16, q * pb1 + (nt * 4 + kb) * 1024);
                 }
 #pragma unroll
                 for (int r = 0; r < NB / 2; ++r) store_tile<NS, F16>(acc[r], bufB, HB, SB, 32 * (rt + 2 * r), 32 * nt, br.b0b, lane, range_bad);
@@ -349,7 +295,7 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 
                 for (int kb = 0; kb < 4; ++kb) {
                     u32x4 b[NS];
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) b[q] = PIPE ? wq[kb][q] : bufld(rs1, lane16, q * pb1 + (nt * 4 + kb) * 1024);
+                    for (int q = 0; q < NS; ++q) b[q] = bufld(rs1, lane16, q * pb1 + (nt * 4 + kb) * 1024);
 #pragma unroll
                     for (int r = 0; r < NB / 2; ++r)
 #pragma unroll
@@ -360,19 +306,13 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 
                                 acc[r][F16 ? p + q : 0] = mfma_bf16<F16>(a, b[q], acc[r][F16 ? p + q : 0]);
                         }
                 }
-                if (PIPE) {                                  // conv2's weights
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                        for (int q = 0; q < NS; ++q) wq[kb][q] = bufld(rs2, lane16, q * pb + (wave * 4 + kb) * 1024);
-                }
 #pragma unroll
                 for (int r = 0; r < NB / 2; ++r) store_tile<NS, F16>(acc[r], bufA, HA, SA, 32 * (rt + 2 * r), 32 * nt, br.b1, lane, range_bad);
             }
             __syncthreads();
         }
         // ---- conv2 (64 -> 128): bufA -> bufB; wave = column tile, both row blocks ----
-        if (!(P2S_F16_ABL & 16)) {
+        {
             f32x16 acc[NB][NA];
 #pragma unroll
             for (int r = 0; r < NB; ++r)
@@ -382,7 +322,7 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 
             for (int kb = 0; kb < 4; ++kb) {
                 u32x4 b[NS];
 #pragma unroll
-                for (int q = 0; q < NS; ++q) b[q] = PIPE ? wq[kb][q] : bufld(rs2, lane16, q * pb + (wave * 4 + kb) * 1024);
+                for (int q = 0; q < NS; ++q) b[q] = bufld(rs2, lane16, q * pb + (wave * 4 + kb) * 1024);
 #pragma unroll
                 for (int r = 0; r < NB; ++r)
 #pragma unroll
@@ -402,84 +342,7 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 
         // other pieces are re-read from LDS in every k-step (conflict-free 16-byte reads, 2 x (NS - HOLD) per 2 NS (NS+1)/2
         // MFMAs).  Holding all three pieces of the split mode needs 192 VGPRs for A alone and spilled (r02: 48 B/lane,
         // 4.9x the algorithmic write traffic).
-        if constexpr (PIPE) {
-            const unsigned short *ap = bufB + (lane & 31) * HB + 8 * (lane >> 5);
-#define P2S_LDA(P_, R_, KB_) (*reinterpret_cast<const u32x4 *>(ap + (P_) * SB + 32 * (R_) * HB + 16 * (KB_)))
-            // A fragments: ONE register set -- a fragment is re-fetched for the next k-step right behind the last MFMA that
-            // reads it (the LDS data arrives tens of cycles later; 4-5 MFMAs lie between the fetch and its first use)
-            u32x4 a00, a01, a10, a11;                        // a<piece><row block>
-            a10 = P2S_LDA(1, 0, 0);
-            a11 = P2S_LDA(1, 1, 0);
-            a00 = P2S_LDA(0, 0, 0);
-            a01 = P2S_LDA(0, 1, 0);
-            f32x16 acc[2][2];                                // [row block][0: h0 h0', 1: (h0 h1' + h1 h0') * 2^11]
-            const f32x16 zero = f32x16{};
-            int base = wbase;                                // byte offset of this column tile's k-block 0
-#pragma unroll 1
-            for (int ct = 0; ct < 8; ++ct) {
-                const int nbase = (ct == 7) ? wbase : base + 8192;      // next column tile (the next point tile's first one)
-#pragma unroll
-                for (int kb = 0; kb < 8; ++kb) {
-                    // weights of step + 3 go into the set step - 1 has just released; the two row blocks alternate, so
-                    // dependent MFMAs are two apart
-                    const int so = (kb + 3 < 8) ? base + (kb + 3) * 1024 : nbase + (kb - 5) * 1024;
-                    const int kn = (kb + 1) & 7;             // (the fetch behind the last step of the last tile is idle)
-                    const u32x4 b0 = bq[kb & 3][0], b1 = bq[kb & 3][1];
-                    acc[0][1] = mfma_bf16<true>(a10, b0, kb == 0 ? zero : acc[0][1]);
-                    a10 = P2S_LDA(1, 0, kn);
-                    acc[1][1] = mfma_bf16<true>(a11, b0, kb == 0 ? zero : acc[1][1]);
-                    a11 = P2S_LDA(1, 1, kn);
-                    acc[0][1] = mfma_bf16<true>(a00, b1, acc[0][1]);
-                    bq[(kb + 3) & 3][0] = bufld(rs3, lane16, so);
-                    acc[1][1] = mfma_bf16<true>(a01, b1, acc[1][1]);
-                    bq[(kb + 3) & 3][1] = bufld(rs3, lane16, pb + so);
-                    acc[0][0] = mfma_bf16<true>(a00, b0, kb == 0 ? zero : acc[0][0]);
-                    a00 = P2S_LDA(0, 0, kn);
-                    acc[1][0] = mfma_bf16<true>(a01, b0, kb == 0 ? zero : acc[1][0]);
-                    a01 = P2S_LDA(0, 1, kn);
-                    // one memory instruction per MFMA shadow (0x008 MFMA, 0x020 VMEM read, 0x100 DS read)
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                float m;
-                if (psum) {
-                    const int nvalid = P - tile * MT;
-                    m = 0.0f;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int row = 32 * r + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                            m += (row < nvalid) ? acc[r][0][i] + acc[r][1][i] * F16_SCALE : 0.0f;
-                        }
-                    m += __shfl_xor(m, 32);
-                } else {
-                    m = -INFINITY;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[r][0][i] + acc[r][1][i] * F16_SCALE);
-                    m = fmaxf(m, __shfl_xor(m, 32));
-                }
-#define P2S_POOL(dst) dst = psum ? dst + m : fmaxf(dst, m)
-                // static register indexing (a runtime-indexed array would go to scratch)
-                if (ct == 0) P2S_POOL(rmax[0]);
-                else if (ct == 1) P2S_POOL(rmax[1]);
-                else if (ct == 2) P2S_POOL(rmax[2]);
-                else if (ct == 3) P2S_POOL(rmax[3]);
-                else if (ct == 4) P2S_POOL(rmax[4]);
-                else if (ct == 5) P2S_POOL(rmax[5]);
-                else if (ct == 6) P2S_POOL(rmax[6]);
-                else P2S_POOL(rmax[7]);
-#undef P2S_POOL
-                base += 8192;
-            }
-#undef P2S_LDA
-        } else {
+        {
             constexpr int HOLDW = F16 ? P2S_F16_HOLD : P2S_BF16_HOLD;
             constexpr int HOLD = (NS == 1) ? 1 : ((HOLDW < NS) ? HOLDW : NS);
             u32x4 af[HOLD > 0 ? HOLD : 1][NB][8];
@@ -503,13 +366,12 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? 4 
                 for (int kb = 0; kb < 8; ++kb) {
 #pragma unroll
                     for (int q = 0; q < NS; ++q)
-                        if (!(P2S_F16_ABL & 2) || kb == 0) b[q] = bufld(rs3, lane16, q * pb + soff + kb * 1024);
+                        b[q] = bufld(rs3, lane16, q * pb + soff + kb * 1024);
 #pragma unroll
                     for (int p = 0; p < NS; ++p)
 #pragma unroll
                         for (int r = 0; r < NB; ++r)
-                            if (!(P2S_F16_ABL & 4) || kb == 0)
-                                a[p][r] = (p < HOLD) ? af[p < HOLD ? p : 0][r][kb] : lds_a(bufB + p * SB, HB, 32 * r, kb, lane);
+                            a[p][r] = (p < HOLD) ? af[p < HOLD ? p : 0][r][kb] : lds_a(bufB + p * SB, HB, 32 * r, kb, lane);
 #pragma unroll
                     for (int r = 0; r < NB; ++r)
 #pragma unroll
@@ -602,11 +464,11 @@ __global__ void p2s_pack_bf16_kernel(const float *__restrict__ src, unsigned sho
 
 }  // namespace
 
-template <int NS, bool F16, bool PIPE, bool SUM>
+template <int NS, bool F16, bool SUM>
 static void launch_bf16(const ChainArgs &args, int n, size_t lds, hipStream_t stream) {
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)p2s_chain_bf16_kernel<NS, F16, PIPE, SUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((p2s_chain_bf16_kernel<NS, F16, PIPE, SUM>), dim3(n), dim3(256), lds, stream, args);
+        (void)hipFuncSetAttribute((const void *)p2s_chain_bf16_kernel<NS, F16, SUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((p2s_chain_bf16_kernel<NS, F16, SUM>), dim3(n), dim3(256), lds, stream, args);
 }
 
 int p2s_launch_chain_bf16(const ChainArgs &args, hipStream_t stream) {
@@ -621,20 +483,17 @@ int p2s_launch_chain_bf16(const ChainArgs &args, hipStream_t stream) {
             p2s_set_error("p2s_launch_chain_bf16: the fp16 pair mode has 2 pieces, not %d", ns);
             return P2S_EINVAL;
         }
-        // P2S_F16_PIPE=1: the software-pipelined conv3 schedule (development / A-B; measured equal to the default one)
-        static const bool pipe = getenv("P2S_F16_PIPE") && atoi(getenv("P2S_F16_PIPE")) != 0;
-        if (sum) launch_bf16<2, true, false, true>(args, n, lds, stream);
-        else if (pipe) launch_bf16<2, true, MT == 64, false>(args, n, lds, stream);      // (written for 64-point tiles)
-        else launch_bf16<2, true, false, false>(args, n, lds, stream);
+        if (sum) launch_bf16<2, true, true>(args, n, lds, stream);
+        else launch_bf16<2, true, false>(args, n, lds, stream);
     } else if (ns == 1) {
-        if (sum) launch_bf16<1, false, false, true>(args, n, lds, stream);
-        else launch_bf16<1, false, false, false>(args, n, lds, stream);
+        if (sum) launch_bf16<1, false, true>(args, n, lds, stream);
+        else launch_bf16<1, false, false>(args, n, lds, stream);
     } else if (ns == 2) {
-        if (sum) launch_bf16<2, false, false, true>(args, n, lds, stream);
-        else launch_bf16<2, false, false, false>(args, n, lds, stream);
+        if (sum) launch_bf16<2, false, true>(args, n, lds, stream);
+        else launch_bf16<2, false, false>(args, n, lds, stream);
     } else if (ns == 3) {
-        if (sum) launch_bf16<3, false, false, true>(args, n, lds, stream);
-        else launch_bf16<3, false, false, false>(args, n, lds, stream);
+        if (sum) launch_bf16<3, false, true>(args, n, lds, stream);
+        else launch_bf16<3, false, false>(args, n, lds, stream);
     } else {
         p2s_set_error("p2s_launch_chain_bf16: %d pieces unsupported", ns);
         return P2S_EINVAL;

@@ -1092,14 +1092,28 @@ int p2s_cloud_create(const float *pts_dev, int n, int device, void *stream, p2s_
     return P2S_OK;
 }
 
+// Drain the streams a handle has noted.  Only the complaint about a caller's stream that no longer exists is dropped; a
+// genuine asynchronous fault (of this or of unrelated work) is recorded and stays pending for the next launch check.
+static void drain_noted_streams(p2s_cloud_s *c, const char *who) {
+    hipError_t fault = hipSuccess;
+    bool stale = false;
+    auto look = [&](hipError_t e) {
+        if (e == hipSuccess) return;
+        if (e == hipErrorInvalidHandle || e == hipErrorInvalidResourceHandle || e == hipErrorContextIsDestroyed) stale = true;
+        else fault = e;
+    };
+    if (c->many_streams) look(hipDeviceSynchronize());
+    else
+        for (int i = 0; i < c->n_streams; ++i) look(hipStreamSynchronize(c->streams[i]));
+    if (fault != hipSuccess) p2s_set_error("%s: asynchronous HIP error while draining the handle's streams: %s", who, hipGetErrorString(fault));
+    else if (stale) (void)hipGetLastError();
+}
+
 int p2s_cloud_destroy(p2s_cloud_t c) {
     if (!c) return P2S_OK;
     (void)hipSetDevice(c->device);
     // the blocks go back to the cache: nothing may still be reading them
-    if (c->many_streams) (void)hipDeviceSynchronize();
-    else
-        for (int i = 0; i < c->n_streams; ++i) (void)hipStreamSynchronize(c->streams[i]);
-    (void)hipGetLastError();        // a caller's stream that no longer exists: ignored, and not left for the next launch check
+    drain_noted_streams(c, "p2s_cloud_destroy");
     if (c->grid_ev) (void)hipEventDestroy(c->grid_ev);
     p2s_pool_free(c->device, c->arena);
     p2s_pool_free(c->device, c->occ);
@@ -1185,12 +1199,7 @@ int p2s_cloud_grid(p2s_cloud_s *c, int res, int eps, const float **q_out, long l
     p2s_cloud_note_stream(c, s);
     // scratch from the device's block cache (p2s_pool_alloc): no hipMalloc on the per-shape path once it is warm.
     // Replaced blocks may still be read by work queued on the handle's streams: drain them first (rare path)
-    auto drain = [&]() {
-        if (c->many_streams) (void)hipDeviceSynchronize();
-        else
-            for (int i = 0; i < c->n_streams; ++i) (void)hipStreamSynchronize(c->streams[i]);
-        (void)hipGetLastError();
-    };
+    auto drain = [&]() { drain_noted_streams(c, "p2s_query_grid"); };
     if (words > c->occ_words) {
         if (c->occ) {
             drain();
@@ -1310,13 +1319,8 @@ int p2s_knn_patch_set(p2s_cloud_t c, const float *query_dev, int64_t nq, int k, 
     P2S_HIP_CHECK(hipSetDevice(c->device));
     p2s_cloud_note_stream(c, stream);
     const unsigned grid = (unsigned)std::min<int64_t>(nq, 256 * 64);
-    static const bool sorted = getenv("P2S_KNN_SORTED") != nullptr;          // development: A/B against the sorting kernel
-    if (sorted)
-        hipLaunchKernelGGL(p2s_knn_kernel<true>, dim3(grid), dim3(64), 0, stream, c->d, query_dev, (long long)nq, k,
-                           (int *)nullptr, patch_ps_out_dev, radius_out_dev);
-    else
-        hipLaunchKernelGGL(p2s_knn_kernel<false>, dim3(grid), dim3(64), 0, stream, c->d, query_dev, (long long)nq, k,
-                           (int *)nullptr, patch_ps_out_dev, radius_out_dev);
+    hipLaunchKernelGGL(p2s_knn_kernel<false>, dim3(grid), dim3(64), 0, stream, c->d, query_dev, (long long)nq, k,
+                       (int *)nullptr, patch_ps_out_dev, radius_out_dev);
     P2S_LAUNCH_CHECK("p2s_knn_kernel");
     return P2S_OK;
 }
@@ -1366,7 +1370,7 @@ int p2s_rng_serial_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long 
     // The recurrence is serial (one workgroup) and pure latency: co-resident MFMA-saturated encoder
     // workgroups slow it ~3x.  Requesting most of a CU's LDS keeps any 50 KB encoder workgroup off its CU
     // (the workgroup is placed when CUs drain at an encoder-kernel boundary); cost: 1 of 256 CUs.
-    static const int hog = getenv("P2S_RNG_LDS_HOG") ? atoi(getenv("P2S_RNG_LDS_HOG")) : 120 * 1024;
+    constexpr int hog = 120 * 1024;
     {   // per device (a process may drive several); the call is cheap
         (void)hipFuncSetAttribute((const void *)p2s_mt_randint_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     }
@@ -1557,19 +1561,17 @@ int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t nq, int n, int32_t
         uint32_t mask = rng;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
         // large requests: parallel generation over 2^levels jump-ahead streams; small ones: the serial kernel
-        static const long long par_min = getenv("P2S_RNG_PARALLEL_MIN") ? atoll(getenv("P2S_RNG_PARALLEL_MIN")) : 400000;
+        constexpr long long par_min = 400000;
         // large requests: values come from a session (2^levels_max jump-ahead streams generated once, many calls
         // take consecutive ranges); small ones outside a matching session: the serial kernel
-        static const bool use_session = !getenv("P2S_RNG_NO_SESSION");
         const bool in_session = r->sess_mode == 1 && r->sess_rng == rng && r->sess_mask == mask;
         int rc;
-        if (r->levels_max > 0 && use_session && (in_session || target >= par_min)) {
+        if (r->levels_max > 0 && (in_session || target >= par_min)) {
             rc = p2s_rng_session_randint(r, rng, mask, target, ids_out_dev, s);
         } else {
             rc = p2s_rng_session_close(r, s);
             if (rc) return rc;
-            if (r->levels > 0 && target >= par_min) rc = p2s_rng_parallel_randint(r, rng, mask, target, ids_out_dev, s);
-            else rc = p2s_rng_serial_randint(r, rng, mask, target, ids_out_dev, s);
+            rc = p2s_rng_serial_randint(r, rng, mask, target, ids_out_dev, s);
         }
         if (rc) return rc;
     }

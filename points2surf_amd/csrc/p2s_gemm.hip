@@ -324,8 +324,7 @@ int p2s_launch_gemm(const GemmArgs &g, hipStream_t stream) {
     }
     // 64-row workgroups when they fill the 1024 workgroup slots of the chip at least twice, else 32-row ones
     const long long wg64 = (long long)((g.M + 63) / 64) * (g.N / 128) * g.Z;
-    static const int force_rt = getenv("P2S_GEMM_RT") ? atoi(getenv("P2S_GEMM_RT")) : 0;     // development: 1 / 2
-    const bool rt2 = force_rt ? force_rt == 2 : wg64 >= 2048;
+    const bool rt2 = wg64 >= 2048;
     if (g.Wh[0]) {                   // fp16 pair operands
         if (rt2) hipLaunchKernelGGL(p2s_gemm_f16_kernel<2>, dim3((g.M + 63) / 64, g.N / 128, g.Z), dim3(256), 0, stream, g);
         else hipLaunchKernelGGL(p2s_gemm_f16_kernel<1>, dim3((g.M + 31) / 32, g.N / 128, g.Z), dim3(256), 0, stream, g);

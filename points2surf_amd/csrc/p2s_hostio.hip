@@ -5,6 +5,7 @@
 // (fp16-pair encoder) the reference's formatting -- 0.3-0.8 s of savetxt, seconds of str() per vertex -- would be the
 // bottleneck of points_to_surf_eval.  Byte-identical to what numpy / Python write (tests/test_hostio.py).
 #include <charconv>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -19,9 +20,21 @@ namespace {
 struct File {
     FILE *f = nullptr;
     explicit File(const char *path) { f = path ? fopen(path, "wb") : nullptr; }
-    ~File() { if (f) fclose(f); }
+    ~File() { if (f) fclose(f); }                     // error paths only: a successful writer has called close()
     bool put(const std::string &s) { return fwrite(s.data(), 1, s.size(), f) == s.size(); }
+    // flush + close with their results checked: a full disk / quota / NFS error often surfaces only here
+    bool close() {
+        if (!f) return false;
+        const bool ok = fflush(f) == 0 && !ferror(f);
+        const bool closed = fclose(f) == 0;
+        f = nullptr;
+        return ok && closed;
+    }
 };
+int io_fail(const char *who, const char *what, const char *path) {
+    p2s_set_error("%s: %s %s: %s", who, what, path, strerror(errno));
+    return P2S_EIO;
+}
 
 // shortest round-trip digits of a finite, non-zero |x| -> (digits, decimal exponent of the first digit)
 template <typename T>
@@ -92,8 +105,7 @@ int p2s_write_txt_f32(const char *path, const float *values_host, int64_t n) {
     }
     File fh(path);
     if (!fh.f) {
-        p2s_set_error("p2s_write_txt_f32: cannot open %s", path);
-        return P2S_EINVAL;
+        return io_fail("p2s_write_txt_f32", "cannot open", path);
     }
     std::string out;
     out.reserve(1 << 20);
@@ -105,11 +117,12 @@ int p2s_write_txt_f32(const char *path, const float *values_host, int64_t n) {
         else len = snprintf(buf, sizeof(buf), "%.18e\n", v);
         out.append(buf, (size_t)len);
         if (out.size() > (1 << 20) - 64) {
-            if (!fh.put(out)) { p2s_set_error("p2s_write_txt_f32: write failed"); return P2S_EINVAL; }
+            if (!fh.put(out)) return io_fail("p2s_write_txt_f32", "write to", path);
             out.clear();
         }
     }
-    if (!fh.put(out)) { p2s_set_error("p2s_write_txt_f32: write failed"); return P2S_EINVAL; }
+    if (!fh.put(out)) return io_fail("p2s_write_txt_f32", "write to", path);
+    if (!fh.close()) return io_fail("p2s_write_txt_f32", "flush / close of", path);
     return P2S_OK;
 }
 
@@ -122,8 +135,7 @@ int p2s_write_query_vis_ply(const char *path, const float *query_host, const flo
     }
     File fh(path);
     if (!fh.f) {
-        p2s_set_error("p2s_write_query_vis_ply: cannot open %s", path);
-        return P2S_EINVAL;
+        return io_fail("p2s_write_query_vis_ply", "cannot open", path);
     }
     char head[512];
     const int hl = snprintf(head, sizeof(head),
@@ -131,7 +143,7 @@ int p2s_write_query_vis_ply(const char *path, const float *query_host, const flo
                             "property float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\n"
                             "property uchar blue\nproperty uchar alpha\nelement face 0\nproperty list uchar int vertex_indices\n"
                             "end_header\n", (long long)n);
-    if (fwrite(head, 1, (size_t)hl, fh.f) != (size_t)hl) return P2S_EINVAL;
+    if (fwrite(head, 1, (size_t)hl, fh.f) != (size_t)hl) return io_fail("p2s_write_query_vis_ply", "write to", path);
     float dmax = -INFINITY;                    // np.abs(d).max(): NaN propagates
     bool has_nan = false;
     for (int64_t i = 0; i < n; ++i) {
@@ -151,10 +163,8 @@ int p2s_write_query_vis_ply(const char *path, const float *query_host, const flo
         r[14] = 0;
         r[15] = 255;
     }
-    if (n > 0 && fwrite(rec.data(), 16, (size_t)n, fh.f) != (size_t)n) {
-        p2s_set_error("p2s_write_query_vis_ply: write failed");
-        return P2S_EINVAL;
-    }
+    if (n > 0 && fwrite(rec.data(), 16, (size_t)n, fh.f) != (size_t)n) return io_fail("p2s_write_query_vis_ply", "write to", path);
+    if (!fh.close()) return io_fail("p2s_write_query_vis_ply", "flush / close of", path);
     return P2S_OK;
 }
 
@@ -169,8 +179,7 @@ int p2s_write_coff_samples(const char *path, const float *query_host, const floa
     if (n == 0) return P2S_OK;                 // write_off returns before opening the file
     File fh(path);
     if (!fh.f) {
-        p2s_set_error("p2s_write_coff_samples: cannot open %s", path);
-        return P2S_EINVAL;
+        return io_fail("p2s_write_coff_samples", "cannot open", path);
     }
     float dmax = -INFINITY;
     bool has_nan = false;
@@ -197,11 +206,12 @@ int p2s_write_coff_samples(const char *path, const float *query_host, const floa
         }
         out += '\n';
         if (out.size() > (1 << 20) - 256) {
-            if (!fh.put(out)) { p2s_set_error("p2s_write_coff_samples: write failed"); return P2S_EINVAL; }
+            if (!fh.put(out)) return io_fail("p2s_write_coff_samples", "write to", path);
             out.clear();
         }
     }
-    if (!fh.put(out)) { p2s_set_error("p2s_write_coff_samples: write failed"); return P2S_EINVAL; }
+    if (!fh.put(out)) return io_fail("p2s_write_coff_samples", "write to", path);
+    if (!fh.close()) return io_fail("p2s_write_coff_samples", "flush / close of", path);
     return P2S_OK;
 }
 

@@ -13,8 +13,7 @@ struct PipeBuffers {
     float *qrot[2] = {};            // [C][3]   rotated query points (GT-query pass)
     double *rot[2] = {};            // [C][9]   per-query rotation (GT-query pass)
     hipEvent_t ready[2] = {};       // data path of the buffer finished (aux stream)
-    hipEvent_t freed[2] = {};       // the gather has read the sub-sample ids of the buffer (prep stream)
-    hipEvent_t prepped[2] = {};     // kNN patch + gathered sub-sample of the buffer are complete (prep stream)
+    hipEvent_t freed[2] = {};       // the gather has read the sub-sample ids of the buffer (compute stream)
     hipEvent_t done[2] = {};        // encoders finished reading the buffer (main stream)
     hipEvent_t ball_ready[2] = {};  // fixed-radius patch of the buffer finished (ball stream)
     hipEvent_t grid = nullptr;
@@ -50,7 +49,6 @@ struct p2s_model_s {
     p2s_counters counters = {};
     // auxiliary stream: the data path (kNN, sub-sample) of chunk i+1, i+2 overlaps the encoders of chunk i
     hipStream_t aux = nullptr;     // high-priority stream of the sub-sample generator
-    hipStream_t prep = nullptr;    // high-priority stream of kNN + gather of chunk i+1 (runs under the encoders of chunk i)
     hipStream_t ball = nullptr;    // fixed-radius models: the serial walk along the first generator's stream (one wave) -- its own
                                    // stream so that it runs beside the sub-sample kernels of the auxiliary stream, not behind them
     bool overlap = true;
@@ -134,7 +132,6 @@ struct p2s_rng_s {
     int device = 0;
     uint32_t *state = nullptr;     // [624] mt + [1] pos
     // parallel generation (GF(2) jump-ahead), optional: tables uploaded by p2s_rng_set_jump_tables
-    int levels = 0;                // streams of a one-shot request = 2^levels
     int levels_max = 0;            // jump tables uploaded (sessions use 2^levels_max streams)
     int levels_alloc = 0;          // tmp / blk_cum sized for 2^levels_alloc streams
     int blocks_per_stream = 0;
@@ -151,15 +148,12 @@ struct p2s_rng_s {
     int *blk_cum = nullptr;        // [S][B] cumulative accepted count per block
     long long *meta = nullptr;     // [S] offsets + locate record + sticky error flag + raw-request record
     // weighted sub-sample workspace (p2s_wchoice.hip), grown on demand
-    double *wc_S[2] = {};          // [C][n]   exact prefix sums of the probabilities (second set: stream skipping overlaps
-    void *wc_T[2] = {};            // [C][K]   guide records of the cdf (16 B each)      the tables of the next batch)
-    double *wc_sc[2] = {};         // [C]      per-query scalars (stot, word offset, pmax, dmax + sum, mu)
-    void *wc_spec = nullptr;       // speculation block: ctl, klo [SP_B], rtab [SP_B][SP_W]
+    double *wc_S = nullptr;        // [C][n]   exact prefix sums of the probabilities
+    void *wc_T = nullptr;          // [C][K]   guide records of the cdf (16 B each)
+    double *wc_sc = nullptr;       // [C]      per-query scalars (stot, word offset, pmax, dmax + sum, mu)
+    void *wc_spec = nullptr;       // offsets pass: ctl, window origins, verdicts [SP_B][SP_W], tentative path, saved windows, scratch
     unsigned short *wc_J = nullptr; // [2 SP_B][SP_W] ruler of jump tables of the offsets chain (p2s_wchoice.hip)
     size_t wc_cap_q = 0, wc_cap_n = 0, wc_cap_k = 0;
-    int wc_bufs = 0;
-    hipStream_t wc_stream2 = nullptr;      // tables of batch b + 1 while the offsets pass of batch b runs (stream skipping)
-    hipEvent_t wc_ev_tab[2] = {}, wc_ev_use[2] = {}, wc_ev_in = nullptr;
     // fixed-radius patches (p2s_ball.hip): hit counts of a shape's queries (device + pinned host), batch work space
     int32_t *ball_counts_dev = nullptr, *ball_counts_host = nullptr;
     size_t ball_counts_cap = 0;
@@ -180,7 +174,6 @@ int p2s_cloud_grid(p2s_cloud_s *c, int res, int eps, const float **q, long long 
 
 // serial generator (p2s_cloud.hip) and parallel generator (p2s_rng.hip)
 int p2s_rng_serial_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s);
-int p2s_rng_parallel_randint(p2s_rng_s *r, uint32_t rng, uint32_t mask, long long target, int32_t *out, hipStream_t s);
 // sessions: one large generated segment of the stream that many calls draw from (p2s_rng.hip)
 long long p2s_rng_session_words(const p2s_rng_s *r);           // raw words a session holds
 long long *p2s_rng_raw_meta(p2s_rng_s *r);                     // device: [0] word cursor of the raw session, [1] sticky error

@@ -30,7 +30,6 @@ void p2s_pipe_free(p2s_model_s *m) {
         if (b.rot[i]) (void)hipFree(b.rot[i]);
         if (b.ready[i]) (void)hipEventDestroy(b.ready[i]);
         if (b.freed[i]) (void)hipEventDestroy(b.freed[i]);
-        if (b.prepped[i]) (void)hipEventDestroy(b.prepped[i]);
         if (b.done[i]) (void)hipEventDestroy(b.done[i]);
         if (b.ball_ready[i]) (void)hipEventDestroy(b.ball_ready[i]);
     }
@@ -56,7 +55,6 @@ int pipe_reserve(p2s_model_s *m, int C, int k, int n, bool small) {
                          hipMalloc(&b.perm[i], (size_t)C * n * 4) == hipSuccess)) &&
              hipEventCreateWithFlags(&b.ready[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&b.freed[i], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&b.prepped[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&b.done[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&b.ball_ready[i], hipEventDisableTiming) == hipSuccess;
     }
@@ -215,38 +213,23 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
     // batches of 4096 queries (two batches per chunk of 8192 measured 6 % SLOWER: 102.7 vs 109.8 k queries/s)
     // r04: with a 16-bit encoder the weighted models run best with 2048 (fp16 pair, test shape at 256^3: 1024 / 2048 / 3072 /
     // 4096 / 8192 queries: 231.8 / 236.9 / 235.4 / 233.8 / 208.9 k queries/s; fp32: 2048 / 4096: 109.7 / 110.4 k)
-    if (chunk <= 0)
-        chunk = (weighted && !getenv("P2S_MAX_CHUNK")) ? std::min(m->max_chunk, m->cfg.encoder_bf16 ? 2048 : 4096) : m->max_chunk;
+    if (chunk <= 0) chunk = weighted ? std::min(m->max_chunk, m->cfg.encoder_bf16 ? 2048 : 4096) : m->max_chunk;
     chunk = std::min(chunk, m->max_chunk);
-    if (getenv("P2S_NO_OVERLAP")) m->overlap = false;   // development knob: single-stream pipeline
     if (m->overlap && !m->aux) {
         // high queue priority: the data-path kernels are tiny next to the encoder kernel and must not queue
         // behind its ~8k workgroups for a free CU slot.  (Giving the stream its own CUs with a CU mask was
         // measured slower: the masked compute stream lost far more than the masked-off CUs.)
         int lo = 0, hi = 0;
         P2S_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        // development knob P2S_AUX_PRIO=normal: the auxiliary stream without the priority (A/B of the scheduling)
-        const char *pr = getenv("P2S_AUX_PRIO");
-        P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, (pr && !strcmp(pr, "normal")) ? lo : hi));
+        P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, hi));
     }
     hipStream_t sa = m->overlap ? m->aux : s;
-    // OPT-IN (P2S_PREP_STREAM=1): kNN + gather of chunk i+1 on a third stream, under the encoders of chunk i.  Measured
-    // (r03, 3 clouds at 256^3): 177.6 k vs 177.3 k queries/s -- the 149 ms of kNN per 1.38 M queries move INTO the
-    // encoder launches one for one (ms_chain_stn 3702 -> 3849): a single-wave, LDS-latency-bound kNN workgroup that takes
-    // a workgroup slot of an MFMA-saturated CU costs that CU the same time it would have cost alone.  Off by default so
-    // that the encoder launch durations (roofline) are those of the kernel alone.  The small-cloud path and the
-    // GT-query pass stay in program order on the main stream either way.
-    const bool prep_overlap = m->overlap && getenv("P2S_PREP_STREAM") && c->d.n >= n && !r_rot;
-    if (prep_overlap && !m->prep) {
-        int lo = 0, hi = 0;
-        P2S_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        P2S_HIP_CHECK(hipStreamCreateWithPriority(&m->prep, hipStreamNonBlocking, hi));
-    }
-    hipStream_t sp = prep_overlap ? m->prep : s;
+    // (kNN + gather of chunk i run on the compute stream, in front of its encoders: on a third stream under the encoders of
+    //  chunk i - 1 they were measured to cost the encoder launches exactly what they cost alone -- r03: 177.6 vs 177.3 k
+    //  queries/s -- so the simpler order stays and the encoder launch durations (roofline) are those of the kernel alone)
     // fixed radius: the walk along the first generator's stream is ONE wave for tens of ms per chunk; on the auxiliary
     // stream it would sit in front of (or behind) the sub-sample's all-CU kernels, on its own stream it runs beside them
-    // (P2S_BALL_STREAM=0: development / A-B, everything on the auxiliary stream)
-    const bool ball_own = m->cfg.patch_radius > 0.0 && m->overlap && !(getenv("P2S_BALL_STREAM") && atoi(getenv("P2S_BALL_STREAM")) == 0);
+    const bool ball_own = m->cfg.patch_radius > 0.0 && m->overlap;
     if (ball_own && !m->ball) {
         int lo = 0, hi = 0;
         P2S_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -263,11 +246,9 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         p2s_model_s *m;
         bool drained = false;
         ~QuietGuard() {
-            if (!drained) {
+            if (!drained) {        // (the model's own streams: an error here is a real fault and stays pending)
                 if (m->aux) (void)hipStreamSynchronize(m->aux);
-                if (m->prep) (void)hipStreamSynchronize(m->prep);
                 if (m->ball) (void)hipStreamSynchronize(m->ball);
-                (void)hipGetLastError();
             }
             --c->foreign_streams_quiet;
         }
@@ -294,8 +275,7 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         quiet.drained = true;
         const hipError_t e1 = hipStreamSynchronize(s);
         hipError_t e2 = (sa != s) ? hipStreamSynchronize(sa) : hipSuccess;
-        hipError_t e3 = (sp != s) ? hipStreamSynchronize(sp) : hipSuccess;
-        if (e3 == hipSuccess && m->ball) e3 = hipStreamSynchronize(m->ball);
+        const hipError_t e3 = m->ball ? hipStreamSynchronize(m->ball) : hipSuccess;
         if (e2 == hipSuccess) e2 = e3;
         if (code == P2S_OK && (e1 != hipSuccess || e2 != hipSuccess)) {
             p2s_set_error("p2s pipeline: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
@@ -312,10 +292,9 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         }                                                                                                  \
     } while (0)
     hipStream_t sbl = ball_own ? m->ball : sa;        // stream of the fixed-radius patch work
-    if (sa != s || sp != s) {
+    if (sa != s) {
         PIPE_HIP(hipEventRecord(b.grid, s));
-        if (sa != s) PIPE_HIP(hipStreamWaitEvent(sa, b.grid, 0));
-        if (sp != s) PIPE_HIP(hipStreamWaitEvent(sp, b.grid, 0));
+        PIPE_HIP(hipStreamWaitEvent(sa, b.grid, 0));
         if (sbl != sa) PIPE_HIP(hipStreamWaitEvent(sbl, b.grid, 0));
     }
 
@@ -328,7 +307,7 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         if ((rc = p2s_ball_counts_to_host(r_patch, c, q_all + (size_t)q_begin * 3, nq, ball_r, &ball_cd, &ball_ch, s))) return fail(rc);
         p2s_prof_span(m, ST_KNN, eb0, p2s_prof_mark(m, s));
     }
-    const bool use_done = sp != s || (ball && sbl != s);
+    const bool use_done = ball && sbl != s;
 
     const int64_t nchunks = (nq + C - 1) / C;
     auto produce = [&](int64_t ci) -> int {       // sub-sample ids of chunk ci on the aux stream
@@ -362,42 +341,36 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         return P2S_OK;
     };
 
-    // kNN patch + radius and the gathered sub-sample of chunk ci into buffer ci % nbuf (stream sp)
+    // kNN patch + radius and the gathered sub-sample of chunk ci into buffer ci % nbuf (compute stream)
     auto prepare = [&](int64_t ci) -> int {
         const int bi = (int)(ci % nbuf);
         const int64_t q0 = q_begin + ci * C;
         const int cur = (int)std::min<int64_t>(C, q_end - q0);
         const float *qc = q_all + (size_t)q0 * 3;
-        // the encoders of chunk ci - nbuf read this buffer
-        if (sp != s && ci >= nbuf) PIPE_HIP(hipStreamWaitEvent(sp, b.done[bi], 0));
-        const int ek0 = p2s_prof_mark(m, sp);
+        const int ek0 = p2s_prof_mark(m, s);
         int rc2 = P2S_OK;
         if (!ball) {
-            rc2 = small ? p2s_knn_patch(c, qc, cur, k, b.knn_ids[bi], nullptr, nullptr, sp)
-                        : p2s_knn_patch_set(c, qc, cur, k, b.patch[bi], b.radius[bi], sp);
+            rc2 = small ? p2s_knn_patch(c, qc, cur, k, b.knn_ids[bi], nullptr, nullptr, s)
+                        : p2s_knn_patch_set(c, qc, cur, k, b.patch[bi], b.radius[bi], s);
             if (rc2) return fail(rc2);
-            p2s_prof_span(m, ST_KNN, ek0, p2s_prof_mark(m, sp));
+            p2s_prof_span(m, ST_KNN, ek0, p2s_prof_mark(m, s));
         }
-        if (sa != sp) PIPE_HIP(hipStreamWaitEvent(sp, b.ready[bi], 0));
-        if (ball && sbl != sp) PIPE_HIP(hipStreamWaitEvent(sp, b.ball_ready[bi], 0));
+        if (sa != s) PIPE_HIP(hipStreamWaitEvent(s, b.ready[bi], 0));
+        if (ball && sbl != s) PIPE_HIP(hipStreamWaitEvent(s, b.ball_ready[bi], 0));
         if (small) {       // the patch is gathered from the array as the queries before this one left it
-            rc2 = p2s_patch_from_ids(c, b.knn_ids[bi], b.perm[bi], qc, cur, k, b.patch[bi], b.radius[bi], sp);
+            rc2 = p2s_patch_from_ids(c, b.knn_ids[bi], b.perm[bi], qc, cur, k, b.patch[bi], b.radius[bi], s);
             if (rc2) return fail(rc2);
         }
-        rc2 = p2s_gather_points(c, b.sub_ids[bi], (int64_t)cur * n, b.sub[bi], sp);
+        rc2 = p2s_gather_points(c, b.sub_ids[bi], (int64_t)cur * n, b.sub[bi], s);
         if (rc2) return fail(rc2);
         // the producer only writes sub_ids: free for chunk ci + nbuf as soon as the gather has read them
-        if (sa != sp) PIPE_HIP(hipEventRecord(b.freed[bi], sp));
-        if (sp != s) PIPE_HIP(hipEventRecord(b.prepped[bi], sp));
+        if (sa != s) PIPE_HIP(hipEventRecord(b.freed[bi], s));
         return P2S_OK;
     };
 
     // prologue: up to nbuf chunks of ids in flight
     for (int64_t ci = 0; ci < std::min<int64_t>(nbuf, nchunks); ++ci)
         if ((rc = produce(ci))) return rc;
-    if (sp != s)
-        for (int64_t ci = 0; ci < std::min<int64_t>(nbuf, nchunks); ++ci)
-            if ((rc = prepare(ci))) return rc;
     for (int64_t ci = 0; ci < nchunks; ++ci) {
         const int bi = (int)(ci % nbuf);
         const int64_t q0 = q_begin + ci * C;
@@ -408,8 +381,7 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
             p2s_set_error("p2s pipeline: injected fault before chunk %lld (p2s_debug_fault_chunk)", (long long)ci);
             return fail(P2S_EHIP);
         }
-        if (sp != s) PIPE_HIP(hipStreamWaitEvent(s, b.prepped[bi], 0));
-        else if ((rc = prepare(ci))) return rc;
+        if ((rc = prepare(ci))) return rc;
         if (r_rot) {
             // data_loader.py:381-393: rotate sub-sample (model space), patch (patch space) and the query point
             if (!ball && (rc = p2s_random_rotations(r_rot, cur, b.rot[bi], s))) return fail(rc);
@@ -424,7 +396,6 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
         if (use_done) PIPE_HIP(hipEventRecord(b.done[bi], s));
         if (ci + nbuf < nchunks) {
             if ((rc = produce(ci + nbuf))) return rc;
-            if (sp != s && (rc = prepare(ci + nbuf))) return rc;
         }
     }
 #undef PIPE_HIP

@@ -666,7 +666,7 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
         hipLaunchKernelGGL(vol_state_init_kernel, dim3((grid + 3) / 4), dim3(256), 0, s, vol_out_dev, nvox, buf0, vs);
         const int n_tiles = ((grid_res + VT_Z - 1) / VT_Z) * ((grid_res + VT_Y - 1) / VT_Y) * ((grid_res + VT_X - 1) / VT_X);
         // persistent workgroups: 4 fit a CU (LDS) -> 1024 fill the chip; fewer tiles than that: one workgroup per tile
-        const int wgs_max = getenv("P2S_VOLUME_WGS") ? std::max(8, atoi(getenv("P2S_VOLUME_WGS")) & ~7) : 1024;
+        constexpr int wgs_max = 1024;
         const int slab_tiles = (n_tiles + 7) / 8;
         if ((slab_tiles + wgs_max / 8 - 1) / (wgs_max / 8) > 256) {
             p2s_set_error("p2s_sdf_volume: %d tiles exceed the per-workgroup tile list", n_tiles);
@@ -687,14 +687,15 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
         // and its verdict into a pinned host mailbox; the host keeps only a few launches ahead of it and stops launching
         // when the verdict is there: no copy and no event between the sweeps (a verdict copied out behind batches of 16
         // launches cost six 10-us gaps and ~17 exit-at-once launches of 4.8 us: 9 % of the run at 256^3).
-        const int ahead = getenv("P2S_VOLUME_AHEAD") ? std::max(1, atoi(getenv("P2S_VOLUME_AHEAD"))) : 4;
+        constexpr int ahead = 4;
         // one mailbox per device (allocated with that device current, portable: visible to every context), used
         // under the device's scratch lock
         static VolMail *mail_h_dev[P2S_MAX_DEVICES] = {};
         static VolMail *mail_d_dev[P2S_MAX_DEVICES] = {};
         VolMail *&mail_h = mail_h_dev[device];
         VolMail *&mail_d = mail_d_dev[device];
-        if (!mail_h && !getenv("P2S_VOLUME_NO_MAILBOX")) {
+        const bool use_mail = !getenv("P2S_VOLUME_NO_MAILBOX");     // test hook: the copy-per-batch protocol below
+        if (!mail_h && use_mail) {
             if (hipHostMalloc((void **)&mail_h, sizeof(VolMail), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess ||
                 hipHostGetDevicePointer((void **)&mail_d, mail_h, 0) != hipSuccess) {
                 (void)hipGetLastError();
@@ -722,7 +723,7 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
             return flag == 0;
         };
         bool flag_checked = false;
-        if (mail_h) {
+        if (mail_h && use_mail) {
             volatile VolMail *mv = mail_h;               // (no kernel of this call touches the mailbox before the first sweep)
             mv->progress = 0;
             mv->final_buf = 0;
@@ -752,7 +753,7 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
         if (!host_vs.done) {
             // copy-per-batch protocol (no mapped host memory, or the mailbox stayed silent): the verdict of batch j is
             // copied out behind it and looked at only after batch j + 1 has been queued
-            const int batch = getenv("P2S_VOLUME_BATCH") ? std::max(1, atoi(getenv("P2S_VOLUME_BATCH"))) : 16;
+            constexpr int batch = 16;
             static VolState *pinned_dev[P2S_MAX_DEVICES] = {};
             static hipEvent_t look_dev[P2S_MAX_DEVICES][2] = {};
             VolState *&pinned = pinned_dev[device];
@@ -797,15 +798,6 @@ extern "C" int p2s_sdf_volume(const float *query_dev, const float *sdf_dev, int6
             return cleanup(P2S_EHIP);
         }
         iters = host_vs.iters;
-        if (getenv("P2S_VOLUME_STATS")) {
-            VolState fin;
-            if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(&fin, vs, sizeof(VolState), hipMemcpyDeviceToHost) == hipSuccess) {
-                unsigned long long run = 0;
-                for (int i = 0; i < NSHARD; ++i) run += fin.tiles_run[i];
-                fprintf(stderr, "[volume stats] res %d: %d sweeps, %llu tile evaluations = %.1f %% of %d tiles x sweeps\n", grid_res, iters,
-                        run, 100.0 * (double)run / ((double)n_tiles * std::max(iters, 1)), n_tiles);
-            }
-        }
         hipLaunchKernelGGL(vol_compose_state_kernel, dim3(grid), dim3(256), 0, s, vol_out_dev, buf0, buf1, vs, grid_res, clamp);
         P2S_LAUNCH_CHECK("vol_compose_state_kernel");
         if (iterations) *iterations = iters;

@@ -719,9 +719,6 @@ constexpr int SP_NB = SP_W + WC_MAX_SEL;             // draws whose bin is neede
 constexpr int SP_NX = SP_NB + 2 * SP_LOOK;           // doubles held
 constexpr int SP_HASH = 4096;
 constexpr int SP_DMAX = 1024;                        // draws that share their bin with another draw of the window (more: undecided)
-constexpr int SP_XL = 384;                           // candidates per query whose close pairs are looked up exactly (more stay undecided)
-constexpr int SP_PAIRS = 256;                        // close pairs among the round-2 positions of a window (more: those candidates stay undecided)
-constexpr int SP_TASKS = 768;                        // exact look-ups per query (pairs of neighbouring close round-2 draws of those candidates)
 
 // ---- the walk s -> s + 2 (nsel + R_q(s)) without walking --------------------------------------------------------------
 // In window coordinates (d = (s - klo[q]) / 2, candidate d of query q) one step is
@@ -745,6 +742,10 @@ struct WcSpec {
     long long *ctl;           // [0] first unresolved query, [1] its word offset
     const float *mu;          // [nq] expected first-round collisions
     unsigned short *jump;     // [SP_JUMP_ROWS][SP_W] ruler of jump tables
+    long long *klo1;          // [SP_B] window origin of the NEXT query as this query's workgroup computed it
+    short *dtil;              // [SP_B] window coordinate where the tentative walk passed every query (-1: not reached)
+    int *save;                // [SP_B][SP_SAVE] dup list + first-round bins of every window (spec -> band kernel)
+    unsigned char *scratch;   // wc_lds_bytes(n) bytes: the arrays of the complete algorithm for the chain kernel
 };
 
 // level k from level k - 1, rows i = 0 mod 2^k
@@ -857,18 +858,13 @@ __device__ __forceinline__ void wc_grp_pass(const WcCand &c, int n, int i, int g
 // in the unmodified cdf); -1 = gave up (the caller leaves the candidate undecided).
 // x2 >= x (a close round-2 draw): *same = it falls into the same bin, i.e. fl(V_bin / St_cur) > x2 as well.
 __device__ __forceinline__ int wc_grp_bin(const WcCand &c, const double *__restrict__ Sq, int n, double Stot, double x, double x2,
-                                          int i0, int gl, int gsh, int *same, long long *dbg = nullptr) {
+                                          int i0, int gl, int gsh, int *same) {
     constexpr unsigned GM = (1u << WC_G) - 1u;
     int i = i0 > n - 1 ? n - 1 : (i0 < 0 ? 0 : i0);
     for (int it = 0; it < 12; ++it) {
         double Cle, Ctot;
         int lo, hi;
-        const long long tp0 = dbg ? wall_clock64() : 0;
         wc_grp_pass(c, n, i, gl, Cle, Ctot, lo, hi);
-        if (dbg) {
-            atomicAdd((unsigned long long *)&dbg[16], 1ull);
-            atomicAdd((unsigned long long *)&dbg[18], (unsigned long long)(wall_clock64() - tp0));
-        }
         const double St_cur = Stot - Ctot;
         // the found-free gap (lo, hi) around i: pred(lo) must be false and pred(hi - 1) true for the answer to lie in it;
         // 32 ids of it in the same round trip (id k0 + WC_G j + gl in slot j), centred where the found mass below i says
@@ -885,11 +881,6 @@ __device__ __forceinline__ int wc_grp_bin(const WcCand &c, const double *__restr
         double sk[WC_GS];
 #pragma unroll
         for (int j = 0; j < WC_GS; ++j) sk[j] = (k0 + WC_G * j + gl < hi) ? Sq[k0 + WC_G * j + gl] : 0.0;
-        if (dbg) {
-            const long long tl0 = wall_clock64();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            atomicAdd((unsigned long long *)&dbg[19], (unsigned long long)(wall_clock64() - tl0));
-        }
         if (lo >= 0 && wc_gt(s_lo - Cle, St_cur, x)) {          // V_lo = S_lo - C(lo), C(lo) = Cle: the answer is below lo
             i = lo - 1;
             if (i < 0) return -1;
@@ -903,7 +894,6 @@ __device__ __forceinline__ int wc_grp_bin(const WcCand &c, const double *__restr
         if (hi - lo < 2) return -1;                              // (cannot happen: the predicate changes inside the gap)
         // inside the gap C is constant
         for (int w = 0; w < 96; ++w) {
-            if (dbg) atomicAdd((unsigned long long *)&dbg[17], 1ull);
             int first = -1;
             double sv = 0.0;
 #pragma unroll
@@ -933,16 +923,20 @@ __device__ __forceinline__ int wc_grp_bin(const WcCand &c, const double *__restr
     return -1;
 }
 
+// verdict byte of a candidate (rtab): 0 .. 126 = redraws R, decided; 128 + m2 = TENTATIVE: round 2 draws m2 doubles that hold
+// a close pair -- R = m2 unless such a pair shares a bin (wc_band_kernel decides that for the candidates near the path);
+// 255 = undecided (the chain runs the complete algorithm if the path gets there)
+constexpr unsigned SP_TENT = 128u, SP_UND = 255u;
+constexpr int SP_SAVE = 4 + SP_DMAX + SP_NB;         // ints per query handed from wc_spec_kernel to wc_band_kernel: ndup, dup list, bins
+constexpr int SP_BAND = 96;                          // candidates per query decided exactly: [path - 48, path + 48)
+constexpr int SP_BAND_LO = 48;
+
 __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
     __shared__ double xs[SP_NX];
     __shared__ int bins[SP_NB];
-    __shared__ __attribute__((aligned(16))) uint32_t hkey[SP_HASH];      // later: diff, nd, pw, rt, xl (offsets below)
+    __shared__ __attribute__((aligned(16))) uint32_t hkey[SP_HASH];      // later: diff, nd, rt (offsets below)
     __shared__ int dl[SP_DMAX];                      // draw | bin << 11, later draw | (previous draw of the same bin + 1) << 11
-    __shared__ int task[SP_TASKS];                   // listed candidate t | round-2 draw j << 10 | its neighbour j2 << 16
-    static_assert(SP_XL <= 1024 && SP_LOOK <= 64, "task encoding");
-    __shared__ int cres[SP_XL];                      // listed candidate t: neighbours in the same bin (m3) | gave up << 16
-    __shared__ int xl[SP_XL];                        // listed candidate d | m2 << 16
-    __shared__ int s_ndup, s_nxl, s_ntask, s_npair, wsum[4];
+    __shared__ int s_ndup, wsum[4];
     __shared__ float redf[2][4];
     if (a.meta[1] != 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -951,15 +945,6 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
     const long long q = qb + i;
     if (q >= a.nq) return;
     const int lim = (int)(a.nq - qb < SP_B ? a.nq - qb : SP_B);
-    long long t_ph = a.stats ? wall_clock64() : 0;
-#define SP_T(k)                                                                                   \
-    do {                                                                                          \
-        if (a.stats && tid == 0) {                                                                \
-            const long long t_ = wall_clock64();                                                  \
-            atomicAdd((unsigned long long *)&a.stats[k], (unsigned long long)(t_ - t_ph));        \
-            t_ph = t_;                                                                            \
-        }                                                                                         \
-    } while (0)
     // predicted start: the block start (exact) + the expected redraws of the queries before this one; the same for the
     // next query (its workgroup sums in exactly this order), whose window origin level 0 of the jump tables refers to
     float part = 0.0f, part1 = 0.0f;
@@ -977,7 +962,7 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
         redf[0][wave] = part;
         redf[1][wave] = part1;
     }
-    if (tid == 0) s_ndup = s_nxl = s_ntask = s_npair = 0;
+    if (tid == 0) s_ndup = 0;
     for (int h = tid; h < SP_HASH; h += 256) hkey[h] = 0xffffffffu;
     __syncthreads();
     long long dpre = (long long)((redf[0][0] + redf[0][1]) + (redf[0][2] + redf[0][3]) + 0.5f) - SP_W / 2;
@@ -986,7 +971,10 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
     dpre1 = dpre1 < 0 ? 0 : dpre1;
     const long long klo = sb + 2 * ((long long)i * a.nsel + dpre);
     const long long klo1 = sb + 2 * ((long long)(i + 1) * a.nsel + dpre1);
-    if (tid == 0) sp.klo[i] = klo;
+    if (tid == 0) {
+        sp.klo[i] = klo;
+        sp.klo1[i] = klo1;
+    }
     const int nsel = a.nsel, nb = SP_W + nsel, nx = nb + 2 * SP_LOOK;
     const double *Sq = a.S + (size_t)q * a.n;
     const WcRec *Rq = a.R + (size_t)q * a.K;
@@ -1011,7 +999,6 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
         if (e < nb) bins[e] = bin;
     }
     __syncthreads();
-    SP_T(0);
     // ---- draws that share their bin with another draw of the window: hash bin -> count
     constexpr int PER = (SP_NB + 255) / 256;
     int slot[PER];
@@ -1053,10 +1040,6 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
     // the hash is dead: its 16 KB now hold
     int *diff = (int *)hkey;                                              // [SP_W + 1]              0 .. 4100
     unsigned char *nd = (unsigned char *)hkey + 4112;                     // [SP_W + SP_LOOK]     4112 .. 5200
-    int *pl = (int *)((unsigned char *)hkey + 5200);                      // [SP_PAIRS]           5200 .. 6224
-    float *pw = (float *)((unsigned char *)hkey + 6336);                  // [SP_NB]              6336 .. 14528
-    unsigned char *rt = (unsigned char *)hkey + 14528;                    // [SP_W]              14528 .. 15552
-    static_assert(14528 + SP_W <= SP_HASH * 4 && 6336 + SP_NB * 4 <= 14528 && 5200 + SP_PAIRS * 4 <= 6336, "overlay");
     for (int d = tid; d <= SP_W; d += 256) diff[d] = 0;
     // ---- previous draw of the same bin for every listed draw (registers; written back behind the barrier)
     int pv[SP_DMAX / 256];
@@ -1104,22 +1087,8 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
 #pragma unroll 9
         for (int j = 1; j < SP_LOOK; ++j) cm |= (unsigned long long)(fabs(x - xs[e + j]) <= wmax) << j;
         nd[r] = (unsigned char)(cm ? __builtin_ctzll(cm) : 255);
-        for (; cm; cm &= cm - 1) {                       // the close pairs themselves (rare): what the exact pass works on
-            const int k = atomicAdd(&s_npair, 1);
-            if (k < SP_PAIRS) pl[k] = r | ((r + __builtin_ctzll(cm)) << 16);
-        }
-    }
-    // ---- probability of every draw's bin, re-derived from the L2-resident cloud exactly as the tables kernel did
-    {
-        const float qx = a.q[3 * q], qy = a.q[3 * q + 1], qz = a.q[3 * q + 2];
-        const float dmax = a.dsum[2 * q], sum = a.dsum[2 * q + 1];
-        for (int e = tid; e < nb; e += 256) {
-            const int b = bins[e];
-            pw[e] = b >= 0 ? wc_clip_prob(wc_dist1(a.pts, b, qx, qy, qz), dmax) / sum : 0.0f;
-        }
     }
     __syncthreads();
-    SP_T(1);
     // ---- scan of the difference array (4 candidates per lane) and the verdict per candidate
     const int d0 = 4 * tid;
     int c[4];
@@ -1139,13 +1108,19 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
 #pragma unroll
     for (int w = 0; w < 4; ++w)
         if (w < wave) run += wsum[w];
+    uint32_t packed = 0;
+    ushort4 o;
+    unsigned short *ov = (unsigned short *)&o;
+    const bool lastq = i + 1 >= lim;                         // the step of the block's last query leaves the block: not a jump
+    const int delta = nsel + (int)((klo - klo1) >> 1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int d = d0 + j;
         const int m2 = run + c[j];
-        unsigned r = 255u;
+        unsigned r = SP_UND;
+        int guess = 0;
         const long long s = klo + 2LL * d;
-        // (room for the third round of an exactly resolved candidate: m3 <= m2)
+        // (room for the third round of a candidate that is decided later: m3 <= m2)
         if (!undecidable && s + 2LL * (nsel + 2 * m2) <= a.cap_words) {
             if (m2 == 0) {
                 r = 0u;
@@ -1153,148 +1128,238 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
                 bool bad = false;
                 for (int e = 0; e < m2; ++e) {
                     const int reach = nd[d + e];
-                    bad |= (reach != 255) && (e + reach < m2);
+                    if (reach != 255 && e + reach < m2) {
+                        bad = true;
+                        // a guess with the right mean: the pair shares a bin of the UNMODIFIED cdf (its bins in the modified
+                        // one lie some ten ids away and are as wide on average).  A tentative walk that took every close
+                        // pair for two bins would fall behind the real one by ~5 draws per 100 queries.
+                        const int ea = d + nsel + e, eb = ea + reach;
+                        guess += (eb < nb && bins[ea] == bins[eb]) ? 1 : 0;
+                    }
                 }
-                if (!bad) {
-                    r = (unsigned)m2;
-                } else {
-                    const int k = atomicAdd(&s_nxl, 1);
-                    if (k < SP_XL) xl[k] = d | (m2 << 16);
-                }
+                r = bad ? SP_TENT + (unsigned)m2 : (unsigned)m2;
             }
         }
-        rt[d] = (unsigned char)r;
+        packed |= r << (8 * j);
+        // level 0 of the jump tables (step of candidate d into the window of the next query); a tentative candidate steps by
+        // its guess -- good enough to find out WHERE the path runs (wc_chain_kernel, tentative)
+        const unsigned rs = r == SP_UND ? r : (r & 127u) + (unsigned)guess;
+        const int ndq = d + (int)rs + delta;
+        ov[j] = (lastq || r == SP_UND || ndq < 0 || ndq >= SP_W) ? SP_INV : (unsigned short)ndq;
+    }
+    ((uint32_t *)(sp.rtab + (size_t)i * SP_W))[tid] = packed;
+    *(ushort4 *)(sp.jump + sp_lev_row(0, i) * SP_W + d0) = o;
+    // ---- what wc_band_kernel needs of this window: the dup list and the first-round bins
+    int *sv = sp.save + (size_t)i * SP_SAVE;
+    if (tid == 0) sv[0] = undecidable ? -1 : ndup;
+    for (int t = tid; t < ndup; t += 256) sv[4 + t] = dl[t];
+    for (int e = tid; e < nb; e += 256) sv[4 + SP_DMAX + e] = bins[e];
+}
+
+// The exact pass: the candidates of a query within [path - 48, path + 48) of where the tentative walk went through its
+// window, if tentative, get their close round-2 pairs looked up in their own modified cdf.  The real path stays that close:
+// it leaves the tentative one by one double per pair that does share a bin (~1 % of the queries) and the two re-merge
+// within tens of queries (a start shifted by one draw loses one first-round draw and gains one, and the redraw counts
+// absorb the difference with ~5 % probability per query).  A path that does escape meets a tentative / undecided verdict
+// and the chain resolves that query itself.
+constexpr int BD_NP = SP_BAND + 2 * SP_LOOK;          // round-2 positions a band touches (+ look-ahead)
+constexpr int BD_PAIRS = 128, BD_TASKS = 256;
+__global__ __launch_bounds__(256) void wc_band_kernel(WcArgs a, WcSpec sp) {
+    __shared__ int bins[SP_NB];
+    __shared__ int dl[SP_DMAX];
+    __shared__ float pwb[SP_BAND + WC_MAX_SEL];      // probability of draw e at pwb[e - band_lo]
+    __shared__ double xsb[BD_NP];                    // double of round-2 position r (draw nsel + r) at xsb[r - band_lo]
+    __shared__ __attribute__((aligned(4))) unsigned char rt[SP_W];
+    __shared__ int pl[BD_PAIRS], task[BD_TASKS], xl[SP_BAND], cres[SP_BAND];
+    __shared__ int s_npair, s_ntask, s_nxl;
+    if (a.meta[1] != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long long qb = sp.ctl[0];
+    const int i = blockIdx.x;
+    const long long q = qb + i;
+    if (q >= a.nq) return;
+    const int lim = (int)(a.nq - qb < SP_B ? a.nq - qb : SP_B);
+    const int nsel = a.nsel, nb = SP_W + nsel;
+    const long long klo = sp.klo[i], klo1 = sp.klo1[i];
+    const int dt = sp.dtil[i];                                   // where the tentative walk passed (-1: it did not get here)
+    const int *sv = sp.save + (size_t)i * SP_SAVE;
+    const int ndup = sv[0];
+    ((uint32_t *)rt)[tid] = ((const uint32_t *)(sp.rtab + (size_t)i * SP_W))[tid];
+    if (tid == 0) s_npair = s_ntask = s_nxl = 0;
+    const int blo = dt < 0 ? 0 : (dt - SP_BAND_LO > 0 ? dt - SP_BAND_LO : 0);
+    const int bhi = dt < 0 ? 0 : (blo + SP_BAND < SP_W ? blo + SP_BAND : SP_W);       // candidates [blo, bhi)
+    __syncthreads();
+    // ---- tentative candidates of the band
+    if (tid < bhi - blo && ndup >= 0) {
+        const unsigned r = rt[blo + tid];
+        if (r >= SP_TENT && r != SP_UND) xl[atomicAdd(&s_nxl, 1)] = (blo + tid) | ((int)(r - SP_TENT) << 16);
     }
     __syncthreads();
-    // ---- close pairs among the round-2 draws of a candidate, decided exactly in the candidate's own modified cdf.
-    // Bins are monotone in x: with the close draws of a candidate sorted by value, m3 = the neighbours (next larger close
-    // draw within wmax) that fall into the same bin as their predecessor -- ONE look-up per such pair.
-    // (1) one thread per listed candidate: its pairs -> look-up tasks
-    SP_T(2);
-    const int nxl = s_nxl < SP_XL ? s_nxl : SP_XL;
+    const int nxl = s_nxl;
     if (a.stats && tid == 0) {
-        atomicAdd((unsigned long long *)&a.stats[6], (unsigned long long)s_nxl);
-        atomicAdd((unsigned long long *)&a.stats[8], 1ull);
-        atomicAdd((unsigned long long *)&a.stats[9], (unsigned long long)ndup);
+        atomicAdd((unsigned long long *)&a.stats[0], 1ull);
+        atomicAdd((unsigned long long *)&a.stats[2], (unsigned long long)nxl);
     }
-    const int npair = s_npair < SP_PAIRS ? s_npair : SP_PAIRS;
-    for (int t = tid; t < nxl; t += 256) cres[t] = s_npair > SP_PAIRS ? 0x10000 : 0;       // pair list overflow: undecided
-    __syncthreads();
-    // 8 lanes per listed candidate over the window's close pairs: a pair inside the candidate's round-2 range [d, d + m2) is a
-    // task if its upper draw u2 (larger x; ties: the later draw) is the NEIGHBOUR of the lower one u1 -- no third draw of the
-    // range lies between them (it would be within wmax of both, i.e. be listed with u1)
-    for (int t = tid >> 3; t < nxl; t += 32) {
-        const int d = xl[t] & 0xffff, m2 = xl[t] >> 16;
-        for (int k = tid & 7; k < npair; k += 8) {
-            const int r1 = pl[k] & 0xffff, r2 = pl[k] >> 16;
-            if (r1 < d || r2 >= d + m2) continue;
-            const double xa = xs[nsel + r1], xb = xs[nsel + r2];
-            const bool up = xb > xa || (xb == xa);                   // r2 > r1: a tie counts the later draw as the larger
-            const int u1 = up ? r1 : r2, u2 = up ? r2 : r1;
-            const double x1 = up ? xa : xb, x2 = up ? xb : xa;
-            bool between = false;
-            for (int k2 = 0; k2 < npair; ++k2) {
-                const int q1 = pl[k2] & 0xffff, q2 = pl[k2] >> 16;
-                if (q1 != u1 && q2 != u1) continue;
-                const int z = q1 == u1 ? q2 : q1;
-                if (z == u2 || z < d || z >= d + m2) continue;
-                const double xz = xs[nsel + z];
-                const bool above = xz > x1 || (xz == x1 && z > u1);
-                const bool below = xz < x2 || (xz == x2 && z < u2);
-                between |= above && below;
+    if (nxl > 0) {
+        const double *Sq = a.S + (size_t)q * a.n;
+        const WcRec *Rq = a.R + (size_t)q * a.K;
+        const double Stot = a.stot[q];
+        const double pm = (double)a.pmax[2 * q];
+        const double wmax = (pm / (Stot - (double)nsel * pm)) * (1.0 + 1e-9);          // (dist_ok held: the candidates are tentative)
+        // ---- the window's state: dup list, first-round bins (wc_spec_kernel), the doubles of the band's round-2 positions
+        for (int t = tid; t < ndup; t += 256) dl[t] = sv[4 + t];
+        for (int e = tid; e < nb; e += 256) bins[e] = sv[4 + SP_DMAX + e];
+        const int np = bhi - blo + 2 * SP_LOOK;
+        for (int r = tid; r < np; r += 256) {
+            const long long w = klo + 2LL * (nsel + blo + r);
+            double x = 2.0;
+            if (w + 1 < a.cap_words) {
+                const uint2 wp = *(const uint2 *)(a.words + w);
+                x = wc_double(wp.x, wp.y);
             }
-            if (!between) {
-                const int kk = atomicAdd(&s_ntask, 1);
-                if (kk < SP_TASKS) task[kk] = t | ((u1 - d) << 10) | ((u2 - d) << 16);
-                else atomicOr(&cres[t], 0x10000);               // no room: stays undecided
+            xsb[r] = x;
+        }
+        __syncthreads();
+        // ---- probability of every draw a band candidate's first round holds, re-derived from the L2-resident cloud exactly
+        // as the tables kernel did; the close pairs among the band's round-2 positions
+        {
+            const float qx = a.q[3 * q], qy = a.q[3 * q + 1], qz = a.q[3 * q + 2];
+            const float dmax = a.dsum[2 * q], sum = a.dsum[2 * q + 1];
+            for (int e = blo + tid; e < bhi + nsel; e += 256) {
+                const int b = bins[e];
+                pwb[e - blo] = b >= 0 ? wc_clip_prob(wc_dist1(a.pts, b, qx, qy, qz), dmax) / sum : 0.0f;
             }
         }
-    }
-    __syncthreads();
-    SP_T(3);
-    if (a.stats && tid == 0) atomicAdd((unsigned long long *)&a.stats[7], (unsigned long long)s_ntask);
-    // (2) the look-ups, 64 at a time
-    {
-        const int ntask = s_ntask < SP_TASKS ? s_ntask : SP_TASKS;
-        const int grp = tid / WC_G, gl = tid & (WC_G - 1), gsh = lane & ~(WC_G - 1);
-        WcCand cd;
-        cd.bins = bins;
-        cd.pw = pw;
-        cd.dl = dl;
-        cd.ndup = ndup;
-        cd.nsel = nsel;
-        for (int k = grp; k < ntask; k += 256 / WC_G) {
-            const int t = task[k] & 1023, j = (task[k] >> 10) & 63, j2 = task[k] >> 16;
-            const int d = xl[t] & 0xffff;
-            cd.d = d;
-            const int e = d + nsel + j;
-            // first guess: the bin of x in the unmodified cdf -- known for the draws that are first-round draws of later
-            // candidates (all but the last few of the window), else one guide look-up
-            int i0;
-            if (e < nb) {
-                i0 = bins[e];
-            } else {
-                int bk = (int)(xs[e] * (double)a.K);
-                bk = bk > a.K - 1 ? a.K - 1 : bk;
-                i0 = Rq[bk].i;
-            }
-            int same = 0;
-            if (a.stats && tid == 0) atomicAdd((unsigned long long *)&a.stats[20], 1ull);
-            const int b = wc_grp_bin(cd, Sq, a.n, Stot, xs[e], xs[d + nsel + j2], i0, gl, gsh, &same, (a.stats && tid == 0) ? a.stats : nullptr);
-            if (gl == 0) {
-                if (b < 0) atomicOr(&cres[t], 0x10000);
-                else if (same) atomicAdd(&cres[t], 1);
+        for (int r = tid; r < bhi - blo + SP_LOOK; r += 256) {
+            const double x = xsb[r];
+            for (int j = 1; j < SP_LOOK; ++j) {
+                if (fabs(x - xsb[r + j]) <= wmax) {
+                    const int k = atomicAdd(&s_npair, 1);
+                    if (k < BD_PAIRS) pl[k] = r | ((r + j) << 16);
+                }
             }
         }
-    }
-    __syncthreads();
-    SP_T(4);
-    // (3) one thread per listed candidate: R = m2 + m3 if m3 <= 1 or the m3 draws of round 3, right behind round 2, are
-    // pairwise farther apart than wmax
-    for (int t = tid; t < nxl; t += 256) {
-        const int d = xl[t] & 0xffff, m2 = xl[t] >> 16;
-        const int m3 = cres[t] & 0xffff;
-        unsigned r = 255u;
-        if (!(cres[t] >> 16)) {
-            if (m3 <= 1) {
-                r = (unsigned)(m2 + m3);
-            } else {
-                bool close = false;
-                for (int u = 0; u < m3; ++u)
-                    for (int v2 = 0; v2 < u; ++v2) close |= fabs(xs[d + nsel + m2 + u] - xs[d + nsel + m2 + v2]) <= wmax;
-                if (!close) r = (unsigned)(m2 + m3);
+        for (int t = tid; t < nxl; t += 256) cres[t] = 0;
+        __syncthreads();
+        const int npair = s_npair < BD_PAIRS ? s_npair : BD_PAIRS;
+        if (s_npair > BD_PAIRS)
+            for (int t = tid; t < nxl; t += 256) cres[t] = 0x10000;           // pair list overflow: stays undecided
+        __syncthreads();
+        // ---- 8 lanes per candidate over the close pairs: a pair inside the candidate's round-2 range [d, d + m2) is a task if
+        // its upper draw u2 (larger x; ties: the later draw) is the NEIGHBOUR of the lower one u1 -- no third draw of the range
+        // lies between them (it would be within wmax of both, i.e. be listed with u1).  Bins are monotone in x, so m3 (round-2
+        // draws that hit a bin another one took first) = the neighbour pairs that share a bin: ONE look-up per pair.
+        for (int t = tid >> 3; t < nxl; t += 32) {
+            const int d = (xl[t] & 0xffff) - blo, m2 = xl[t] >> 16;          // band coordinates
+            for (int k = tid & 7; k < npair; k += 8) {
+                const int r1 = pl[k] & 0xffff, r2 = pl[k] >> 16;
+                if (r1 < d || r2 >= d + m2) continue;
+                const double xa = xsb[r1], xb = xsb[r2];
+                const bool up = xb >= xa;                                // r2 > r1: a tie counts the later draw as the larger
+                const int u1 = up ? r1 : r2, u2 = up ? r2 : r1;
+                const double x1 = up ? xa : xb, x2 = up ? xb : xa;
+                bool between = false;
+                for (int k2 = 0; k2 < npair; ++k2) {
+                    const int q1 = pl[k2] & 0xffff, q2 = pl[k2] >> 16;
+                    if (q1 != u1 && q2 != u1) continue;
+                    const int z = q1 == u1 ? q2 : q1;
+                    if (z == u2 || z < d || z >= d + m2) continue;
+                    const double xz = xsb[z];
+                    const bool above = xz > x1 || (xz == x1 && z > u1);
+                    const bool below = xz < x2 || (xz == x2 && z < u2);
+                    between |= above && below;
+                }
+                if (!between) {
+                    const int kk = atomicAdd(&s_ntask, 1);
+                    if (kk < BD_TASKS) task[kk] = t | ((u1 - d) << 8) | ((u2 - d) << 16);
+                    else atomicOr(&cres[t], 0x10000);               // no room: stays undecided
+                }
             }
         }
-        rt[d] = (unsigned char)(r > 254u ? 255u : r);
+        __syncthreads();
+        // ---- the look-ups, 64 at a time
+        {
+            const int ntask = s_ntask < BD_TASKS ? s_ntask : BD_TASKS;
+            const int grp = tid / WC_G, gl = tid & (WC_G - 1), gsh = lane & ~(WC_G - 1);
+            WcCand cd;
+            cd.bins = bins;
+            cd.pw = pwb - blo;                                       // indexed by the draw
+            cd.dl = dl;
+            cd.ndup = ndup;
+            cd.nsel = nsel;
+            for (int k = grp; k < ntask; k += 256 / WC_G) {
+                const int t = task[k] & 255, j = (task[k] >> 8) & 255, j2 = task[k] >> 16;
+                const int d = xl[t] & 0xffff;
+                cd.d = d;
+                const int e = d + nsel + j;
+                const double x = xsb[d - blo + j];
+                // first guess: the bin of x in the unmodified cdf -- known for the draws that are first-round draws of later
+                // candidates (all but the last few of the window), else one guide look-up
+                int i0;
+                if (e < nb) {
+                    i0 = bins[e];
+                } else {
+                    int bk = (int)(x * (double)a.K);
+                    bk = bk > a.K - 1 ? a.K - 1 : bk;
+                    i0 = Rq[bk].i;
+                }
+                int same = 0;
+                const int b = wc_grp_bin(cd, Sq, a.n, Stot, x, xsb[d - blo + j2], i0, gl, gsh, &same);
+                if (gl == 0) {
+                    if (b < 0) atomicOr(&cres[t], 0x10000);
+                    else if (same) atomicAdd(&cres[t], 1);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- one thread per candidate: R = m2 + m3 if m3 <= 1 or the m3 draws of round 3, right behind round 2, are pairwise
+        // farther apart than wmax
+        for (int t = tid; t < nxl; t += 256) {
+            const int d = xl[t] & 0xffff, m2 = xl[t] >> 16;
+            const int m3 = cres[t] & 0xffff;
+            unsigned r = SP_UND;
+            if (!(cres[t] >> 16)) {
+                if (m3 <= 1) {
+                    r = (unsigned)(m2 + m3);
+                } else {
+                    bool close = false;
+                    for (int u = 0; u < m3; ++u)
+                        for (int v2 = 0; v2 < u; ++v2) close |= fabs(xsb[d - blo + m2 + u] - xsb[d - blo + m2 + v2]) <= wmax;
+                    if (!close) r = (unsigned)(m2 + m3);
+                }
+            }
+            rt[d] = (unsigned char)(r > 126u ? SP_UND : r);
+        }
+        if (a.stats && tid == 0) atomicAdd((unsigned long long *)&a.stats[5], (unsigned long long)s_ntask);
+        __syncthreads();
     }
-    __syncthreads();
-    // ---- out: the verdicts and level 0 of the jump tables (step of candidate d into the window of the next query)
+    // ---- out: the verdicts, and level 0 of the jump tables again -- now only decided candidates step
     ((uint32_t *)(sp.rtab + (size_t)i * SP_W))[tid] = ((const uint32_t *)rt)[tid];
     {
-        const bool lastq = i + 1 >= lim;                     // the step of the block's last query leaves the block: not a jump
+        const bool lastq = i + 1 >= lim;
         const int delta = nsel + (int)((klo - klo1) >> 1);
-        unsigned short *J0 = sp.jump + sp_lev_row(0, i) * SP_W;
+        const int d0 = 4 * tid;
         ushort4 o;
         unsigned short *ov = (unsigned short *)&o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned r = rt[d0 + j];
             const int ndq = d0 + j + (int)r + delta;
-            ov[j] = (lastq || r == 255u || ndq < 0 || ndq >= SP_W) ? SP_INV : (unsigned short)ndq;
+            ov[j] = (lastq || r >= SP_TENT || ndq < 0 || ndq >= SP_W) ? SP_INV : (unsigned short)ndq;
         }
-        *(ushort4 *)(J0 + d0) = o;
+        *(ushort4 *)(sp.jump + sp_lev_row(0, i) * SP_W + d0) = o;
     }
-    SP_T(5);
-#undef SP_T
 }
 
+// tentative != 0: the walk over wc_spec_kernel's verdicts with the tentative ones taken at face value -- it only records where
+// the path passes every query's window (sp.dtil) for wc_band_kernel and commits nothing.
 // last != 0: the final launch of a request -- whatever is unresolved behind its block goes through the complete algorithm,
 // query by query.  serial != 0 (development / tests: P2S_WC_SERIAL): no speculation at all, every query that way.
-__global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp, int last, int serial) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
+__global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp, int last, int serial, int tentative) {
+    // Small on purpose (8.7 KB of LDS): next to the encoders the kernel must fit the slot ONE retiring encoder workgroup frees.
+    // The complete algorithm's arrays (rare since r05: undecided candidates, the remainder) live in global memory here.
     __shared__ int wsum[16];
     __shared__ double wsumd[16];
-    __shared__ long long s_klo[SP_B];
     __shared__ long long s_ev[3];
     __shared__ unsigned short s_mark[SP_B];          // window coordinate of query j where the walk KNEW it; SP_INV = jumped over
     __shared__ short s_from[SP_B];
@@ -1304,11 +1369,12 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp, int 
     const int tid = threadIdx.x;
     const long long qb = sp.ctl[0];
     if (qb >= a.nq) return;
-    const WcLds l = wc_carve(wc_lds, a.n);
+    const WcLds l = wc_carve(sp.scratch, a.n);
     const int BW = (a.n + 31) >> 5;
-    for (int i = tid; i < BW; i += 256) l.bitmap[i] = 0;
+    if (!tentative)
+        for (int i = tid; i < BW; i += 256) l.bitmap[i] = 0;
     const int lim = serial ? 0 : (int)(a.nq - qb < SP_B ? a.nq - qb : SP_B);
-    for (int i = tid; i < lim; i += 256) s_klo[i] = sp.klo[i];
+    const long long *s_klo = sp.klo;
     for (int j = tid; j < SP_B; j += 256) s_mark[j] = SP_INV;
     long long s = sp.ctl[1];
     int i = 0;
@@ -1352,12 +1418,16 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp, int 
                         break;
                     }
                     const unsigned r = sp.rtab[(size_t)i * SP_W + d];
-                    if (r == 255u) {
-                        ev = 1;
+                    if (tentative ? r == SP_UND : r >= SP_TENT) {
+                        ev = tentative ? 2 : 1;       // undecided (exact walk: also a tentative verdict outside the band)
+                        if (a.stats && !tentative && sp.dtil[i] >= 0) {      // how far the real path is from the tentative one
+                            const long long dl_ = d - sp.dtil[i];
+                            atomicMax((unsigned long long *)&a.stats[9], (unsigned long long)(dl_ < 0 ? -dl_ : dl_));
+                        }
                         break;
                     }
-                    a.base[qb + i] = s;
-                    s += 2LL * (a.nsel + (int)r);
+                    if (!tentative) a.base[qb + i] = s;
+                    s += 2LL * (a.nsel + (int)(r & 127u));
                     ++i;
                 }
                 s_ev[0] = ev;
@@ -1369,6 +1439,7 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp, int 
             i = (int)s_ev[1];
             s = s_ev[2];
             __syncthreads();
+            if (tentative && ev == 3) ev = 2;         // words exhausted: the exact walk reports it
         }
         if (ev == 2 && in_block) {
             in_block = false;
@@ -1406,10 +1477,15 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp, int 
                 }
                 // (a start itself: m = 0 from the beginning.  The ids kernel re-derives every query's consumption and
                 //  flags any disagreement, so a wrong offset cannot pass silently.)
-                if (m == 0 && dd != SP_INV) a.base[qb + j] = s_klo[j] + 2LL * dd;
+                if (tentative) sp.dtil[j] = (m == 0 && dd != SP_INV) ? (short)dd : (short)-1;
+                else if (m == 0 && dd != SP_INV) a.base[qb + j] = s_klo[j] + 2LL * dd;
                 else a.meta[1] = 4;
             }
+            if (tentative)
+                for (int j = tid; j < lim; j += 256)
+                    if (j >= i) sp.dtil[j] = -1;
         }
+        if (tentative) return;                        // nothing is committed: the exact walk follows
         // words exhausted: in the block (the walk found out) or for the next query of the remainder
         if (ev == 3 || (ev == 2 && (last || serial) && qb + i < a.nq && s + 2LL * a.nsel > a.cap_words)) {
             if (tid == 0) {
@@ -1598,11 +1674,11 @@ struct WcBatchMem {
     long long *base;
     float *pmax, *dsum, *mu;
 };
-WcBatchMem wc_batch_mem(p2s_rng_s *r, int b) {
+WcBatchMem wc_batch_mem(p2s_rng_s *r) {
     WcBatchMem m;
-    m.S = r->wc_S[b];
-    m.R = (WcRec *)r->wc_T[b];
-    m.stot = r->wc_sc[b];
+    m.S = r->wc_S;
+    m.R = (WcRec *)r->wc_T;
+    m.stot = r->wc_sc;
     m.base = (long long *)(m.stot + r->wc_cap_q);
     m.pmax = (float *)(m.base + r->wc_cap_q);
     m.dsum = m.pmax + 2 * r->wc_cap_q;
@@ -1611,63 +1687,47 @@ WcBatchMem wc_batch_mem(p2s_rng_s *r, int b) {
 }
 
 void wc_free(p2s_rng_s *r) {
-    for (int b = 0; b < 2; ++b) {
-        if (r->wc_S[b]) (void)hipFree(r->wc_S[b]);
-        if (r->wc_T[b]) (void)hipFree(r->wc_T[b]);
-        if (r->wc_sc[b]) (void)hipFree(r->wc_sc[b]);
-        r->wc_S[b] = nullptr;
-        r->wc_T[b] = nullptr;
-        r->wc_sc[b] = nullptr;
-    }
+    if (r->wc_S) (void)hipFree(r->wc_S);
+    if (r->wc_T) (void)hipFree(r->wc_T);
+    if (r->wc_sc) (void)hipFree(r->wc_sc);
     if (r->wc_spec) (void)hipFree(r->wc_spec);
     if (r->wc_J) (void)hipFree(r->wc_J);
+    r->wc_S = nullptr;
+    r->wc_T = nullptr;
+    r->wc_sc = nullptr;
     r->wc_spec = nullptr;
     r->wc_J = nullptr;
     r->wc_cap_q = r->wc_cap_n = r->wc_cap_k = 0;
-    r->wc_bufs = 0;
 }
 
-// bufs = 2: a second set of tables, so that the tables of batch b + 1 are built (second stream) while the offsets pass of
-// batch b runs -- used when a call holds more than one batch and wants no ids (stream skipping: the chip is idle otherwise)
-int wc_reserve(p2s_rng_s *r, size_t nq, size_t n, size_t K, int bufs) {
-    if (nq <= r->wc_cap_q && n <= r->wc_cap_n && K <= r->wc_cap_k && bufs <= r->wc_bufs) return P2S_OK;
+constexpr size_t WC_SCRATCH = 160 * 1024;            // >= wc_lds_bytes(n) of every cloud the ids kernel takes
+constexpr size_t WC_SPEC_BYTES = 64 + (size_t)SP_B * 16 + (size_t)SP_B * SP_W + (size_t)SP_B * 2 + 64 + (size_t)SP_B * SP_SAVE * 4 + 64 +
+                                 WC_SCRATCH;
+
+int wc_reserve(p2s_rng_s *r, size_t nq, size_t n, size_t K) {
+    if (nq <= r->wc_cap_q && n <= r->wc_cap_n && K <= r->wc_cap_k) return P2S_OK;
     nq = std::max(nq, r->wc_cap_q);
     n = std::max(n, r->wc_cap_n);
     K = std::max(K, r->wc_cap_k);
-    bufs = std::max(bufs, r->wc_bufs);
     wc_free(r);
-    bool ok = hipMalloc(&r->wc_J, SP_JUMP_ROWS * SP_W * 2) == hipSuccess &&
-              hipMalloc(&r->wc_spec, 64 + (size_t)SP_B * 8 + (size_t)SP_B * SP_W) == hipSuccess;
-    for (int b = 0; b < bufs && ok; ++b)
-        ok = hipMalloc(&r->wc_S[b], nq * n * 8) == hipSuccess && hipMalloc(&r->wc_T[b], nq * K * sizeof(WcRec)) == hipSuccess &&
-             hipMalloc(&r->wc_sc[b], nq * 40) == hipSuccess;
+    const bool ok = hipMalloc(&r->wc_J, SP_JUMP_ROWS * SP_W * 2) == hipSuccess && hipMalloc(&r->wc_spec, WC_SPEC_BYTES) == hipSuccess &&
+                    hipMalloc(&r->wc_S, nq * n * 8) == hipSuccess && hipMalloc(&r->wc_T, nq * K * sizeof(WcRec)) == hipSuccess &&
+                    hipMalloc(&r->wc_sc, nq * 40) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         wc_free(r);
-        p2s_set_error("weighted sub-sample: hipMalloc of the per-query tables failed (%zu queries x %zu points x %d)", nq, n, bufs);
+        p2s_set_error("weighted sub-sample: hipMalloc of the per-query tables failed (%zu queries x %zu points)", nq, n);
         return P2S_ENOMEM;
     }
     r->wc_cap_q = nq;
     r->wc_cap_n = n;
     r->wc_cap_k = K;
-    r->wc_bufs = bufs;
     return P2S_OK;
 }
 
 }  // namespace
 
-void p2s_wc_free_rng(p2s_rng_s *r) {
-    wc_free(r);
-    for (int b = 0; b < 2; ++b) {
-        if (r->wc_ev_tab[b]) (void)hipEventDestroy(r->wc_ev_tab[b]);
-        if (r->wc_ev_use[b]) (void)hipEventDestroy(r->wc_ev_use[b]);
-        r->wc_ev_tab[b] = r->wc_ev_use[b] = nullptr;
-    }
-    if (r->wc_ev_in) (void)hipEventDestroy(r->wc_ev_in);
-    if (r->wc_stream2) (void)hipStreamDestroy(r->wc_stream2);
-    r->wc_ev_in = nullptr;
-    r->wc_stream2 = nullptr;
-}
+void p2s_wc_free_rng(p2s_rng_s *r) { wc_free(r); }
 
 static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_t nq, int n_sel, int32_t *ids_out_dev,
                         float *pts_out_dev, void *stream, bool fixed, uint32_t fixed_seed);
@@ -1722,26 +1782,18 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
         p2s_set_error("p2s_subsample_weighted: jump tables too small for one query");
         return P2S_EINVAL;
     }
+    // one bit per cloud point next to the arrays of one query in the ids kernel's LDS: the size limit of this mode
+    // (475,040 points; stated at the prototype)
     const size_t lds_ids = wc_lds_bytes(n);
-    const size_t lds_chain_max = 160 * 1024 - 4096 - SP_B * 8 - SP_B * 4 - 1024;      // the chain kernel's static arrays
-    if (lds_ids > lds_chain_max) {
+    const size_t lds_limit = 160 * 1024 - 4096 - SP_B * 8 - SP_B * 4 - 1024;
+    static_assert(160 * 1024 - 4096 - SP_B * 8 - SP_B * 4 - 1024 <= WC_SCRATCH, "chain scratch");
+    if (lds_ids > lds_limit) {
         p2s_set_error("p2s_subsample_weighted: cloud of %d points does not fit the LDS bitmap (limit: %d points)", n,
-                      (int)((lds_chain_max - wc_lds_bytes(0) - 16) / 6 * 32));
+                      (int)((lds_limit - wc_lds_bytes(0) - 16) / 6 * 32));
         return P2S_ECAPACITY;
     }
-    // stream skipping (no ids wanted) over several batches: the tables of batch b + 1 on a second stream while the offsets
-    // pass of batch b runs (the chip is idle otherwise: 9.1 -> ms per 4096 queries)
-    const bool overlap = !ids_out_dev && !fixed && nq > per_req && !getenv("P2S_WC_NO_OVERLAP");
-    rc = wc_reserve(r, (size_t)per_req, (size_t)n, (size_t)K, overlap ? 2 : 1);
+    rc = wc_reserve(r, (size_t)per_req, (size_t)n, (size_t)K);
     if (rc) return rc;
-    if (overlap && !r->wc_stream2) {
-        P2S_HIP_CHECK(hipStreamCreateWithFlags(&r->wc_stream2, hipStreamNonBlocking));
-        for (int b = 0; b < 2; ++b) {
-            P2S_HIP_CHECK(hipEventCreateWithFlags(&r->wc_ev_tab[b], hipEventDisableTiming));
-            P2S_HIP_CHECK(hipEventCreateWithFlags(&r->wc_ev_use[b], hipEventDisableTiming));
-        }
-        P2S_HIP_CHECK(hipEventCreateWithFlags(&r->wc_ev_in, hipEventDisableTiming));
-    }
     WcPlanDev plan;
     plan.leaf = c->wc_plan;
     plan.ops = c->wc_plan + c->wc_ops_at;
@@ -1753,37 +1805,24 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     WcSpec sp;
     sp.ctl = (long long *)r->wc_spec;
     sp.klo = sp.ctl + 8;
-    sp.rtab = (unsigned char *)(sp.klo + SP_B);
+    sp.klo1 = sp.klo + SP_B;
+    sp.rtab = (unsigned char *)(sp.klo1 + SP_B);
+    sp.dtil = (short *)(sp.rtab + (size_t)SP_B * SP_W);
+    sp.save = (int *)(((uintptr_t)(sp.dtil + SP_B) + 63) & ~(uintptr_t)63);
+    sp.scratch = (unsigned char *)(((uintptr_t)(sp.save + (size_t)SP_B * SP_SAVE) + 63) & ~(uintptr_t)63);
     sp.jump = r->wc_J;
     const bool serial_only = getenv("P2S_WC_SERIAL") != nullptr;   // development / tests: every query through the in-order remainder path
-    // the chain workgroup of a full block claims a CU of its own (LDS no encoder workgroup fits next to): sharing a CU
-    // with the encoders' MFMA-saturated waves it gets an instruction issued every ~200 cycles
-    const size_t lds_chain = nq >= 64 ? std::max(lds_ids, (size_t)100000) : lds_ids;
     {   // per device (a process may drive several); the call is cheap
         (void)hipFuncSetAttribute((const void *)wc_ids_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void *)wc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chain_max);
         (void)hipFuncSetAttribute((const void *)wc_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NP_BUFSIZE + WC_MAX_NODES) * 4);
     }
     long long *meta = p2s_rng_raw_meta(r);
     static long long *stats_dev = nullptr;
     const bool want_stats = getenv("P2S_WC_STATS") != nullptr;
-    if (want_stats && !stats_dev) (void)hipMalloc(&stats_dev, 32 * 8);
-    auto launch_tables = [&](int64_t done, int cur, int b, hipStream_t st) {
-        const WcBatchMem m = wc_batch_mem(r, b);
-        hipLaunchKernelGGL(wc_tables_kernel, dim3(cur), dim3(256), (size_t)(NP_BUFSIZE + ((plan.n_nodes + 3) & ~3)) * 4, st, c->d.pts, n,
-                           q_dev + (size_t)done * 3, plan, K, m.S, m.R, m.stot, m.pmax, m.mu, m.dsum, n_sel, meta);
-    };
-    if (overlap) {
-        // the second stream starts behind everything the caller queued (the queries, the cloud)
-        P2S_HIP_CHECK(hipEventRecord(r->wc_ev_in, s));
-        P2S_HIP_CHECK(hipStreamWaitEvent(r->wc_stream2, r->wc_ev_in, 0));
-        launch_tables(0, (int)std::min<int64_t>(per_req, nq), 0, r->wc_stream2);
-        P2S_HIP_CHECK(hipEventRecord(r->wc_ev_tab[0], r->wc_stream2));
-    }
-    int bi = 0;
-    for (int64_t done = 0; done < nq; bi ^= 1) {
+    if (want_stats && !stats_dev) (void)hipMalloc(&stats_dev, 16 * 8);
+    const WcBatchMem m = wc_batch_mem(r);
+    for (int64_t done = 0; done < nq;) {
         const int cur = (int)std::min<int64_t>(per_req, nq - done);
-        const int b = overlap ? bi : 0;
         if (fixed) {
             // a fresh generator per batch: every query of the batch reads the same words from its start
             if ((rc = p2s_rng_reseed(r, fixed_seed, s))) return rc;
@@ -1792,19 +1831,8 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
             rc = p2s_rng_session_raw(r, (long long)(2.0 * n_sel * 1.15 * cur) + margin, s);
         }
         if (rc) return rc;
-        if (overlap) {
-            const int64_t nxt = done + cur;
-            if (nxt < nq) {
-                // tables of the next batch into the other buffer, once the offsets pass two batches back has left it
-                if (nxt >= 2 * per_req) P2S_HIP_CHECK(hipStreamWaitEvent(r->wc_stream2, r->wc_ev_use[b ^ 1], 0));
-                launch_tables(nxt, (int)std::min<int64_t>(per_req, nq - nxt), b ^ 1, r->wc_stream2);
-                P2S_HIP_CHECK(hipEventRecord(r->wc_ev_tab[b ^ 1], r->wc_stream2));
-            }
-            P2S_HIP_CHECK(hipStreamWaitEvent(s, r->wc_ev_tab[b], 0));
-        } else {
-            launch_tables(done, cur, 0, s);
-        }
-        const WcBatchMem m = wc_batch_mem(r, b);
+        hipLaunchKernelGGL(wc_tables_kernel, dim3(cur), dim3(256), (size_t)(NP_BUFSIZE + ((plan.n_nodes + 3) & ~3)) * 4, s, c->d.pts, n,
+                           q_dev + (size_t)done * 3, plan, K, m.S, m.R, m.stot, m.pmax, m.mu, m.dsum, n_sel, meta);
         WcArgs a;
         a.S = m.S;
         a.R = m.R;
@@ -1826,44 +1854,44 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
         a.fixed = fixed ? 1 : 0;
         sp.mu = m.mu;
         if (want_stats) {
-            (void)hipMemsetAsync(stats_dev, 0, 32 * 8, s);
+            (void)hipMemsetAsync(stats_dev, 0, 16 * 8, s);
             a.stats = stats_dev;
         }
         if (fixed) {
             // no serial dependence between the queries: the ids kernel alone (it reports the last query's consumption)
         } else if (serial_only) {
             hipLaunchKernelGGL(wc_ctl_init_kernel, dim3(1), dim3(1), 0, s, sp.ctl, meta);
-            hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), lds_ids, s, a, sp, 1, 1);
+            hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), 0, s, a, sp, 1, 1, 0);
         } else {
-            // speculation tables on all CUs + a light chain per block of SP_B queries; two spare pairs for blocks that
-            // end early (start outside the window); the last chain launch also takes whatever is still unresolved
+            // per block of SP_B queries: speculation tables on all CUs (tentative where round-2 draws lie close together), the
+            // tentative walk to find out where the path runs, the exact decision for the candidates near it, the walk.  One
+            // spare round for a block that ends early (start outside the window); the last chain launch also takes whatever
+            // is still unresolved then
             hipLaunchKernelGGL(wc_ctl_init_kernel, dim3(1), dim3(1), 0, s, sp.ctl, meta);
             const int blk = std::min(cur, SP_B);
-            const int pairs = (cur + SP_B - 1) / SP_B + (cur > SP_B / 2 ? 2 : 0);
-            for (int pr = 0; pr < pairs; ++pr) {
-                hipLaunchKernelGGL(wc_spec_kernel, dim3(blk), dim3(256), 0, s, a, sp);
+            const int rounds = (cur + SP_B - 1) / SP_B + (cur > SP_B / 2 ? 1 : 0);
+            auto jumps = [&]() {
                 for (int k = 1; k < SP_LEV && (1 << k) < blk; ++k)
                     hipLaunchKernelGGL(wc_jumpk_kernel, dim3((blk + (1 << k) - 1) >> k), dim3(256), 0, s, a, sp, k);
-                hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), pr < (cur + SP_B - 1) / SP_B ? lds_chain : lds_ids, s, a, sp,
-                                   pr == pairs - 1 ? 1 : 0, 0);
+            };
+            for (int pr = 0; pr < rounds; ++pr) {
+                hipLaunchKernelGGL(wc_spec_kernel, dim3(blk), dim3(256), 0, s, a, sp);
+                jumps();
+                hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), 0, s, a, sp, 0, 0, 1);
+                hipLaunchKernelGGL(wc_band_kernel, dim3(blk), dim3(256), 0, s, a, sp);
+                jumps();
+                hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), 0, s, a, sp, pr == rounds - 1 ? 1 : 0, 0, 0);
             }
         }
         if (ids_out_dev) hipLaunchKernelGGL(wc_ids_kernel, dim3(cur), dim3(256), lds_ids, s, a);   // NULL: advance the stream only
-        if (overlap) P2S_HIP_CHECK(hipEventRecord(r->wc_ev_use[b], s));
         P2S_LAUNCH_CHECK("weighted sub-sample kernels");
         if (want_stats) {
-            long long h[32];
+            long long h[16];
             (void)hipMemcpyAsync(h, stats_dev, sizeof(h), hipMemcpyDeviceToHost, s);
             (void)hipStreamSynchronize(s);
             fprintf(stderr, "[wc stats] %d queries: chain launches that did work %lld, queries through the complete algorithm %lld "
-                            "taking %lld of %lld 10-ns ticks; spec workgroups %lld: 10-ns ticks per workgroup in window %lld, dups+nd+pw %lld, "
-                            "verdict %lld, task list %lld, look-ups %lld, out %lld; listed candidates %.1f, tasks %.1f, dup draws %.1f per query\n",
-                    cur, h[11], h[12], h[13], h[14], h[8], h[0] / std::max(h[8], 1LL), h[1] / std::max(h[8], 1LL), h[2] / std::max(h[8], 1LL),
-                    h[3] / std::max(h[8], 1LL), h[4] / std::max(h[8], 1LL), h[5] / std::max(h[8], 1LL), (double)h[6] / std::max(h[8], 1LL),
-                    (double)h[7] / std::max(h[8], 1LL), (double)h[9] / std::max(h[8], 1LL));
-            fprintf(stderr, "[wc stats]   look-ups of lane 0: %lld tasks, %.2f passes and %.2f window steps per task, %.1f ticks per pass, %.1f ticks "
-                            "waiting for the loads per pass\n", h[20], (double)h[16] / std::max(h[20], 1LL), (double)h[17] / std::max(h[20], 1LL),
-                    (double)h[18] / std::max(h[16], 1LL), (double)h[19] / std::max(h[16], 1LL));
+                            "taking %lld of %lld 10-ns ticks (largest distance from the tentative path there: %lld draws); band: %lld "
+                            "windows, %lld tentative candidates, %lld exact look-ups\n", cur, h[11], h[12], h[13], h[14], h[9], h[0], h[2], h[5]);
         }
         done += cur;
     }

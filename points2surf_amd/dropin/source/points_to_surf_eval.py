@@ -269,8 +269,8 @@ def points_to_surf_eval(eval_opt):
         t_model = time.time() - t_load0
         # the engine's own chunk size (8192 / 4096 / 2048 queries by model and encoder): results do not depend on it, and the
         # reference's --batchSize (501 in its scripts: a DataLoader batch) as chunk size costs 9 % of the throughput
-        # (163 k instead of 179 k queries/s at 256^3).  P2S_DROPIN_CHUNK=<n> for experiments
-        chunk = int(os.environ.get('P2S_DROPIN_CHUNK', 0))
+        # (163 k instead of 179 k queries/s at 256^3)
+        chunk = 0
 
         with open(os.path.join(eval_opt.indir, eval_opt.dataset)) as f:
             shape_names = [x.strip() for x in f.readlines()]

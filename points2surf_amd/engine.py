@@ -251,14 +251,13 @@ class Rng:
             _lib.check(self.lib.p2s_rng_create(ctypes.c_uint32(int(seed) & 0xffffffff), self.device.index,
                                                ctypes.byref(self.handle)))
             if parallel is None:
-                parallel = not os.environ.get('P2S_RNG_SERIAL')
+                parallel = True
             if parallel and os.path.isfile(_JUMP_TABLES):
                 t = np.load(_JUMP_TABLES)
                 # table entry m = jump of base*2^m blocks.  Streams of `bps` blocks need the entries from
-                # log2(bps/base) upwards; fewer, longer streams mean fewer dependent jump rounds (each round is a
-                # separate launch that has to find CU space next to the encoder kernel): 16 x 1024 by default.
+                # log2(bps/base) upwards; fewer, longer streams mean fewer dependent jump rounds: 512 x 1024
                 base = int(t['blocks_per_stream'])
-                bps = int(os.environ.get('P2S_RNG_BLOCKS_PER_STREAM', 1024))
+                bps = 1024
                 first = max(0, int(round(np.log2(bps / base))))
                 levels = int(t['levels']) - first
                 bps = base << first

@@ -136,7 +136,8 @@ def query_range(n_queries, world, rank):
 
 def skip_queries(cloud, rng_dev, cfg, queries, sub_sample_size, chunk=4096, rng_patch=None):
     """advance the RNG stream past ``queries`` ([m,3] device tensor, in order) without inference.  Fixed-radius models:
-    ``rng_patch`` (the data set's first generator) is advanced past the patch choices of the same queries."""
+    ``rng_patch`` (the data set's first generator) is advanced past the patch choices of the same queries.  (``chunk``: kept for
+    callers of earlier rounds; the library chooses its own batches.)"""
     m = int(queries.shape[0])
     if m == 0:
         return
@@ -161,9 +162,7 @@ def skip_queries(cloud, rng_dev, cfg, queries, sub_sample_size, chunk=4096, rng_
     if cfg.get('uniform_subsample'):
         rng_dev.skip(cloud, sub_sample_size, n_queries=m)
     else:
-        # ONE call: the library walks the queries in batches of 4096 and builds the tables of the next batch on a second
-        # stream while the offsets pass of the current one runs (p2s_wchoice.hip)
-        rng_dev.skip(cloud, sub_sample_size, query_ms=queries)
+        rng_dev.skip(cloud, sub_sample_size, query_ms=queries)      # one call: the library walks the queries in batches of 4096
 
 
 def skip_shape_stream(cloud, rng_dev, cfg, grid_resolution, epsilon, sub_sample_size, chunk=4096, rng_patch=None):

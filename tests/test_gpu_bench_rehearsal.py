@@ -19,7 +19,7 @@ def test_two_ranks_on_one_gpu(mode):
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
     env['P2S_BENCH_SHARE_GPU'] = '1'
     r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2',
-                        '--warmup', '1', '--res', '32', '--rng-mode', mode], env=env, capture_output=True, text=True,
+                        '--warmup', '1', '--res', '32', '--rng-mode', mode, '--cpu-seconds', '3'], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     lines = [l for l in r.stdout.split('\n') if l.startswith('{')]
@@ -27,7 +27,12 @@ def test_two_ranks_on_one_gpu(mode):
     d = json.loads(lines[0])
     assert d['config']['rng_mode'] == mode and 'REHEARSAL' in d['config']['parallelism'] and d['n_gpus'] == 1
     assert d['config']['queries_per_shape'] == {'00994122': 2976} and d['value'] > 0 and d['steps'] == 2
-    assert d['roofline']['launches'] > 0 and 'cpu_baseline' not in d
+    assert d['roofline']['launches'] > 0
+    # also at N > 1 rank 0 times the CPU baseline (after the timed region) and relates shapes/hour to it
+    cb = d['cpu_baseline']
+    assert cb['kind'] in ('port', 'reference') and cb['value'] > 0 and cb['cores'] >= 1 and len(cb['thread_probe_queries_per_s']) >= 1
+    assert d['config']['shapes_per_hour_vs_cpu'] > 1.0 and cb['shapes_per_hour_cpu'] > 0
+    assert d['self_check']['vs_cpu_' + cb['kind']]['sign_flips'] == 0
     assert d['stage_ms_rank0']['ms_cloud'] > 0 and d['stage_ms_rank0']['ms_grid'] > 0      # fresh handle per step
     g = d['self_check']['vs_reference_golden']
     assert g['queries'] == 2976 and g['sign_flips'] == 0 and g['max_abs_dsdf'] < 1e-4
@@ -49,7 +54,7 @@ def test_eight_ranks_three_clouds_at_the_real_world_size():
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
     env['P2S_BENCH_SHARE_GPU'] = '1'
     r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--backend', 'gloo', '--steps', '3',
-                        '--warmup', '1', '--res', '64', '--dataset', 'abc3'], env=env, capture_output=True, text=True,
+                        '--warmup', '1', '--res', '64', '--dataset', 'abc3', '--cpu-seconds', '3'], env=env, capture_output=True, text=True,
                        timeout=1200)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     lines = [l for l in r.stdout.split('\n') if l.startswith('{')]
@@ -61,6 +66,8 @@ def test_eight_ranks_three_clouds_at_the_real_world_size():
     assert g['sign_flips'] == 0 and g['max_abs_dsdf'] < 1e-4 and g['queries'] == sum(d['config']['queries_per_shape'].values())
     h = d['self_check']['stream_handoff']
     assert d['config']['stream_mode'] == 'dataset/handoff' and h['bit_identical_to_single_stream'] is True and h['owner'] != 0
+    # the keys a SCALE run is read by: the CPU baseline and the ratio at the real world size
+    assert d['cpu_baseline']['value'] > 0 and d['config']['shapes_per_hour_vs_cpu'] > 1.0 and d['config']['shapes_per_hour'] > 0
 
 
 def test_replicate_mode_still_gives_the_exact_stream():
@@ -68,7 +75,7 @@ def test_replicate_mode_still_gives_the_exact_stream():
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
     env.update(P2S_BENCH_SHARE_GPU='1', P2S_STREAM_HANDOFF='replicate')
     r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2',
-                        '--warmup', '1', '--res', '32'], env=env, capture_output=True, text=True, timeout=600)
+                        '--warmup', '1', '--res', '32', '--cpu-seconds', '0'], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     d = json.loads([l for l in r.stdout.split('\n') if l.startswith('{')][0])
     assert d['config']['stream_mode'] == 'dataset/replicate' and d['value'] > 0
@@ -98,7 +105,7 @@ def test_golden_check_classifies_a_flipped_sign_with_device_and_cpu_logits(fixtu
     rec, ok = bench.golden_check(engine, parity, model, w, cfg, shapes, 24, sdfs, 1e-4, 0)
     assert not ok and rec['sign_flips'] == 1 and rec['sign_flips_not_ties'] == 1
     f = rec['flipped'][0]
-    assert f['shape'] == 'shape_b' and f['query'] == j and not f['fp32_tie']
+    assert f['shape'] == 'shape_b' and f['query'] == j and not f['tie'] and rec['tie_logit'] == parity.TIE_LOGIT_FP32
     assert abs(f['sign_logit_device'] - f['sign_logit_cpu_port']) < 1e-3 and abs(f['sign_logit_device']) > 1e-3
     assert abs(rec['max_abs_diff_unmasked'] - 2 * abs(sdfs[1][j])) < 1e-6 and rec['max_abs_dsdf'] < 1e-6
     # the logit the analysis computed belongs to THAT query: its sign is the sign of the device's SDF there
@@ -123,7 +130,7 @@ def test_dropin_leg_of_the_bench(encoder, golden_dir, capsys):
     before = os.environ.get('P2S_ENCODER')
     mods = [m for m in sys.modules if m == 'source' or m.startswith('source.')]
     try:
-        rec = bench.dropin_leg(shapes, 32, encoder, 'tests/golden/ref_fulleval_p2s_max_abc3_grid32.npz', parity)
+        rec, sdfs = bench.dropin_leg(shapes, 32, encoder)
     finally:
         for m in [m for m in sys.modules if (m == 'source' or m.startswith('source.')) and m not in mods]:
             del sys.modules[m]
@@ -134,6 +141,25 @@ def test_dropin_leg_of_the_bench(encoder, golden_dir, capsys):
     cap = capsys.readouterr()
     assert cap.out == '' and 'evaluated' in cap.err
     assert rec['files_written'] == 7 * 3 and rec['shapes'] == 3 and rec['queries'] == sum(s[2].shape[0] for s in shapes)
-    v = rec['vs_reference_golden']
-    assert v['max_abs_dsdf'] < 1e-5 and v['sign_flips'] == 0
+    for sdf, (_, _, ref) in zip(sdfs, shapes):           # what the drop-in wrote, against the reference's golden
+        c = parity.compare_sdf(sdf, ref)
+        assert c['max_abs_dsdf'] < 1e-5 and c['flipped'].size == 0
     assert rec['value'] > 0 and rec['value_shape_loop'] >= rec['value'] and rec['seconds_mesh_directory'] > 0
+
+
+def test_bench_model_flag_measures_configs3():
+    """``bench.py --model p2s_vanilla --bf16 4`` = BASELINE configs[3] (p2s_vanilla with QSTN, fp16-pair
+    encoder + fp32 decoder) through the same line: metric / workload name the model, the QSTN trunk launch is counted (3
+    chain launches per chunk), the golden check runs against the model's own golden with the split-precision tie threshold"""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--model', 'p2s_vanilla', '--bf16', '4', '--steps', '2',
+                        '--warmup', '1', '--res', '32', '--cpu-seconds', '0'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = json.loads([l for l in r.stdout.split('\n') if l.startswith('{')][0])
+    assert 'p2s_vanilla' in d['metric'] and 'fp16-pair' in d['metric'] and d['dtype'] == 'fp16x2'
+    assert 'configs[3]' in d['config']['workload'] and 'p2s_vanilla' in d['config']['workload']
+    assert d['roofline']['launches'] % 3 == 0 and d['roofline']['mfma_passes_per_product'] == 3
+    assert d['stage_ms_rank0']['ms_chain_qstn'] > 0
+    g = d['self_check']['vs_reference_golden']
+    assert g['file'].endswith('ref_p2s_vanilla_grid32.npz') and g['queries'] == 2976 and g['max_abs_dsdf'] < 1e-4
+    assert g['sign_flips_not_ties'] == 0 and g['tie_logit'] == 2e-5 and 'secondary' not in d

@@ -107,3 +107,17 @@ def test_bad_arguments(tmp_path):
         writers.savetxt_f32(str(tmp_path / 'no_such_dir_x' / 'y' / '..' / '..' / 'nope' / 'f.txt') + '/', np.zeros(3, np.float32))
     with pytest.raises(ValueError):
         writers.query_vis_ply(str(tmp_path / 'x.ply'), np.zeros((4, 3), np.float32), np.zeros(5, np.float32))
+
+
+def test_write_errors_are_reported_with_the_io_error_code(tmp_path):
+    """a failed open / write / flush / close is P2S_EIO with errno's text, never a silent truncated file.
+    /dev/full accepts the open and fails the flush: the deferred error a plain fclose() in a destructor would swallow"""
+    from points2surf_amd import _lib
+    vals = np.linspace(-1, 1, 5000).astype(np.float32)
+    with pytest.raises(_lib.P2SError) as e:
+        writers.savetxt_f32(str(tmp_path), vals)                      # a directory: fopen fails
+    assert e.value.code == -6 and 'cannot open' in str(e.value)
+    if os.path.exists('/dev/full'):
+        with pytest.raises(_lib.P2SError) as e:
+            writers.savetxt_f32('/dev/full', vals)
+        assert e.value.code == -6 and ('No space' in str(e.value) or 'write to' in str(e.value) or 'flush' in str(e.value))
