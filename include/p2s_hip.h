@@ -371,6 +371,7 @@ int p2s_nn_distance_stats(p2s_cloud_t target, const float *query_dev, int64_t n,
  *                          (points2surf_amd/ply.py): float32 xyz + uchar rgba per query point.
  * p2s_write_coff_samples:  mesh_io.write_off(file, query_pts_ms, [], colors_vertex=...) with the colours of
  *                          source/sdf.py:203-209 (source/base/mesh_io.py:75-140): str() of every number.
+ * A file that cannot be opened, written, flushed or closed: P2S_EIO with errno's text (never a silently truncated file).
  * ------------------------------------------------------------------------------------------ */
 int p2s_write_txt_f32(const char *path, const float *values_host, int64_t n);
 int p2s_write_query_vis_ply(const char *path, const float *query_host, const float *dist_host, int64_t n);

@@ -1560,7 +1560,6 @@ int p2s_subsample_uniform(p2s_rng_t r, p2s_cloud_t c, int64_t nq, int n, int32_t
     } else {
         uint32_t mask = rng;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-        // large requests: parallel generation over 2^levels jump-ahead streams; small ones: the serial kernel
         constexpr long long par_min = 400000;
         // large requests: values come from a session (2^levels_max jump-ahead streams generated once, many calls
         // take consecutive ranges); small ones outside a matching session: the serial kernel

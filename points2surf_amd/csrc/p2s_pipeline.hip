@@ -209,11 +209,11 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
     const double ball_r = m->cfg.patch_radius;
     const bool ball = ball_r > 0.0;                         // patch = points within a fixed radius (p2s_ball.hip)
     const int k = m->cfg.points_per_patch, n = m->cfg.sub_sample_size;
-    // default chunk: 8192 queries for the uniform sub-sample; 4096 for the distance-weighted one, whose generator works in
-    // batches of 4096 queries (two batches per chunk of 8192 measured 6 % SLOWER: 102.7 vs 109.8 k queries/s)
-    // r04: with a 16-bit encoder the weighted models run best with 2048 (fp16 pair, test shape at 256^3: 1024 / 2048 / 3072 /
-    // 4096 / 8192 queries: 231.8 / 236.9 / 235.4 / 233.8 / 208.9 k queries/s; fp32: 2048 / 4096: 109.7 / 110.4 k)
-    if (chunk <= 0) chunk = weighted ? std::min(m->max_chunk, m->cfg.encoder_bf16 ? 2048 : 4096) : m->max_chunk;
+    // default chunk: 8192 queries, except the distance-weighted sub-sample next to the fp32 encoders: 4096 (its generator works
+    // in batches of 4096 queries; fp32, test shape at 256^3, r05: 2048 / 4096 / 6144 / 8192 queries: 110.8 / 112.1 / 111.6 /
+    // 112.2 k queries/s -- the smaller one for its table memory; fp16 pair: 1024 / 2048 / 4096 / 8192: 250.6 / 261.4 / 261.9 /
+    // 266.8 k: until r04 the auxiliary stream's chain kernel waited milliseconds for a drained CU and 2048 was best)
+    if (chunk <= 0) chunk = (weighted && !m->cfg.encoder_bf16) ? std::min(m->max_chunk, 4096) : m->max_chunk;
     chunk = std::min(chunk, m->max_chunk);
     if (m->overlap && !m->aux) {
         // high queue priority: the data-path kernels are tiny next to the encoder kernel and must not queue

@@ -1568,7 +1568,7 @@ __global__ __launch_bounds__(256) void wc_ids_kernel(WcArgs a) {
         if (tid == 0 && q == a.nq - 1 && used >= 0) a.meta[0] = used;
         return;
     }
-    // cross-check against the offsets kernel: both must agree on where the next query starts
+    // cross-check against the offsets pass: both must agree on where the next query starts
     const long long next = (q + 1 < a.nq) ? a.base[q + 1] : a.meta[0];
     if (tid == 0 && (used < 0 || base + used != next)) a.meta[1] = 4;
 }

@@ -91,11 +91,12 @@ def test_every_environment_switch_is_documented():
 
 
 def test_kernels_named_in_the_docs_exist():
-    """every `..._kernel` DESIGN.md / profiles/README.md name is a kernel of points2surf_amd/csrc"""
+    """every `..._kernel` name in DESIGN.md / INTEGRATION.md is a kernel of points2surf_amd/csrc (HISTORY.md and
+    profiles/README.md are records of earlier rounds and may name kernels that are gone)"""
     import glob
     src = ''.join(open(f).read() for f in glob.glob(os.path.join(REPO, 'points2surf_amd', 'csrc', '*')))
-    for doc in ('DESIGN.md', os.path.join('profiles', 'README.md')):
+    for doc in ('DESIGN.md', 'INTEGRATION.md'):
         t = open(os.path.join(REPO, doc)).read()
         names = set(re.findall(r'`((?:p2s|wc|vol|mc|mt|rs)_[a-z0-9_]*_kernel)(?:<[^`]*>)?`', t))
         missing = sorted(n for n in names if ('void ' + n) not in src)
-        assert len(names) >= 10 and not missing, (doc, missing)
+        assert (len(names) >= 10 or doc != 'DESIGN.md') and not missing, (doc, missing)

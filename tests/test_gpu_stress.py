@@ -114,8 +114,8 @@ def test_forward_extreme_but_finite_inputs(fixture_cloud):
 def test_scans_beyond_the_reference_cap(name, n_pts):
     """raw scans larger than what make_pc_dataset.py:39 lets through (150,000 points) -- nothing in points_to_surf_eval /
     data_loader.py limits the cloud: 2,000,000 points for the uniform sub-sample; 185,000 and 470,000 for the
-    distance-weighted one (its per-query found-bitmap lives in LDS: up to 185,664 points next to the serial kernel's ring,
-    beyond that with the plain remainder kernel up to 475,040 points -- see the next tests).  kNN ids, radius, the
+    distance-weighted one (its per-query found-bitmap lives in the ids kernel's LDS: up to 475,040 points -- see the next
+    tests).  kNN ids, radius, the
     sub-sample (``randint`` draws / ``choice(p, replace=False)``), generator position and SDF of the GT-query pass
     against the oracle"""
     import torch
@@ -143,9 +143,9 @@ def test_scans_beyond_the_reference_cap(name, n_pts):
 
 
 @pytest.mark.parametrize('serial', [False, True])
-def test_weighted_subsample_of_a_300k_cloud_also_through_the_plain_serial_kernel(serial, monkeypatch):
-    """clouds beyond 185,664 points: the offsets pass behind the speculative chain is wc_offsets_plain_kernel (the whole
-    algorithm per query, in order); ``P2S_WC_SERIAL=1`` sends every query through it.  ids and stream position == numpy's
+def test_weighted_subsample_of_a_300k_cloud_also_in_order(serial, monkeypatch):
+    """a 300,000-point cloud through the speculative offsets pass and, with ``P2S_WC_SERIAL=1``, through the chain kernel's
+    in-order remainder path alone (the whole algorithm per query).  ids and stream position == numpy's
     ``choice(N, 1000, replace=False, p)`` as the oracle restates it"""
     import torch
     from oracle import p2s_oracle as O

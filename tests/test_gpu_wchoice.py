@@ -182,7 +182,8 @@ def test_rng_sessions_mixed_calls_match_numpy(fixture_cloud, torch_cuda):
 
 def test_speculative_offsets_across_blocks_match_numpy_and_serial_kernel(fixture_cloud, torch_cuda, monkeypatch):
     """the parallel offsets pass (wc_spec_kernel + wc_chain_kernel, blocks of 2048 queries) against numpy's stream for
-    4,300 consecutive grid queries (three blocks), and against the serial kernel (P2S_WC_SERIAL) including the skip path
+    4,300 consecutive grid queries (three blocks), and against the in-order path of the chain kernel (P2S_WC_SERIAL) including
+    the skip path
     (NULL ids: stream advanced only)"""
     from points2surf_amd import engine
     cloud = engine.Cloud(fixture_cloud)
@@ -210,7 +211,7 @@ def test_speculative_offsets_across_blocks_match_numpy_and_serial_kernel(fixture
 
 def test_weighted_at_the_size_cap(torch_cuda):
     """the clouds the weighted sub-sample takes (LDS bitmap of the in-place algorithm): 170,000 points work
-    and match numpy, 260,000 too since r04 (the plain remainder kernel behind the speculative chain); 480,000 are refused
+    and match numpy, 260,000 too; 480,000 are refused
     with an error code, not a wrong result (more sizes: tests/test_gpu_stress.py)"""
     from points2surf_amd import engine, _lib
     g = np.random.default_rng(17)
