@@ -13,12 +13,11 @@
 //    of 2^-52 below 2, i.e. EXACT.  np.cumsum (sequential) therefore equals a parallel scan in any order, and
 //    "zero the found entries and cumsum again" (iterations >= 2) equals S_i minus the found mass below i.
 //  * cdf_i = fl(S_i / S_N) and searchsorted(cdf, x, 'right') are evaluated with the same IEEE operations; a guide
-//    table over K ~ N buckets, R[b] = (i = #{cdf_i <= b/K}, S_{i-1}, S_i, S_{i+1}), answers most look-ups with one
-//    32-byte load.
+//    table over K ~ N buckets, R[b] = #{cdf_i <= b/K}, tells every look-up where to read S.
 //
 // Three stages per batch of queries:
 //   wc_tables_kernel   one workgroup per query, fully parallel: distances, max, plan-ordered sum, exact prefix sums
-//                      S[q][N] (float64), guide records R[q][K].  HBM-resident (288 GB: ~1.4 MB per query).
+//                      S[q][N] (float64), guide R[q][K].  HBM-resident (288 GB: ~0.5 MB per query).
 //   offsets pass       where every query's draws start in the stream -- the number of random words a query consumes
 //                      depends on its collisions, so the stream position is a true serial dependence: speculation
 //                      tables over candidate starts on all CUs (wc_spec_kernel), jump tables, one light chain
@@ -43,12 +42,13 @@ constexpr int WC_MAX_NODES = 8192;   // plan nodes held in LDS -> clouds up to 5
 constexpr int PW_BLOCK = 128;        // numpy PW_BLOCKSIZE
 constexpr int NP_BUFSIZE = 8192;     // numpy ufunc buffer size (np.getbufsize())
 
-// guide record of bucket b of the cdf (x in [b/K, (b+1)/K)):  i = #{cdf_j <= b/K} is the first candidate,
-// c0 = cdf_i.  x < c0 -> bin i; otherwise bin i+1 unless `more` (a second boundary may lie inside the bucket).
-struct __attribute__((aligned(16))) WcRec {
-    double c0;
-    int i, more;
-};
+// guide entry of bucket b of the cdf (x in [b/K, (b+1)/K)):  i = #{cdf_j <= b/K}, the first candidate -- a HINT: the look-up
+// (wc_finish) starts there and decides with the exact predicate on S_(i-1), S_i, S_(i+1), one round trip in all but the
+// rare buckets that hold three or more boundaries.  r05: 4 bytes per bucket.  Rounds 1-4 kept {cdf_i, i, more} = 16 bytes,
+// which decided 95 % of the first-round look-ups without touching S -- and made the tables kernel write 1 MB per query:
+// timing-only ablations (no divisions, no power sums, no S store) left its 2.85 ms per 4096 queries unchanged; it was
+// bound by those 4.3 GB of record writes.
+typedef int WcRec;
 
 struct WcPlanDev {
     const int *leaf;       // [L][3] start, len, node
@@ -302,13 +302,9 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
         }
         const double excl = base + (v - l4);          // S_{i0-1}
         const double sv[6] = {excl, excl + l1, excl + l2, excl + l3, excl + l4, (excl + l4) + p[4]};
-        double cd[6];
         int cc[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            cd[k] = sv[k] / Stot;                     // cdf value exactly as numpy computes it
-            cc[k] = (int)ceil(cd[k] * dK);            // first bucket whose lower edge is >= cdf
-        }
+        for (int k = 0; k < 6; ++k) cc[k] = (int)ceil((sv[k] / Stot) * dK);   // first bucket whose lower edge is >= cdf_k (as numpy divides)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int idx = i0 + j;
@@ -316,15 +312,7 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
                 S[idx] = sv[j + 1];
                 const int c = cc[j + 1];
                 const int ce = c < K ? c : K;
-                WcRec rec;
-                rec.c0 = cd[j + 1];
-                rec.i = idx;
-                rec.more = 0;
-                for (int b = cc[j]; b < ce; ++b) {
-                    // only the bucket that contains cdf_idx can hold further boundaries
-                    rec.more = (b == c - 1 && idx + 1 < n && cc[j + 2] == c) ? 1 : 0;
-                    R[b] = rec;
-                }
+                for (int b = cc[j]; b < ce; ++b) R[b] = idx;
             }
         }
         carry += total;
@@ -406,10 +394,6 @@ __device__ __forceinline__ WcLoc wc_finish(const double *__restrict__ Sq, int n,
         prev = sv;
     }
 #undef WC_PRED
-}
-// first-round shortcut: bin from the guide record alone (unmodified cdf), -1 if a second boundary must be checked
-__device__ __forceinline__ int wc_quick_bin(double c0, int i, int more, double x) {
-    return x < c0 ? i : (more ? -1 : i + 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -501,9 +485,7 @@ __device__ __forceinline__ long long wc_full_query(const WcQuery &qa, const WcLd
                 xs[j] = wc_double(wpair[j].x, wpair[j].y);
                 int bk = (int)(xs[j] * (double)qa.K);                 // the bucket of x itself
                 bk = bk > qa.K - 1 ? qa.K - 1 : bk;
-                const WcRec rec = qa.Rq[bk];
-                const int qb = wc_quick_bin(rec.c0, rec.i, rec.more, xs[j]);
-                st[j] = qb >= 0 ? qb : rec.i + 1;
+                st[j] = qa.Rq[bk];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -524,7 +506,7 @@ __device__ __forceinline__ long long wc_full_query(const WcQuery &qa, const WcLd
                     const uint2 wp = *(const uint2 *)(qa.words + o + 2LL * d);
                     const double x = wc_double(wp.x, wp.y);
                     const WcGap g = wc_gap(qa.n, qa.K, Stot, Stot_cur, x, m_found, l.sid, l.sV, l.sC);
-                    const WcLoc L = wc_finish(qa.Sq, qa.n, qa.Rq[g.bucket].i, g.lo, g.hi, g.Ck, Stot_cur, x);
+                    const WcLoc L = wc_finish(qa.Sq, qa.n, qa.Rq[g.bucket], g.lo, g.hi, g.Ck, Stot_cur, x);
                     bins[j] = L.bin;
                     sb[j] = L.s;
                     sp[j] = L.sprev;
@@ -990,9 +972,7 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
             if (e < nb) {
                 int bk = (int)(x * (double)a.K);
                 bk = bk > a.K - 1 ? a.K - 1 : bk;
-                const WcRec rec = Rq[bk];
-                bin = wc_quick_bin(rec.c0, rec.i, rec.more, x);
-                if (bin < 0) bin = wc_finish(Sq, a.n, rec.i + 1, 0, a.n, 0.0, Stot, x).bin;
+                bin = wc_finish(Sq, a.n, Rq[bk], 0, a.n, 0.0, Stot, x).bin;
             }
         }
         xs[e] = x;
@@ -1301,7 +1281,7 @@ __global__ __launch_bounds__(256) void wc_band_kernel(WcArgs a, WcSpec sp) {
                 } else {
                     int bk = (int)(x * (double)a.K);
                     bk = bk > a.K - 1 ? a.K - 1 : bk;
-                    i0 = Rq[bk].i;
+                    i0 = Rq[bk];
                 }
                 int same = 0;
                 const int b = wc_grp_bin(cd, Sq, a.n, Stot, x, xsb[d - blo + j2], i0, gl, gsh, &same);
