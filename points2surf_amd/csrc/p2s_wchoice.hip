@@ -371,9 +371,13 @@ __device__ __forceinline__ bool wc_gt(double S, double St, double x) {
 __device__ __forceinline__ WcLoc wc_finish(const double *__restrict__ Sq, int n, int i, int g_lo, int g_hi, double Ck,
                                            double Stot_cur, double x) {
     i = i < g_lo ? g_lo : (i > g_hi - 1 ? g_hi - 1 : i);
+    // ONE round trip decides the answers i .. i + 4 (a guide bucket holds one or two cdf boundaries on average; the six
+    // values sit in one or two 64-byte sectors); anything else walks, one dependent read per step
     double s_m1 = (i > 0) ? Sq[i - 1] : 0.0;
     double s_0 = Sq[i];
-    const double s_p1 = Sq[i + 1 < n ? i + 1 : n - 1];
+    double sp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sp[k] = Sq[i + 1 + k < n ? i + 1 + k : n - 1];
 #define WC_PRED(sv) wc_gt((sv)-Ck, Stot_cur, x)
     if (WC_PRED(s_0)) {
         while (i > g_lo && WC_PRED(s_m1)) {
@@ -383,9 +387,14 @@ __device__ __forceinline__ WcLoc wc_finish(const double *__restrict__ Sq, int n,
         }
         return {i, s_0, s_m1};
     }
-    if (WC_PRED(s_p1)) return {i + 1, s_p1, s_0};
-    i += 1;
-    double prev = s_p1;
+    double prev = s_0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i + 1 + k >= n) return {n - 1, prev, prev};       // unreachable for valid tables
+        if (WC_PRED(sp[k])) return {i + 1 + k, sp[k], prev};
+        prev = sp[k];
+    }
+    i += 4;
     for (;;) {
         ++i;
         if (i >= n) return {n - 1, prev, prev};       // unreachable for valid tables; keeps the loop finite
@@ -910,8 +919,8 @@ __device__ __forceinline__ int wc_grp_bin(const WcCand &c, const double *__restr
 // 255 = undecided (the chain runs the complete algorithm if the path gets there)
 constexpr unsigned SP_TENT = 128u, SP_UND = 255u;
 constexpr int SP_SAVE = 4 + SP_DMAX + SP_NB;         // ints per query handed from wc_spec_kernel to wc_band_kernel: ndup, dup list, bins
-constexpr int SP_BAND = 96;                          // candidates per query decided exactly: [path - 48, path + 48)
-constexpr int SP_BAND_LO = 48;
+constexpr int SP_BAND = 144;                         // candidates per query decided exactly: [path - 72, path + 72)
+constexpr int SP_BAND_LO = 72;
 
 __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
     __shared__ double xs[SP_NX];
@@ -1136,14 +1145,14 @@ __global__ __launch_bounds__(256) void wc_spec_kernel(WcArgs a, WcSpec sp) {
     for (int e = tid; e < nb; e += 256) sv[4 + SP_DMAX + e] = bins[e];
 }
 
-// The exact pass: the candidates of a query within [path - 48, path + 48) of where the tentative walk went through its
+// The exact pass: the candidates of a query within [path - 72, path + 72) of where the tentative walk went through its
 // window, if tentative, get their close round-2 pairs looked up in their own modified cdf.  The real path stays that close:
 // it leaves the tentative one by one double per pair that does share a bin (~1 % of the queries) and the two re-merge
 // within tens of queries (a start shifted by one draw loses one first-round draw and gains one, and the redraw counts
 // absorb the difference with ~5 % probability per query).  A path that does escape meets a tentative / undecided verdict
 // and the chain resolves that query itself.
 constexpr int BD_NP = SP_BAND + 2 * SP_LOOK;          // round-2 positions a band touches (+ look-ahead)
-constexpr int BD_PAIRS = 128, BD_TASKS = 256;
+constexpr int BD_PAIRS = 192, BD_TASKS = 384;
 __global__ __launch_bounds__(256) void wc_band_kernel(WcArgs a, WcSpec sp) {
     __shared__ int bins[SP_NB];
     __shared__ int dl[SP_DMAX];
@@ -1335,9 +1344,12 @@ __global__ __launch_bounds__(256) void wc_band_kernel(WcArgs a, WcSpec sp) {
 // the path passes every query's window (sp.dtil) for wc_band_kernel and commits nothing.
 // last != 0: the final launch of a request -- whatever is unresolved behind its block goes through the complete algorithm,
 // query by query.  serial != 0 (development / tests: P2S_WC_SERIAL): no speculation at all, every query that way.
-__global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp, int last, int serial, int tentative) {
-    // Small on purpose (8.7 KB of LDS): next to the encoders the kernel must fit the slot ONE retiring encoder workgroup frees.
-    // The complete algorithm's arrays (rare since r05: undecided candidates, the remainder) live in global memory here.
+// lds_arrays != 0: the launch carries wc_lds_bytes(n) of dynamic LDS for the complete algorithm's arrays (stream skipping: the
+// chip is idle, 23 us per query); 0: they live in global memory (60 us per query) and the kernel keeps 8.7 KB of LDS.
+__global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp, int last, int serial, int tentative, int lds_arrays) {
+    // Small on purpose: next to the encoders the kernel must fit the slot ONE retiring encoder workgroup frees.  The complete
+    // algorithm runs rarely since r05 (undecided candidates: more than 64 first-round collisions, the remainder).
+    extern __shared__ __attribute__((aligned(16))) unsigned char wc_lds[];
     __shared__ int wsum[16];
     __shared__ double wsumd[16];
     __shared__ long long s_ev[3];
@@ -1349,7 +1361,7 @@ __global__ __launch_bounds__(256) void wc_chain_kernel(WcArgs a, WcSpec sp, int 
     const int tid = threadIdx.x;
     const long long qb = sp.ctl[0];
     if (qb >= a.nq) return;
-    const WcLds l = wc_carve(sp.scratch, a.n);
+    const WcLds l = wc_carve(lds_arrays ? wc_lds : sp.scratch, a.n);
     const int BW = (a.n + 31) >> 5;
     if (!tentative)
         for (int i = tid; i < BW; i += 256) l.bitmap[i] = 0;
@@ -1748,8 +1760,10 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     p2s_cloud_note_stream(c, s);
     int rc = wc_build_plan(c);
     if (rc) return rc;
+    // guide buckets: a power of two in (n / 2, n] -- one to two cdf boundaries per bucket, all decided by the look-up's one
+    // read of S (wc_finish); twice as many buckets (rounds 1-4) only make the tables kernel write more
     int K = 1024;
-    while (K < n) K <<= 1;
+    while (2 * K < n) K <<= 1;
     // queries per batch (table memory: ~1.4 MB per query at 50k points); random words come from the raw session
     long long per_req = 4096;
     const long long req_env = getenv("P2S_WCHOICE_QUERIES") ? atoll(getenv("P2S_WCHOICE_QUERIES")) : 0;   // tests
@@ -1792,7 +1806,11 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     sp.scratch = (unsigned char *)(((uintptr_t)(sp.save + (size_t)SP_B * SP_SAVE) + 63) & ~(uintptr_t)63);
     sp.jump = r->wc_J;
     const bool serial_only = getenv("P2S_WC_SERIAL") != nullptr;   // development / tests: every query through the in-order remainder path
+    // stream skipping (no ids wanted): nothing else runs on the chip, the chain kernel may take the LDS the complete algorithm
+    // likes; next to the encoders (ids wanted) it must stay small
+    const size_t skip_lds = ids_out_dev ? 0 : lds_ids;
     {   // per device (a process may drive several); the call is cheap
+        (void)hipFuncSetAttribute((const void *)wc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 146 * 1024);
         (void)hipFuncSetAttribute((const void *)wc_ids_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute((const void *)wc_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (NP_BUFSIZE + WC_MAX_NODES) * 4);
     }
@@ -1841,7 +1859,7 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
             // no serial dependence between the queries: the ids kernel alone (it reports the last query's consumption)
         } else if (serial_only) {
             hipLaunchKernelGGL(wc_ctl_init_kernel, dim3(1), dim3(1), 0, s, sp.ctl, meta);
-            hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), 0, s, a, sp, 1, 1, 0);
+            hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), skip_lds, s, a, sp, 1, 1, 0, skip_lds ? 1 : 0);
         } else {
             // per block of SP_B queries: speculation tables on all CUs (tentative where round-2 draws lie close together), the
             // tentative walk to find out where the path runs, the exact decision for the candidates near it, the walk.  One
@@ -1857,10 +1875,10 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
             for (int pr = 0; pr < rounds; ++pr) {
                 hipLaunchKernelGGL(wc_spec_kernel, dim3(blk), dim3(256), 0, s, a, sp);
                 jumps();
-                hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), 0, s, a, sp, 0, 0, 1);
+                hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), 0, s, a, sp, 0, 0, 1, 0);
                 hipLaunchKernelGGL(wc_band_kernel, dim3(blk), dim3(256), 0, s, a, sp);
                 jumps();
-                hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), 0, s, a, sp, pr == rounds - 1 ? 1 : 0, 0, 0);
+                hipLaunchKernelGGL(wc_chain_kernel, dim3(1), dim3(256), skip_lds, s, a, sp, pr == rounds - 1 ? 1 : 0, 0, 0, skip_lds ? 1 : 0);
             }
         }
         if (ids_out_dev) hipLaunchKernelGGL(wc_ids_kernel, dim3(cur), dim3(256), lds_ids, s, a);   // NULL: advance the stream only
