@@ -36,6 +36,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef P2S_BF16_MT
 #define P2S_BF16_MT 64
@@ -118,30 +119,35 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[NS]
 constexpr float F16_LIMIT = 6.0e4f;       // |activation| beyond this does not fit fp16 (max 65504)
 constexpr float F16_SCALE = 1.0f / 2048.0f;
 
-// acc (+ bias, ReLU) -> pieces into buf[p][row0 + r][col0 + c].  fp16 pair: the value is acc[0] + acc[1] * 2^-11
+// Small layers run TRANSPOSED: D = W^T X^T, the weight fragment is the MFMA's first operand and the activation fragment the
+// second (the register contents of an A and a B fragment are the same: 8 consecutive k of row / column l & 31), so a lane's
+// 16 results are ONE point (l & 31) and four groups of 4 consecutive channels, (i & 3) + 8 (i >> 2) + 4 (l >> 5): in the
+// [point][channel] tile that is one 8-byte store per group and piece (4 x ds_write_b64 instead of 16 x ds_write_b16 per
+// piece; 272- / 144-byte rows: the 64 lanes of a store cover every bank twice).
+// acc (+ bias, ReLU) -> pieces into buf[p][pt0 + point][ch0 + channel].  fp16 pair: the value is acc[0] + acc[1] * 2^-11
 template <int NS, bool F16>
-__device__ __forceinline__ void store_tile(const f32x16 (&acc)[F16 ? 2 : 1], unsigned short *buf, int H, int pstride, int row0, int col0,
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[F16 ? 2 : 1], unsigned short *buf, int H, int pstride, int pt0, int ch0,
                                            const float *__restrict__ bias, int lane, bool &range_bad) {
-    const int c = col0 + (lane & 31);
-    const float b = bias[c];
-    unsigned short *dst = buf + (row0 + 4 * (lane >> 5)) * H + c;
+    unsigned short *dst = buf + (pt0 + (lane & 31)) * H + ch0 + 4 * (lane >> 5);
+    const float *bsrc = bias + ch0 + 4 * (lane >> 5);
 #pragma unroll
-    for (int i = 0; i < 16; i += 2) {
-        const int r = (i & 3) + 8 * (i >> 2);             // rows r and r + 1
-        float v0 = acc[0][i], v1 = acc[0][i + 1];
-        if (F16) {
-            v0 += acc[F16 ? 1 : 0][i] * F16_SCALE;
-            v1 += acc[F16 ? 1 : 0][i + 1] * F16_SCALE;
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(bsrc + 8 * g);
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            v[t] = acc[0][4 * g + t];
+            if (F16) v[t] = fmaf(acc[F16 ? 1 : 0][4 * g + t], F16_SCALE, v[t]);
+            v[t] = fmaxf(v[t] + b[t], 0.0f);
+            if (F16) range_bad = range_bad || v[t] > F16_LIMIT;
         }
-        v0 = fmaxf(v0 + b, 0.0f);
-        v1 = fmaxf(v1 + b, 0.0f);
-        if (F16) range_bad = range_bad || v0 > F16_LIMIT || v1 > F16_LIMIT;
-        unsigned u[NS];
-        split_pair<NS, F16>(v0, v1, u);
+        unsigned lo[NS], hi[NS];
+        split_pair<NS, F16>(v[0], v[1], lo);
+        split_pair<NS, F16>(v[2], v[3], hi);
 #pragma unroll
         for (int p = 0; p < NS; ++p) {
-            dst[p * pstride + r * H] = (unsigned short)u[p];
-            dst[p * pstride + (r + 1) * H] = (unsigned short)(u[p] >> 16);
+            const u32x2 w = {lo[p], hi[p]};
+            *reinterpret_cast<u32x2 *>(dst + p * pstride + 8 * g) = w;
         }
     }
 }
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? (S
                             const u32x4 a = lds_a(bufA + p * SA, HA, 32 * (rt + 2 * r), kb, lane);
 #pragma unroll
                             for (int q = NS - 1 - p; q >= 0; --q)
-                                acc[r][F16 ? p + q : 0] = mfma_bf16<F16>(a, b[q], acc[r][F16 ? p + q : 0]);
+                                acc[r][F16 ? p + q : 0] = mfma_bf16<F16>(b[q], a, acc[r][F16 ? p + q : 0]);   // transposed: channels x points
                         }
                 }
 #pragma unroll
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? (S
                             const u32x4 a = lds_a(bufB + p * SB, HB, 32 * (rt + 2 * r), kb, lane);
 #pragma unroll
                             for (int q = NS - 1 - p; q >= 0; --q)
-                                acc[r][F16 ? p + q : 0] = mfma_bf16<F16>(a, b[q], acc[r][F16 ? p + q : 0]);
+                                acc[r][F16 ? p + q : 0] = mfma_bf16<F16>(b[q], a, acc[r][F16 ? p + q : 0]);   // transposed: channels x points
                         }
                 }
 #pragma unroll
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? (S
                         const u32x4 a = lds_a(bufA + p * SA, HA, 32 * r, kb, lane);
 #pragma unroll
                         for (int q = NS - 1 - p; q >= 0; --q)
-                            acc[r][F16 ? p + q : 0] = mfma_bf16<F16>(a, b[q], acc[r][F16 ? p + q : 0]);
+                            acc[r][F16 ? p + q : 0] = mfma_bf16<F16>(b[q], a, acc[r][F16 ? p + q : 0]);   // transposed: channels x points
                     }
             }
 #pragma unroll
@@ -399,8 +405,15 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? (S
 #pragma unroll
                     for (int r = 0; r < NB; ++r)
 #pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            m = fmaxf(m, F16 ? acc[r][0][i] + acc[r][F16 ? 1 : 0][i] * F16_SCALE : acc[r][0][i]);
+                        for (int i = 0; i < 16; i += 2) {
+                            f32x2 v = {acc[r][0][i], acc[r][0][i + 1]};
+                            if (F16) {                    // one v_pk_fma_f32 per pair, one v_max3_f32 per pair
+                                const f32x2 lo = {acc[r][F16 ? 1 : 0][i], acc[r][F16 ? 1 : 0][i + 1]};
+                                const f32x2 sc = {F16_SCALE, F16_SCALE};
+                                v = __builtin_elementwise_fma(lo, sc, v);
+                            }
+                            m = fmaxf(fmaxf(m, v[0]), v[1]);
+                        }
                     m = fmaxf(m, __shfl_xor(m, 32));
                     rmax[ct] = fmaxf(rmax[ct], m);
                 }
