@@ -10,7 +10,8 @@ import sys
 tag, out = sys.argv[1], sys.argv[2]
 src = os.path.join('gpurun_out', 'prof_' + tag)
 os.makedirs(out, exist_ok=True)
-shutil.copy(os.path.join(src, 'trace', 'bench_kernel_stats.csv'), os.path.join(out, 'bench_kernel_stats.csv'))
+if os.path.isfile(os.path.join(src, 'trace', 'bench_kernel_stats.csv')):
+    shutil.copy(os.path.join(src, 'trace', 'bench_kernel_stats.csv'), os.path.join(out, 'bench_kernel_stats.csv'))
 if os.path.isfile(os.path.join(src, 'counters_available.txt')):
     shutil.copy(os.path.join(src, 'counters_available.txt'), os.path.join(out, 'counters_available.txt'))
 for sub, name in (('trace_vanilla', 'vanilla_kernel_stats.csv'), ('trace_bf16x3', 'bf16x3_kernel_stats.csv'),
@@ -27,6 +28,8 @@ for log, name in (('trace_stdout.log', 'bench_profiled.json'), ('bf16x3_stdout.l
 raw, rows = {}, []
 for name in sorted(d for d in os.listdir(src) if d.startswith('pmc') and os.path.isdir(os.path.join(src, d))):
     acc = collections.defaultdict(list)
+    if not os.path.isfile(os.path.join(src, name, 'pmc_counter_collection.csv')):      # a counter name this rocprofv3 does not know
+        continue
     for r in csv.DictReader(open(os.path.join(src, name, 'pmc_counter_collection.csv'))):
         k = r['Kernel_Name']
         if 'p2s_' not in k:
@@ -38,6 +41,10 @@ for name in sorted(d for d in os.listdir(src) if d.startswith('pmc') and os.path
         short = short.replace('chain_bf16_kernel<2, true, false, false>', 'chain_bf16_kernel<2, true>') \
                      .replace('chain_bf16_kernel<3, false, false, false>', 'chain_bf16_kernel<3, false>') \
                      .replace('chain_bf16_kernel<1, false, false, false>', 'chain_bf16_kernel<1>')
+        # r05: template <NS, F16, SUM>
+        short = {'chain_bf16_kernel<2, true, false>': 'chain_bf16_kernel<2, true>',
+                 'chain_bf16_kernel<3, false, false>': 'chain_bf16_kernel<3, false>',
+                 'chain_bf16_kernel<1, false, false>': 'chain_bf16_kernel<1>'}.get(short, short)
         acc[(short, r['Counter_Name'])].append(float(r['Counter_Value']))
         rows.append([name, short, r['Dispatch_Id'], r['Grid_Size'], r['Workgroup_Size'], r['LDS_Block_Size'],
                      r['VGPR_Count'], r['Accum_VGPR_Count'], r['SGPR_Count'], r['Counter_Name'], r['Counter_Value'],
