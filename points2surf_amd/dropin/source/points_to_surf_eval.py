@@ -418,10 +418,17 @@ def points_to_surf_eval(eval_opt):
                 cloud.close()
                 if handoff is not None:
                     handoff.done(shape_ind)
-        for f in pending:
-            f.result()                     # re-raise writer errors; everything is on disk when we return
-        writers.shutdown(wait=True)
+        try:
+            for f in pending:
+                f.result()                 # re-raise writer errors; everything is on disk when we return
+            writers.shutdown(wait=True)
+        except BaseException as e:
+            if handoff is not None:
+                handoff.fail(len(shape_names), e)          # a writer error is this rank's failure too: peers raise in finish()
+            raise
         dt = time.time() - t0
+        if handoff is not None:
+            handoff.finish()               # every rank is through, or raises with the record of the one that failed
         _sharding.barrier()                # no-op without a process group
         if shard_queries:
             # every piece is on disk (barrier): rank r takes the shapes i = r mod world first; the claim is atomic,

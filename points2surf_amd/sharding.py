@@ -192,6 +192,7 @@ class StreamHandoff:
                     h.publish_after(i, rngs, advance)        # advance(k): consume shape k's draws (skip_shape_stream)
                 ... infer shape i with rngs ...
                 h.done(i)
+        h.finish()                                           # all ranks through, or the failure of one of them raised here
 
     ``rngs``: list of engine.Rng (the sub-sample generator; fixed-radius models add the patch-choice generator).
     Consecutive shapes of one owner: the token for the next FOREIGN shape j is published as soon as the first of them
@@ -316,6 +317,33 @@ class StreamHandoff:
 
     def done(self, i):
         self.at = i + 1
+
+    def finish(self):
+        """after a rank's last shape, before the closing collective: returns when every rank has got here, raises when one
+        left a failure record instead -- a plain barrier would sit out the process group's time-out on a rank that raised
+        after the others were through with their shapes"""
+        import time
+        world = max(self.owner) + 1 if self.owner else 1
+        try:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                world = dist.get_world_size()
+        except Exception:
+            pass
+        self.store.set('p2s/stream/%s/finished/%d' % (self.tag, self.rank), b'1')
+        keys = ['p2s/stream/%s/finished/%d' % (self.tag, r) for r in range(world)]
+        t0, nap = time.time(), 0.001
+        while not self.store.check(keys):
+            why = self.failed()
+            if why is not None:
+                raise RuntimeError('stream hand-off (%s): rank %d is through with its shapes, but %s' % (self.tag, self.rank, why))
+            if time.time() - t0 > self.timeout_s:
+                raise TimeoutError('stream hand-off (%s): not every rank finished within %.0f s' % (self.tag, self.timeout_s))
+            time.sleep(nap)
+            nap = min(nap * 1.5, self.poll_s)
+        why = self.failed()
+        if why is not None:
+            raise RuntimeError('stream hand-off (%s): %s' % (self.tag, why))
 
 
 def stream_handoff_enabled():

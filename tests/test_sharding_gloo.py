@@ -138,6 +138,7 @@ def _handoff_worker(rank, world, port, outdir):
             h.done(i)
     np.save(os.path.join(outdir, 'seen_%d.npy' % rank), np.array([[k] + list(v) for k, v in seen.items()], dtype=np.int64))
     np.save(os.path.join(outdir, 'pub_%d.npy' % rank), np.array(sorted(published_at.items()), dtype=np.int64).reshape(-1, 2))
+    h.finish()                                        # every rank is through: returns
     sharding.barrier()
     dist.destroy_process_group()
 
@@ -210,3 +211,47 @@ def test_stream_handoff_failure_reaches_the_waiting_ranks(tmp_path):
         assert out[r][1].startswith('raised RuntimeError: stream hand-off (failing)'), out[r]
         assert 'rank 1 failed at shape 1' in out[r][1] and 'injected failure' in out[r][1]
         assert out[r][0] < 30.0, out[r]
+
+
+def _handoff_late_failure_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    sharding.init_process_group('gloo')
+    a = _FakeRng(7)
+    h = sharding.StreamHandoff('late', [0, 1], rank=rank, timeout_s=120.0)
+    t0 = time.time()
+    what = 'finished'
+    try:
+        for i in [k for k, o in enumerate(h.owner) if o == rank]:
+            with h.guard(i):
+                h.begin(i, [a])
+                if h.must_publish(i):
+                    h.publish_after(i, [a], lambda k: a.consume(DRAWS[k]))
+                if rank == 1:
+                    time.sleep(1.0)                      # rank 0 is through with its only shape by now
+                    raise ValueError('injected late failure')
+                a.consume(DRAWS[i])
+                h.done(i)
+        h.finish()
+    except ValueError as e:
+        what = 'raised ValueError: %s' % e
+    except RuntimeError as e:
+        what = 'raised RuntimeError: %s' % e
+    with open(os.path.join(outdir, 'late_%d.txt' % rank), 'w') as f:
+        f.write('%.2f\n%s\n' % (time.time() - t0, what))
+    dist.destroy_process_group()
+
+
+def test_stream_handoff_finish_raises_on_a_rank_that_failed_after_the_others_were_done(tmp_path):
+    """a rank that is through with its shapes does not walk into the closing barrier while another rank has failed (it would
+    sit out the process group's time-out there): StreamHandoff.finish polls the failure record"""
+    port = _free_port()
+    mp.spawn(_handoff_late_failure_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    out = {}
+    for r in range(2):
+        with open(os.path.join(str(tmp_path), 'late_%d.txt' % r)) as f:
+            secs, what = f.read().split('\n')[:2]
+        out[r] = (float(secs), what)
+    assert out[1][1].startswith('raised ValueError: injected late failure')
+    assert out[0][1].startswith('raised RuntimeError: stream hand-off (late): rank 0 is through with its shapes, but rank 1 failed at shape 1'), out[0]
+    assert out[0][0] < 30.0
