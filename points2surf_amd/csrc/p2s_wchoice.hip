@@ -13,7 +13,8 @@
 //    of 2^-52 below 2, i.e. EXACT.  np.cumsum (sequential) therefore equals a parallel scan in any order, and
 //    "zero the found entries and cumsum again" (iterations >= 2) equals S_i minus the found mass below i.
 //  * cdf_i = fl(S_i / S_N) and searchsorted(cdf, x, 'right') are evaluated with the same IEEE operations; a guide
-//    table over K ~ N buckets, R[b] = #{cdf_i <= b/K}, tells every look-up where to read S.
+//    table over K ~ N buckets, R[b] ~ #{S_i <= b/K}, tells every look-up where to START reading S (a hint: the decision is
+//    always taken on S itself, walking either way if the hint is off).
 //
 // Three stages per batch of queries:
 //   wc_tables_kernel   one workgroup per query, fully parallel: distances, max, plan-ordered sum, exact prefix sums
@@ -136,7 +137,6 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
     float *pcs = wc_tab_lds;                       // [NP_BUFSIZE] clipped probabilities of one numpy buffer chunk
     float *nodes = wc_tab_lds + NP_BUFSIZE;        // [plan.n_nodes]
     __shared__ float red_f[4];
-    __shared__ double red_d[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = blockIdx.x;
     double *S = S_all + (size_t)qi * n;
@@ -217,60 +217,15 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
         dsum_all[2 * qi + 1] = sum;
     }
 
-    // pass 3: p_i = pc_i / sum (float32) -> the total mass S_N (exact in any order), power sums, max
-    double acc = 0.0, acc2 = 0.0, acc3 = 0.0;
-    float pm = 0.0f;
-    for (int t0 = 0; t0 < n; t0 += 1024 * WC_BATCH) {
-        float d[WC_BATCH][4];
-#pragma unroll
-        for (int u = 0; u < WC_BATCH; ++u) wc_dist4(pts, n, t0 + 1024 * u + 4 * tid, qx, qy, qz, d[u]);
-#pragma unroll
-        for (int u = 0; u < WC_BATCH; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (t0 + 1024 * u + 4 * tid + j < n) {
-                    const float pi = wc_clip_prob(d[u][j], dmax) / sum;
-                    acc += (double)pi;
-                    acc2 += (double)pi * (double)pi;              // power sums: expected collisions of the first round (below)
-                    acc3 += (double)pi * (double)pi * (double)pi;
-                    pm = fmaxf(pm, pi);
-                }
-            }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        acc += __shfl_xor(acc, off);
-        acc2 += __shfl_xor(acc2, off);
-        acc3 += __shfl_xor(acc3, off);
-        pm = fmaxf(pm, __shfl_xor(pm, off));
-    }
-    __shared__ double red_2[4], red_3[4];
-    if (lane == 0) {
-        red_d[wave] = acc;
-        red_2[wave] = acc2;
-        red_3[wave] = acc3;
-        red_f[wave] = pm;
-    }
-    __syncthreads();
-    const double Stot = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
-    if (tid == 0) {
-        // E[nsel - #distinct bins of nsel draws] = C(nsel,2) sum p^2 - C(nsel,3) sum p^3 + ...: where the speculation
-        // windows of the offsets pass are centred (a prediction only -- never part of the result)
-        const double s2 = ((red_2[0] + red_2[1]) + (red_2[2] + red_2[3])) / (Stot * Stot);
-        const double s3 = ((red_3[0] + red_3[1]) + (red_3[2] + red_3[3])) / (Stot * Stot * Stot);
-        const double ns = (double)nsel;
-        mu_all[qi] = (float)(0.5 * ns * (ns - 1.0) * s2 - ns * (ns - 1.0) * (ns - 2.0) / 6.0 * s3);
-    }
-    if (tid == 0) {
-        pmax_all[2 * qi] = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));     // widest bin of the cdf x S_N
-        pmax_all[2 * qi + 1] = 0.0f;
-    }
-    __syncthreads();                                  // red_d is reused by the scan below
-
-    // pass 4: prefix sums + guide records, tiles of 1024 elements (4 consecutive per lane + the first of the next
-    // lane); the distances of the next tile are in flight while this one is scanned
+    // pass 3: p_i = pc_i / sum (float32): prefix sums + guide, tiles of 1024 elements (4 consecutive per lane + the first of
+    // the next lane); the distances of the next tile are in flight while this one is scanned.  The same pass collects the
+    // power sums and the widest bin (r05: they had a pass of their own, 30 % of the kernel's instructions, only because the
+    // guide wanted the total mass S_N up front -- the guide is a hint, every look-up decides on S itself (wc_finish), so
+    // its buckets are cut at cdf ~ S_i instead of S_i / S_N: S_N = 1 to ~1e-6, less than a bucket at any cloud size).
     const double dK = (double)K;
     double carry = 0.0;
+    double acc2 = 0.0, acc3 = 0.0;
+    float pm = 0.0f;
     __shared__ double red_p4[2][4];
     float dn[5];
     wc_dist4(pts, n, 4 * tid, qx, qy, qz, (float(&)[4])dn);
@@ -279,7 +234,15 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
         const int i0 = t0 + 4 * tid;
         double p[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) p[j] = (i0 + j < n) ? (double)(wc_clip_prob(dn[j], dmax) / sum) : 0.0;
+        for (int j = 0; j < 5; ++j) {
+            const float pf = (i0 + j < n) ? wc_clip_prob(dn[j], dmax) / sum : 0.0f;
+            p[j] = (double)pf;
+            if (j < 4) {
+                acc2 += p[j] * p[j];                               // power sums: expected collisions of the first round (below)
+                acc3 += p[j] * p[j] * p[j];
+                pm = fmaxf(pm, pf);
+            }
+        }
         if (t0 + 1024 < n) {
             wc_dist4(pts, n, i0 + 1024, qx, qy, qz, (float(&)[4])dn);
             dn[4] = i0 + 1028 < n ? wc_dist1(pts, i0 + 1028, qx, qy, qz) : 0.0f;
@@ -304,18 +267,43 @@ __global__ __launch_bounds__(256) void wc_tables_kernel(const float *__restrict_
         const double sv[6] = {excl, excl + l1, excl + l2, excl + l3, excl + l4, (excl + l4) + p[4]};
         int cc[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) cc[k] = (int)ceil((sv[k] / Stot) * dK);   // first bucket whose lower edge is >= cdf_k (as numpy divides)
+        for (int k = 0; k < 6; ++k) cc[k] = (int)ceil(sv[k] * dK);            // first bucket whose lower edge is >= S_k
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int idx = i0 + j;
             if (idx < n) {
                 S[idx] = sv[j + 1];
                 const int c = cc[j + 1];
-                const int ce = c < K ? c : K;
+                const int ce = (c < K && idx < n - 1) ? c : K;               // the last id takes every bucket that is left
                 for (int b = cc[j]; b < ce; ++b) R[b] = idx;
             }
         }
         carry += total;
+    }
+    const double Stot = carry;                        // S_N, exact in any order (every thread holds it)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        acc2 += __shfl_xor(acc2, off);
+        acc3 += __shfl_xor(acc3, off);
+        pm = fmaxf(pm, __shfl_xor(pm, off));
+    }
+    __shared__ double red_2[4], red_3[4];
+    __syncthreads();                                  // red_f: every wave is past dmax
+    if (lane == 0) {
+        red_2[wave] = acc2;
+        red_3[wave] = acc3;
+        red_f[wave] = pm;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // E[nsel - #distinct bins of nsel draws] = C(nsel,2) sum p^2 - C(nsel,3) sum p^3 + ...: where the speculation
+        // windows of the offsets pass are centred (a prediction only -- never part of the result)
+        const double s2 = ((red_2[0] + red_2[1]) + (red_2[2] + red_2[3])) / (Stot * Stot);
+        const double s3 = ((red_3[0] + red_3[1]) + (red_3[2] + red_3[3])) / (Stot * Stot * Stot);
+        const double ns = (double)nsel;
+        mu_all[qi] = (float)(0.5 * ns * (ns - 1.0) * s2 - ns * (ns - 1.0) * (ns - 2.0) / 6.0 * s3);
+        pmax_all[2 * qi] = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));     // widest bin of the cdf x S_N
+        pmax_all[2 * qi + 1] = 0.0f;
     }
     if (tid == 0) stot_all[qi] = Stot;
 }
