@@ -1749,10 +1749,10 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
     int rc = wc_build_plan(c);
     if (rc) return rc;
     // guide buckets: a power of two in (n / 2, n] -- one to two cdf boundaries per bucket, all decided by the look-up's one
-    // read of S (wc_finish); twice as many buckets (rounds 1-4) only make the tables kernel write more
+    // read of S (wc_finish); twice as many buckets (as until r04) only make the tables kernel write more
     int K = 1024;
     while (2 * K < n) K <<= 1;
-    // queries per batch (table memory: ~1.4 MB per query at 50k points); random words come from the raw session
+    // queries per batch (table memory: 8 n + 4 K bytes per query, ~0.6 MB at 50k points); random words come from the raw session
     long long per_req = 4096;
     const long long req_env = getenv("P2S_WCHOICE_QUERIES") ? atoll(getenv("P2S_WCHOICE_QUERIES")) : 0;   // tests
     if (req_env > 0) per_req = std::min<long long>(req_env, 16384);
