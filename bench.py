@@ -517,6 +517,9 @@ def main():
     acc = {}
     run_block(0, args.warmup * world, False)
     barrier()
+    clocks = ClockSampler(torch.cuda.current_device()) if rank == 0 else None        # sysfs reads on a thread: not in the way
+    if clocks is not None:
+        clocks.start()
     t0 = time.time()
     mine_timed = run_block(args.warmup * world, n_rounds * world, True)
     n_queries = sum(int(o[0].shape[0]) for o in mine_timed)
@@ -531,6 +534,7 @@ def main():
             gathered = sum(int(p_.shape[0]) for p_ in parts)
     barrier()
     dt = time.time() - t0
+    device_clock = clocks.stop() if clocks is not None else None
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -604,7 +608,8 @@ def main():
                          'kernel': 'p2s_chain_bf16_kernel' if bf16 else 'p2s_chain_kernel', 'launches': int(launches), 'avg_launch_ms': avg_launch_ms,
                          'algorithmic_flop_per_launch': flop_per_launch, 'mfma_passes_per_product': passes,
                          'whole_step_frac': value / world * flop['total'] * passes / 1e12 / peak,
-                         'hbm_algorithmic_GBps': value / world * BYTES_PER_QUERY / 1e9},
+                         'hbm_algorithmic_GBps': value / world * BYTES_PER_QUERY / 1e9,
+                         'device_clock_rank0': device_clock},
             'stage_ms_rank0': stage,
         }
 
@@ -711,6 +716,70 @@ def main():
         dist.destroy_process_group()
 
 
+class ClockSampler:
+    """Shader clock and socket power of the device while a timed region runs, read from the amdgpu hwmon files of the PCI device
+    torch reports for it (freq1_input = sclk in Hz, power1_input in microwatt) by a thread every ~20 ms.  Explains box-to-box
+    spread: under 16-bit MFMA load the sustained clock differs by ~10 % between boxes (profiles/README.md).  Measurement side
+    only; ``region()`` returns None where the files do not exist."""
+
+    def __init__(self, device=0, hwmon=None):
+        self.freq, self.power = None, None
+        try:
+            if hwmon is None:
+                import glob
+                import torch
+                pr = torch.cuda.get_device_properties(device)
+                dev = '/sys/bus/pci/devices/%04x:%02x:%02x.0' % (int(getattr(pr, 'pci_domain_id', 0)), int(pr.pci_bus_id),
+                                                                 int(getattr(pr, 'pci_device_id', 0)))
+                cand = sorted(glob.glob(os.path.join(dev, 'hwmon', 'hwmon*')))
+                hwmon = cand[0] if cand else None
+            if hwmon and os.path.isfile(os.path.join(hwmon, 'freq1_input')):
+                self.freq = os.path.join(hwmon, 'freq1_input')
+                if os.path.isfile(os.path.join(hwmon, 'power1_input')):
+                    self.power = os.path.join(hwmon, 'power1_input')
+        except Exception:
+            self.freq = None
+        self._t, self._stop, self._f, self._p = None, False, [], []
+
+    @staticmethod
+    def _read(path):
+        with open(path) as f:
+            return float(f.read().strip())
+
+    def _loop(self):
+        while not self._stop:
+            try:
+                self._f.append(self._read(self.freq))
+                if self.power:
+                    self._p.append(self._read(self.power))
+            except Exception:
+                pass
+            time.sleep(0.02)
+
+    def start(self):
+        if self.freq is None:
+            return
+        import threading
+        self._stop, self._f, self._p = False, [], []
+        self._t = threading.Thread(target=self._loop, daemon=True)
+        self._t.start()
+
+    def stop(self):
+        """mean / min shader clock (MHz) and mean power (W) since start(); None without samples"""
+        if self._t is None:
+            return None
+        self._stop = True
+        self._t.join()
+        self._t = None
+        if not self._f:
+            return None
+        out = {'sclk_MHz_mean': sum(self._f) / len(self._f) * 1e-6, 'sclk_MHz_min': min(self._f) * 1e-6, 'samples': len(self._f),
+               'source': self.freq}
+        if self._p:
+            out['power_W_mean'] = sum(self._p) / len(self._p) * 1e-6
+        return out
+
+
 def secondary_block(args, engine, parity, synth, sharding, shapes, headline_value, check, bail):
     """N = 1: per entry ONE warm-up and ``--secondary-reps`` timed complete shapes of the test shape (a fresh cloud handle per
     shape, ONE generator handle re-seeded before each: nothing is allocated inside a timed shape), the median with all
@@ -731,6 +800,8 @@ def secondary_block(args, engine, parity, synth, sharding, shapes, headline_valu
         complete_shape(engine, m2, fixture, r2, args.res, args.chunk)       # warm-up: every buffer of the pass exists now
         torch.cuda.synchronize()
         runs = []
+        clocks = ClockSampler()
+        clocks.start()
         for _ in range(reps):
             reseed(r2)
             ev2 = {}
@@ -742,6 +813,7 @@ def secondary_block(args, engine, parity, synth, sharding, shapes, headline_valu
             st = {k: v for k, v in cnt.items() if k.startswith('ms_')}
             st.update({k: float(v[0]) for k, v in ev2.items()})
             runs.append((d2, st, int(cnt['launches_chain']), s2))
+        clk = clocks.stop()
         order = sorted(range(reps), key=lambda i: runs[i][0])
         d2, st, launches, s2 = runs[order[reps // 2]]
         chain_ms = st.get('ms_chain_stn', 0.0) + st.get('ms_chain_main', 0.0) + st.get('ms_chain_qstn', 0.0)
@@ -751,7 +823,8 @@ def secondary_block(args, engine, parity, synth, sharding, shapes, headline_valu
                 'timed_shapes': reps, 'statistic': 'median',
                 'model': mname, 'dtype': DTYPE[enc],
                 'workload': 'one complete shape (host to host) of the abc_minimal test shape at %d^3' % args.res,
-                'chain_ms': chain_ms, 'chain_launches': launches, 'non_chain_ms': d2 * 1e3 - chain_ms, 'stage_ms': st}
+                'chain_ms': chain_ms, 'chain_launches': launches, 'non_chain_ms': d2 * 1e3 - chain_ms, 'stage_ms': st,
+                'device_clock': clk}
         t_inf[key] = d2
         if os.path.isfile(gfile):
             ref2 = np.load(gfile)['rec_0']

@@ -73,3 +73,24 @@ def test_launcher_uses_all_visible_devices_by_default(tmp_path, monkeypatch):
         monkeypatch.delenv(k, raising=False)
     assert run.main([str(script)]) == 0
     assert (tmp_path / 'rank_0').read_text() == '2' and (tmp_path / 'rank_1').read_text() == '2'
+
+
+def test_clock_sampler_reads_hwmon_files(tmp_path):
+    """bench.ClockSampler: mean / min shader clock and power from the hwmon files while a region runs; None where there are none"""
+    import time
+    import bench
+    hw = tmp_path / 'hwmon3'
+    hw.mkdir()
+    (hw / 'freq1_input').write_text('1550000000\n')
+    (hw / 'power1_input').write_text('1000000000\n')
+    c = bench.ClockSampler(hwmon=str(hw))
+    c.start()
+    time.sleep(0.1)
+    (hw / 'freq1_input').write_text('1450000000\n')
+    time.sleep(0.1)
+    r = c.stop()
+    assert r['samples'] >= 4 and r['sclk_MHz_min'] == 1450.0 and 1450.0 < r['sclk_MHz_mean'] < 1550.0
+    assert abs(r['power_W_mean'] - 1000.0) < 1e-6
+    none = bench.ClockSampler(hwmon=str(tmp_path / 'missing'))
+    none.start()
+    assert none.stop() is None
