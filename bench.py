@@ -723,7 +723,7 @@ class ClockSampler:
     only; ``region()`` returns None where the files do not exist."""
 
     def __init__(self, device=0, hwmon=None):
-        self.freq, self.power = None, None
+        self.freq, self.power, self.cap_w = None, None, None
         try:
             if hwmon is None:
                 import glob
@@ -737,6 +737,8 @@ class ClockSampler:
                 self.freq = os.path.join(hwmon, 'freq1_input')
                 if os.path.isfile(os.path.join(hwmon, 'power1_input')):
                     self.power = os.path.join(hwmon, 'power1_input')
+                if os.path.isfile(os.path.join(hwmon, 'power1_cap')):
+                    self.cap_w = self._read(os.path.join(hwmon, 'power1_cap')) * 1e-6
         except Exception:
             self.freq = None
         self._t, self._stop, self._f, self._p = None, False, [], []
@@ -777,6 +779,8 @@ class ClockSampler:
                'source': self.freq}
         if self._p:
             out['power_W_mean'] = sum(self._p) / len(self._p) * 1e-6
+        if self.cap_w is not None:
+            out['power_cap_W'] = self.cap_w
         return out
 
 
