@@ -24,7 +24,7 @@ def needs_build():
     if not os.path.isfile(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + \
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inl')) + \
         glob.glob(os.path.join(os.path.dirname(HERE), 'include', '*.h'))
     return any(os.path.getmtime(d) > t for d in deps)
 

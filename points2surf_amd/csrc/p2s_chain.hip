@@ -133,6 +133,51 @@ __device__ __forceinline__ float half_max(float m) {
     return o;
 }
 
+// ---- 16-row tail (the last point tile of an item when at most 48 of its 64 rows are points) -------------------------
+// Row tile 1 of such a tile holds <= 16 points (P = 300: 12, P = 1000: 8).  v_mfma_f32_16x16x1_4b_f32 multiplies FOUR
+// independent 16x16 outer products per instruction, block = lane / 16 -- with the B register of the 32x32x2 layout
+// unchanged (lane = 32 kk + col) the blocks are (cols 0-15, kk 0), (cols 16-31, kk 0), (cols 0-15, kk 1), (cols 16-31,
+// kk 1): 16 rows x 32 columns x 2 k per instruction at half the cycles of the 32x32x2 form (8 passes), same weight
+// fragments, same LDS tile.  The two kk partial sums of a column are added before the pool (one rounding more than
+// the 32x32x2 chain on these <= 16 rows).  Saves a quarter of conv3 on one tile in 5 (P = 300) / 16 (P = 1000).
+__device__ __forceinline__ f32x16 mfma16b(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, c, 0, 0, 0);
+}
+template <bool TAIL>
+__device__ __forceinline__ f32x16 mfma_r1(float a, float b, f32x16 c) {
+    if constexpr (TAIL) return mfma16b(a, b, c);
+    else return mfma32(a, b, c);
+}
+// max over the 16 accumulator values of one output column of ONE row tile (see tile_colmax for the asm)
+__device__ __forceinline__ float tile_colmax1(const f32x16 &a) {
+    float m;
+    asm volatile("s_nop 15\n\ts_nop 4\n\tv_max_f32 %0, %1, %2" : "=v"(m) : "v"(a[0]), "v"(a[1]));
+#pragma unroll
+    for (int i = 2; i < 16; i += 2) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(a[i]), "v"(a[i + 1]));
+    return m;
+}
+// column max of the 4-block accumulator: D layout block b = regs 4b..4b+3, row = 4 (lane / 16) + reg, col = lane % 16.
+// cols 0-15: blocks 0 + 2, cols 16-31: blocks 1 + 3.  Returns, in lane l, the max over the 8 rows that lane l and
+// lane l ^ 16 hold of column (l & 31) -- the lane's own column in the 32x32 layout; the l ^ 32 exchange that follows
+// in half_max() completes the 16 rows.  v_permlane16_swap(x, y) trades the odd 16-lane rows of x for the even ones of y.
+__device__ __forceinline__ float tail_colmax(const f32x16 &c) {
+    float sa[4], sb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sa[i] = c[i] + c[8 + i];
+        sb[i] = c[4 + i] + c[12 + i];
+    }
+    float ma, mb;
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(ma) : "v"(sa[0]), "v"(sa[1]), "v"(sa[2]));
+    asm volatile("v_max_f32 %0, %0, %1" : "+v"(ma) : "v"(sa[3]));
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(mb) : "v"(sb[0]), "v"(sb[1]), "v"(sb[2]));
+    asm volatile("v_max_f32 %0, %0, %1" : "+v"(mb) : "v"(sb[3]));
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ma), __float_as_uint(mb), false, false);
+    float x = __uint_as_float(r[0]), y = __uint_as_float(r[1]), o;
+    asm volatile("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(x), "v"(y));
+    return o;
+}
+
 // sym_op='sum' (reference source/points_to_surf_model.py:213-214): sum over the VALID rows of the two row tiles of one
 // output column.  Rows past the item's last point replicate that point (harmless for a max) and are masked here.
 // Plain C++: the compiler pads the XDL-write -> VALU-read hazard itself and adds need no sNaN quieting.
@@ -197,9 +242,9 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
         for (int i = 0; i < 9; ++i) R[i] = br.rot[item * 9 + i];
     }
 
-    float rmax[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) rmax[i] = SUM ? 0.0f : -INFINITY;
+    // eight named scalars, not an array: the pair index pr is a run-time value, an indexed array would live in scratch
+    const float pool0 = SUM ? 0.0f : -INFINITY;
+    float rm0 = pool0, rm1 = pool0, rm2 = pool0, rm3 = pool0, rm4 = pool0, rm5 = pool0, rm6 = pool0, rm7 = pool0;
     // torch's conv/ReLU/MaxPool propagate NaN (a non-finite coordinate poisons every channel of the
     // item); v_max_f32 does not.  Track non-finite inputs and poison the pooled output instead.
     bool bad = false;
@@ -311,89 +356,16 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
         // One continuous software pipeline over the 4 x 16 k-groups: two operand register sets (A/B)
         // ping-pong, the operands of k-group g+1 are fetched while the 16 MFMAs of k-group g issue --
         // across pair boundaries too -- and every memory instruction sits in its own MFMA shadow.
-        {
-            const float *a0p = bufB + (lane & 31) * SB + 4 * (lane >> 5);
-            const float *a1p = a0p + 32 * SB;
-#define P2S_MFMA16(A0, A1, B0, B1)                                   \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                  \
-        c00 = mfma32(A0[t], B0[t], c00);                             \
-        c01 = mfma32(A0[t], B1[t], c01);                             \
-        c10 = mfma32(A1[t], B0[t], c10);                             \
-        c11 = mfma32(A1[t], B1[t], c11);                             \
-    }
-// first k-group of a pair: accumulate into literal zero (inline constant C operand, no v_mov init)
-#define P2S_MFMA16_FIRST(A0, A1, B0, B1)                             \
-    c00 = mfma32(A0[0], B0[0], zero16());                            \
-    c01 = mfma32(A0[0], B1[0], zero16());                            \
-    c10 = mfma32(A1[0], B0[0], zero16());                            \
-    c11 = mfma32(A1[0], B1[0], zero16());                            \
-    _Pragma("unroll") for (int t = 1; t < 4; ++t) {                  \
-        c00 = mfma32(A0[t], B0[t], c00);                             \
-        c01 = mfma32(A0[t], B1[t], c01);                             \
-        c10 = mfma32(A1[t], B0[t], c10);                             \
-        c11 = mfma32(A1[t], B1[t], c11);                             \
-    }
-// fetch the operands of k-group KG of pair PR into a register set.  B comes through a buffer descriptor
-// (SGPR base + scalar offset + one 32-bit lane offset): no 64-bit VALU address arithmetic in the loop.
-#define P2S_FETCH(BS0, BS1, AS0, AS1, PR, KG)                                                          \
-    BS0 = bufld4(w3rsrc, lane16, w3soff + (((2 * (PR)) * 16 + (KG)) * 1024));                           \
-    BS1 = bufld4(w3rsrc, lane16, w3soff + (((2 * (PR) + 1) * 16 + (KG)) * 1024));                       \
-    AS0 = lds4(a0p + 8 * (KG));                                                                         \
-    AS1 = lds4(a1p + 8 * (KG));
-// issue order of one 16-MFMA block: ONE memory instruction per MFMA shadow.  A VMEM/DS instruction costs
-// tens of issue cycles; clustered at the block boundary (or sunk to first use, the scheduler's default)
-// their issue time exceeds the 64-cycle shadow of one MFMA and the matrix pipe bubbles (measured: 13 %).
-#define P2S_SPREAD()                                                                              \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            f32x16 c00, c01, c10, c11;
-            aA0 = lds4(a0p);
-            aA1 = lds4(a1p);
-            if (tile + 1 < ntiles) load_point(tile + 1, nx0, nx1, nx2);   // lands during conv3
-#pragma unroll 1
-            for (int pr = 0; pr < 4; ++pr) {
-                // k-group 0 (set A, C = 0) while set B <- k-group 1
-                P2S_FETCH(bB0, bB1, aB0, aB1, pr, 1)
-                P2S_MFMA16_FIRST(aA0, aA1, bA0, bA1)
-                P2S_SPREAD()
-#pragma unroll 1
-                for (int kg = 1; kg < 15; kg += 2) {
-                    P2S_FETCH(bA0, bA1, aA0, aA1, pr, kg + 1)
-                    P2S_MFMA16(aB0, aB1, bB0, bB1)
-                    P2S_SPREAD()
-                    P2S_FETCH(bB0, bB1, aB0, aB1, pr, kg + 2)
-                    P2S_MFMA16(aA0, aA1, bA0, bA1)
-                    P2S_SPREAD()
-                }
-                // k-group 15 (set B) while set A <- k-group 0 of the next pair (the last pair re-fetches its own)
-                const int prn = (pr < 3) ? pr + 1 : 3;
-                P2S_FETCH(bA0, bA1, aA0, aA1, prn, 0)
-                P2S_MFMA16(aB0, aB1, bB0, bB1)
-                P2S_SPREAD()
-                float m0, m1;
-                if constexpr (SUM) {
-                    const int nvalid = P - tile * MT;       // rows of this tile that are points of the item
-                    m0 = half_sum(tile_colsum(c00, c10, nvalid, lane));
-                    m1 = half_sum(tile_colsum(c01, c11, nvalid, lane));
-                } else {
-                    m0 = half_max(tile_colmax(c00, c10));
-                    m1 = half_max(tile_colmax(c01, c11));
-                }
-#define P2S_POOL(dst, v) dst = SUM ? dst + (v) : fmaxf(dst, (v))
-                // static register indexing (runtime-indexed arrays would go to scratch)
-                if (pr == 0) { P2S_POOL(rmax[0], m0); P2S_POOL(rmax[1], m1); }
-                else if (pr == 1) { P2S_POOL(rmax[2], m0); P2S_POOL(rmax[3], m1); }
-                else if (pr == 2) { P2S_POOL(rmax[4], m0); P2S_POOL(rmax[5], m1); }
-                else { P2S_POOL(rmax[6], m0); P2S_POOL(rmax[7], m1); }
-#undef P2S_POOL
-            }
-#undef P2S_MFMA16
-#undef P2S_MFMA16_FIRST
-#undef P2S_FETCH
-#undef P2S_SPREAD
+        // P2S_TAIL (see mfma16b): the item's last tile with <= 48 points -- row tile 1 runs as 16 rows on the 4-block MFMA.
+        // sum pool: padded rows are masked per row of the 32x32 layout (tile_colsum) -- keeps the full tile
+        if (!SUM && tile == ntiles - 1 && P - tile * MT <= 48) {
+#define P2S_TAIL 1
+#include "p2s_chain_conv3.inl"
+#undef P2S_TAIL
+        } else {
+#define P2S_TAIL 0
+#include "p2s_chain_conv3.inl"
+#undef P2S_TAIL
         }
         // next tile's first layer writes bufA, whose last readers (conv2) are behind the barrier above
     }
@@ -403,6 +375,7 @@ __global__ __launch_bounds__(256, 3) void p2s_chain_kernel(ChainArgs args) {
     if (lane < 32) {
         float *out = br.out + (long long)item * 1024 + 256 * wave + lane;
         const float *b3 = br.b3 + 256 * wave + lane;
+        const float rmax[8] = {rm0, rm1, rm2, rm3, rm4, rm5, rm6, rm7};
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             float v = rmax[t] + (SUM ? (float)P * b3[32 * t] : b3[32 * t]);     // sum: the bias once per point
