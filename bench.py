@@ -100,6 +100,8 @@ def parse():
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary passes')
     ap.add_argument('--secondary-reps', type=int, default=3, help='timed shapes per secondary entry (median reported)')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
+    # test hook (tests/test_gpu_bench_rehearsal.py): RANK:K -- that rank raises when it reaches its K-th own shape (0-based)
+    ap.add_argument('--fault', default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -176,7 +178,7 @@ def cpu_baseline(w, cfg, model_name, cloud_name, cloud, queries, target_seconds,
            'blas': 'mkl' if torch.backends.mkl.is_available() else 'other'}
     if ref_shims.reference_available() and cloud_name is not None:
         n, dt, sdf = _reference_leg(model_name, cloud_name, threads)
-        rec.update({'value': n / dt, 'kind': 'reference',
+        rec.update({'value': n / dt, 'kind': 'reference', 'same_box': True,
                     'sample': 'the UNMODIFIED reference (source.points_to_surf_eval.points_to_surf_eval, torch CPU, --workers 0, '
                               'batch 500) over the %d queries of the 32^3 grid of the dataset\'s shape %s -- the same per-query '
                               'work as at %d^3 (kNN 300 / sub-sample 1000 / same network), %.1f s' % (n, cloud_name[:8], grid_res, dt)})
@@ -195,7 +197,9 @@ def cpu_baseline(w, cfg, model_name, cloud_name, cloud, queries, target_seconds,
                     '(tests/golden/meta_sizes.json)' % (m['threads'], m['reference_queries_per_s']))
     except Exception:
         pass
-    rec.update({'value': n / dt, 'kind': 'port',
+    # same_box: is `value` the REFERENCE ITSELF timed on this box?  No: no checkout exists here, `value` is the port on this
+    # box's cores, and `reference_itself` quotes the reference's own rate from ANOTHER machine (the build container)
+    rec.update({'value': n / dt, 'kind': 'port', 'same_box': False,
                 'sample': 'oracle/torch_port.py (no reference checkout on this box): first %d of the %d^3-grid queries of the '
                           'dataset\'s first shape (kNN cKDTree + RandomState sub-sample + torch-CPU forward, batch 500), %.1f s'
                           % (n, grid_res, dt),
@@ -374,7 +378,7 @@ def golden_check(engine, parity, model, w, cfg, shapes, res, sdfs, tol, bf16):
                 patch, sub, one = engine.query_inputs(model, cloud, rng, q_all, int(j))
                 lg_dev = float(model.forward(patch, sub, one)[0][0, 1])
                 lg_cpu = float(TorchPort(w, cfg).forward(patch.cpu().numpy(), sub.cpu().numpy(), one.cpu().numpy())[0, 1])
-                tie = abs(lg_dev) < parity.tie_logit(bf16) and abs(lg_cpu) < parity.tie_logit(bf16)
+                tie = parity.is_tie(lg_dev, lg_cpu, bf16)
                 not_ties += 0 if tie else 1
                 rec['flipped'].append({'shape': name[:8], 'query': int(j), 'sdf': float(sdf[j]), 'ref': float(ref[j]),
                                        'sign_logit_device': lg_dev, 'sign_logit_cpu_port': lg_cpu, 'tie': bool(tie)})
@@ -488,10 +492,25 @@ def main():
         sharding.skip_shape_stream(c2, r, cfg, args.res, EPSILON, n_sub)
         c2.close()
 
+    # N > 1: every rank leaves, per own shape, the digest of the generator state at its first draw and after its last one and
+    # the sha256 of its SDF in the rendezvous store (control plane, 200 bytes): rank 0 replays the whole dataset stream after
+    # the timed region and compares (self_check.stream_handoff)
+    store = None
+    if sharding.is_initialized():
+        from torch.distributed.distributed_c10d import _get_default_store
+        store = _get_default_store()
+    fault = tuple(int(x) for x in args.fault.split(':')) if args.fault else None
+    own_seen = [0]
+
+    def state_digest(r):
+        import hashlib
+        return hashlib.sha256(sharding.StreamHandoff.pack([r])).hexdigest()
+
     def run_block(lo, hi, timed):
         """shapes lo..hi-1 of the dataset in order: mine are inferred (complete shapes, host to host); returns the list
         of (host SDF, device SDF, cloud index)"""
         import contextlib
+        import hashlib
         outs = []
         for g in range(lo, hi):
             pts = shapes[cloud_of[g]][1]
@@ -506,7 +525,16 @@ def main():
                     handoff.begin(g, [rng])
                     if handoff.must_publish(g):
                         handoff.publish_after(g, [rng], lambda k: skip_shape(k, rng))
+                if fault is not None and fault[0] == rank:
+                    if fault[1] == own_seen[0]:
+                        raise RuntimeError('injected fault (--fault %s) at shape %d' % (args.fault, g))
+                    own_seen[0] += 1
+                st0 = state_digest(rng) if store is not None else None
                 outs.append(complete_shape(engine, model, pts, rng, args.res, args.chunk, ev if timed else None) + (cloud_of[g],))
+                if store is not None:
+                    store.set('p2s/bench/rec/%d' % g, json.dumps({
+                        'start': st0, 'end': state_digest(rng), 'queries': int(outs[-1][0].shape[0]),
+                        'sha256': hashlib.sha256(outs[-1][0].numpy().tobytes()).hexdigest()}))
                 if timed:
                     for k, v in model.counters().items():        # per pipeline call (reset at its start)
                         acc[k] = acc.get(k, 0) + v
@@ -526,6 +554,9 @@ def main():
     per_shape_q = {shapes[ci][0][:8]: q_of_cloud[ci] for ci in sorted(set(cloud_of[args.warmup * world:]))}
     gathered = 0
     parts = None
+    if handoff is not None:
+        handoff.finish()        # every rank is through with its shapes -- or the failure record of one of them raises HERE,
+                                # not after the process group's time-out inside the gather below
     if sharding.is_initialized():
         # the final variable-length gather of the SDF values to rank 0 (RCCL over xGMI): the path's only exchange
         mine_dev = torch.cat([o[1] for o in mine_timed]) if mine_timed else torch.empty((0,), dtype=torch.float32, device='cuda')
@@ -640,24 +671,41 @@ def main():
                 bail('against the reference golden', check)
         elif golden_file is not None:
             check['vs_reference_golden'] = {'file': os.path.relpath(golden_file, REPO), 'missing': True}
-        # (1b) N > 1 with the stream hand-off: rank 0 re-derives the LAST timed shape of another rank from scratch (fresh
-        # stream, every earlier shape's draws consumed one after the other) and compares it with what that rank produced
-        if handoff is not None and parts is not None:
+        # (1b) N > 1: rank 0 replays the WHOLE dataset stream from a fresh start -- every shape's draws consumed by the
+        # NULL-ids skip, one after the other -- and compares, per shape, the generator state at its first draw and after
+        # its last one with what the shape's owner left in the store (start: the hand-off delivered the right state; end:
+        # the inference consumed what the skip consumes).  The LAST timed shape of every other rank is also inferred again
+        # from the replayed state and must be bit-identical (sha256, and the gathered values themselves).
+        if store is not None and parts is not None and world > 1:
+            import hashlib
             lo = args.warmup * world
-            foreign = [g for g in range(lo, n_rounds * world) if owner[g] != 0]
-            if foreign:
-                gstar = foreign[-1]
-                reseed(rng)
-                for g in range(gstar):
+            last_of = {}
+            for g in range(lo, n_rounds * world):
+                last_of[owner[g]] = g
+            hrec = {'mode': stream_mode, 'shapes': n_rounds * world, 'state_mismatches': [], 'sdf_replayed': []}
+            reseed(rng)
+            for g in range(n_rounds * world):
+                if args.rng_mode == 'per_shape':
+                    reseed(rng, SEED_DATA + g)
+                theirs = json.loads(store.get('p2s/bench/rec/%d' % g).decode())
+                if state_digest(rng) != theirs['start']:
+                    hrec['state_mismatches'].append({'shape': g, 'owner': owner[g], 'at': 'start'})
+                if owner[g] != 0 and last_of.get(owner[g]) == g:
+                    again = complete_shape(engine, model, shapes[cloud_of[g]][1], rng, args.res, args.chunk)[0].numpy()
+                    before = sum(q_of_cloud[cloud_of[k]] for k in range(lo, g) if owner[k] == owner[g])
+                    got = parts[owner[g]][before:before + again.shape[0]].cpu().numpy()
+                    same = bool(got.shape == again.shape and np.array_equal(got, again)
+                                and hashlib.sha256(again.tobytes()).hexdigest() == theirs['sha256'])
+                    hrec['sdf_replayed'].append({'shape': g, 'owner': owner[g], 'queries': int(again.shape[0]), 'bit_identical': same})
+                else:
                     skip_shape(g, rng)
-                mine_again = complete_shape(engine, model, shapes[cloud_of[gstar]][1], rng, args.res, args.chunk)[0].numpy()
-                before = sum(q_of_cloud[cloud_of[g]] for g in range(lo, gstar) if owner[g] == owner[gstar])
-                theirs = parts[owner[gstar]][before:before + mine_again.shape[0]].cpu().numpy()
-                same = bool(theirs.shape == mine_again.shape and np.array_equal(theirs, mine_again))
-                check['stream_handoff'] = {'shape': gstar, 'owner': owner[gstar], 'queries': int(mine_again.shape[0]),
-                                           'bit_identical_to_single_stream': same}
-                if not same:
-                    bail('stream hand-off: shape %d of rank %d differs from the single-stream result' % (gstar, owner[gstar]), check)
+                if state_digest(rng) != theirs['end']:
+                    hrec['state_mismatches'].append({'shape': g, 'owner': owner[g], 'at': 'end'})
+            hrec['bit_identical_to_single_stream'] = bool(not hrec['state_mismatches'] and hrec['sdf_replayed']
+                                                          and all(r['bit_identical'] for r in hrec['sdf_replayed']))
+            check['stream_handoff'] = hrec
+            if not hrec['bit_identical_to_single_stream']:
+                bail('stream replay: %s' % json.dumps(hrec['state_mismatches'][:4] + [r for r in hrec['sdf_replayed'] if not r['bit_identical']][:4]), check)
         # (2) the r02 measurement beside the headline: cloud handles + query grids resident, SDF left on the device
         if world == 1 and mname == 'p2s_max':
             resident = [engine.Cloud(pts) for _, pts, _ in shapes]

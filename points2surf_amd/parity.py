@@ -34,6 +34,15 @@ def compare_sdf(sdf, ref):
     return {'max_abs_dsdf': float(d.max()) if d.size else 0.0, 'flipped': flipped}
 
 
+def is_tie(sign_logit_device, sign_logit_cpu, encoder_bf16=0):
+    """THE rule for accepting a sign that differs from the reference's golden (bench.py's self-check, the full-grid parity
+    tests, the drop-in's tie report): BOTH the device's own sign logit for the query and the CPU restatement's sign logit
+    on the same inputs (the same ATen ops as the reference, oracle/torch_port.py -- computed by the caller, this package does
+    not import the oracle) lie within the encoder mode's threshold of zero"""
+    t = tie_logit(encoder_bf16)
+    return abs(float(sign_logit_device)) < t and abs(float(sign_logit_cpu)) < t
+
+
 def not_ties(sign_logits, encoder_bf16=0):
     """how many of the flipped queries are NOT ties, given the device's sign logits for them and the encoder mode"""
     t = tie_logit(encoder_bf16)

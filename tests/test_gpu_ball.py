@@ -8,6 +8,8 @@ import os
 
 import numpy as np
 import pytest
+
+from conftest import missing_golden
 from scipy import spatial
 
 pytestmark = pytest.mark.gpu
@@ -149,7 +151,7 @@ def test_radius_models_match_the_reference_golden(fixture_cloud, golden_dir, mod
     from points2surf_amd import engine, synth
     path = os.path.join(golden_dir, 'ref_rec_%s_testset_grid32.npz' % model)
     if not os.path.isfile(path):
-        pytest.skip('golden not generated yet: ' + os.path.basename(path))
+        missing_golden('golden not generated yet: ' + os.path.basename(path))
     ref = np.load(path)['rec_0']
     w, cfg = synth.make_weights(model)
     m = engine.Model(w, cfg)
@@ -179,7 +181,7 @@ def test_radius_models_match_the_reference_at_128(fixture_cloud, golden_dir, mod
     from points2surf_amd import engine, parity, synth
     path = os.path.join(golden_dir, 'ref_rec_%s_testset_grid128.npz' % model)
     if not os.path.isfile(path):
-        pytest.skip('golden not generated yet: ' + os.path.basename(path))
+        missing_golden('golden not generated yet: ' + os.path.basename(path))
     ref = np.load(path)['rec_0']
     w, cfg = synth.make_weights(model)
     m = engine.Model(w, cfg)

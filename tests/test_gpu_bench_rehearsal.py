@@ -42,9 +42,12 @@ def test_two_ranks_on_one_gpu(mode):
         # from a fresh single stream and finds it bit-identical
         assert d['config']['stream_mode'] == 'dataset/handoff'
         h = d['self_check']['stream_handoff']
-        assert h['bit_identical_to_single_stream'] is True and h['owner'] == 1 and h['queries'] == 2976
+        assert h['bit_identical_to_single_stream'] is True and h['shapes'] == 6 and not h['state_mismatches']
+        assert h['sdf_replayed'] == [{'shape': 5, 'owner': 1, 'queries': 2976, 'bit_identical': True}]
     else:
-        assert d['config']['stream_mode'] == 'per_shape' and 'stream_handoff' not in d['self_check']
+        # per-shape seeds: nothing crosses shapes, the replay still re-derives rank 1's last shape bit for bit
+        h = d['self_check']['stream_handoff']
+        assert d['config']['stream_mode'] == 'per_shape' and h['mode'] == 'per_shape' and h['bit_identical_to_single_stream'] is True
 
 
 def test_eight_ranks_three_clouds_at_the_real_world_size():
@@ -64,10 +67,34 @@ def test_eight_ranks_three_clouds_at_the_real_world_size():
     g = d['self_check']['vs_reference_golden']
     assert g['file'].endswith('ref_rec_p2s_max_abc3_grid64.npz') and len(g['shapes']) == 3
     assert g['sign_flips'] == 0 and g['max_abs_dsdf'] < 1e-4 and g['queries'] == sum(d['config']['queries_per_shape'].values())
+    # rank 0 replays the whole stream -- the generator state at both ends of ALL 32 shapes equals what
+    # their owners saw -- and re-infers the last shape of EVERY other rank bit for bit
     h = d['self_check']['stream_handoff']
-    assert d['config']['stream_mode'] == 'dataset/handoff' and h['bit_identical_to_single_stream'] is True and h['owner'] != 0
+    assert d['config']['stream_mode'] == 'dataset/handoff' and h['bit_identical_to_single_stream'] is True
+    assert h['shapes'] == 32 and not h['state_mismatches']
+    assert sorted(r['owner'] for r in h['sdf_replayed']) == list(range(1, 8)) and all(r['bit_identical'] for r in h['sdf_replayed'])
+    assert d['cpu_baseline']['same_box'] == (d['cpu_baseline']['kind'] == 'reference')
     # the keys a SCALE run is read by: the CPU baseline and the ratio at the real world size
     assert d['cpu_baseline']['value'] > 0 and d['config']['shapes_per_hour_vs_cpu'] > 1.0 and d['config']['shapes_per_hour'] > 0
+
+
+def test_a_rank_that_raises_takes_the_run_down_within_seconds():
+    """VERDICT r5 item 4 / ADVICE r5: a rank that raises mid-run (injected: rank 2 at its third shape, i.e. inside the timed
+    block, while ranks that are already through sit in ``StreamHandoff.finish()``) must end the WHOLE run promptly with a
+    non-zero exit code -- not leave its peers in the closing gather until the process group's time-out (30 min)"""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['P2S_BENCH_SHARE_GPU'] = '1'
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '4', '--backend', 'gloo', '--steps', '3',
+                        '--warmup', '1', '--res', '32', '--cpu-seconds', '0', '--fault', '2:2'], env=env, capture_output=True,
+                       text=True, timeout=600)
+    dt = time.time() - t0
+    assert r.returncode != 0 and 'injected fault' in r.stderr, (r.returncode, r.stderr[-1500:])
+    assert not [l for l in r.stdout.split('\n') if l.startswith('{')]            # no JSON line from a broken run
+    assert dt < 180, dt
+    # a peer that was waiting names the failed rank (hand-off record), it does not time out
+    assert 'TimeoutError' not in r.stderr
 
 
 def test_replicate_mode_still_gives_the_exact_stream():

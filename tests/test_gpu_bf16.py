@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import missing_golden, flip_logits
+
 pytestmark = pytest.mark.gpu
 
 
@@ -154,7 +156,7 @@ def test_fp16_pair_full_512_grid(name, golden_dir, torch_cuda):
     from points2surf_amd import engine, synth, parity
     path = os.path.join(golden_dir, 'ref_rec_%s_testset_grid512.npz' % name)
     if not os.path.isfile(path):
-        pytest.skip('512^3 golden not generated')
+        missing_golden('512^3 golden not generated')
     ref = np.load(path)['rec_0']
     w, cfg = synth.make_weights(name)
     m = engine.Model(w, dict(cfg, encoder_bf16=4))
@@ -167,5 +169,5 @@ def test_fp16_pair_full_512_grid(name, golden_dir, torch_cuda):
           % (name, c['max_abs_dsdf'], c['flipped'].size, ref.size))
     assert c['max_abs_dsdf'] < 1e-4 and c['flipped'].size <= 8
     for j in c['flipped']:
-        lg = engine.query_logits(m, cloud, engine.Rng(40938661), q, int(j)).cpu().numpy()
-        assert parity.not_ties([lg[1]], encoder_bf16=4) == 0, (int(j), lg)
+        lg = flip_logits(m, w, cfg, cloud, engine.Rng(40938661), q, int(j))     # device (fp16 pair) and CPU port (fp32)
+        assert parity.is_tie(lg[0], lg[1], encoder_bf16=4), (int(j), lg)

@@ -11,6 +11,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import missing_golden
+
 pytestmark = pytest.mark.gpu
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -63,7 +65,7 @@ def test_full_eval_call_sequence_matches_reference(model, dropin_eval, tmp_path)
     tol = 1e-4 if model.endswith('_radius') else 1e-5
     key = 'ref_fulleval_%s_abc3_grid32' % model
     if not os.path.isfile(os.path.join(GOLDEN, key + '.npz')):
-        pytest.skip(key + ' not generated')
+        missing_golden(key + ' not generated')
     g = np.load(os.path.join(GOLDEN, key + '.npz'))
     with open(os.path.join(GOLDEN, 'meta_sizes.json')) as f:
         meta = json.load(f)[key]

@@ -21,6 +21,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import missing_golden
+
 from points2surf_amd import parity
 
 pytestmark = pytest.mark.gpu
@@ -68,7 +70,7 @@ def test_cloud_to_mesh_equals_scikit_image_on_the_reference_sdf(model_name, data
     from points2surf_amd import engine, synth
     gfile = os.path.join(GOLDEN, 'ref_rec_%s_%s_grid%d.npz' % (model_name, dataset, res))
     if not os.path.isfile(gfile):
-        pytest.skip(gfile + ' not generated')
+        missing_golden(gfile + ' not generated')
     g = np.load(gfile)
     meta = _meta()
     w, cfg = synth.make_weights(model_name)

@@ -10,6 +10,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import missing_golden, flip_logits
+
 from points2surf_amd import parity
 
 pytestmark = pytest.mark.gpu
@@ -28,7 +30,7 @@ def _golden(job, model, dataset, res):
     key = 'ref_%s_%s_%s_grid%d' % (job, model, dataset, res)
     path = os.path.join(GOLDEN, key + '.npz')
     if not os.path.isfile(path):
-        pytest.skip('%s not generated (hours of reference CPU time; see oracle/make_golden_sizes.py)' % key)
+        missing_golden('%s not generated (hours of reference CPU time; see oracle/make_golden_sizes.py)' % key)
     with open(os.path.join(GOLDEN, 'meta_sizes.json')) as f:
         meta = json.load(f)[key]
     return np.load(path), meta
@@ -126,9 +128,10 @@ def test_three_clouds_one_stream_256_matches_reference(res):
                 sharding.skip_shape_stream(c, rng, cfg, res, 3, model.sub_sample_size)
                 c.close()
             cloud = engine.Cloud(np.load(os.path.join(FIX, '04_pts', names[si] + '.xyz.npy')))
-            lg = engine.query_logits(model, cloud, rng, torch.from_numpy(out[si][1]).cuda(), j).cpu().numpy()
-            print('shape %d query %d: logits %s, device sdf %.6g, reference %.6g' % (si, j, lg, out[si][0][j], g['rec_%d' % si][j]))
-            assert parity.not_ties([lg[1]]) == 0, (si, j, lg)
+            lg = flip_logits(model, w, cfg, cloud, rng, torch.from_numpy(out[si][1]).cuda(), j)
+            print('shape %d query %d: sign logits device %.3g / CPU port %.3g, device sdf %.6g, reference %.6g'
+                  % (si, j, lg[0], lg[1], out[si][0][j], g['rec_%d' % si][j]))
+            assert parity.is_tie(lg[0], lg[1]), (si, j, lg)          # the same two-logit rule as bench.py's self-check
             cloud.close()
 
 
@@ -145,8 +148,8 @@ def test_full_grid512_matches_reference(model):
     The sign is ``sign logit >= 0`` (sdf_nn.py:16-21): among 757k queries a few have a sign logit within fp32 noise of
     zero (2 here, |logit| < 6e-6 with a logit accuracy of ~1.5e-5) -- the reference's own answer for them depends on
     its batch composition and thread count (the golden run says +, the same ATen ops on the same inputs in another batch
-    say -5.0e-6: oracle/torch_port.py).  Such TIES are tolerated, if and only if the device's own sign logit is that
-    close to zero; every other query must agree in sign, and all magnitudes within 1e-4."""
+    say -5.0e-6: oracle/torch_port.py).  Such TIES are tolerated, if and only if the device's own sign logit AND the CPU
+    port's on the same inputs are that close to zero (parity.is_tie); every other query must agree in sign, and all magnitudes within 1e-4."""
     import torch
     from points2surf_amd import engine, synth
     g, meta = _golden('rec', model, 'testset', 512)
@@ -158,9 +161,10 @@ def test_full_grid512_matches_reference(model):
         model = engine.Model(w, cfg)
         cloud = engine.Cloud(np.load(os.path.join(FIX, '04_pts', _names('testset')[0] + '.xyz.npy')))
         for _, j in flipped:
-            lg = engine.query_logits(model, cloud, engine.Rng(SEED), torch.from_numpy(out[0][1]).cuda(), j).cpu().numpy()
-            print('query %d: logits %s, device sdf %.6g, reference %.6g' % (j, lg, out[0][0][j], g['rec_0'][j]))
-            assert parity.not_ties([lg[1]]) == 0, (j, lg)
+            lg = flip_logits(model, w, cfg, cloud, engine.Rng(SEED), torch.from_numpy(out[0][1]).cuda(), j)
+            print('query %d: sign logits device %.3g / CPU port %.3g, device sdf %.6g, reference %.6g'
+                  % (j, lg[0], lg[1], out[0][0][j], g['rec_0'][j]))
+            assert parity.is_tie(lg[0], lg[1]), (j, lg)              # the same two-logit rule as bench.py's self-check
 
 
 @pytest.mark.parametrize('res', [32, 64])
@@ -184,7 +188,7 @@ def test_sym_op_sum_matches_reference(encoder):
     from points2surf_amd import engine, synth
     key = 'ref_rec_p2s_max_sum_testset_grid32'
     if not os.path.isfile(os.path.join(GOLDEN, key + '.npz')):
-        pytest.skip(key + ' not generated')
+        missing_golden(key + ' not generated')
     ref = np.load(os.path.join(GOLDEN, key + '.npz'))['rec_0']
     w, cfg = synth.make_weights('p2s_max_sum')
     assert cfg['sym_op'] == 'sum'
@@ -214,7 +218,7 @@ def test_sym_op_sum_with_the_single_encoder_matches_reference():
     from points2surf_amd import engine, synth
     key = 'ref_rec_p2s_shared_encoder_sum_testset_grid32'
     if not os.path.isfile(os.path.join(GOLDEN, key + '.npz')):
-        pytest.skip(key + ' not generated')
+        missing_golden(key + ' not generated')
     ref = np.load(os.path.join(GOLDEN, key + '.npz'))['rec_0']
     w, cfg = synth.make_weights('p2s_shared_encoder_sum')
     m = engine.Model(w, cfg)
@@ -250,7 +254,7 @@ def test_fixed_subsample_matches_reference(model):
     from oracle import p2s_oracle as O
     key = 'ref_rec_%s_testset_fixed_grid32' % model
     if not os.path.isfile(os.path.join(GOLDEN, key + '.npz')):
-        pytest.skip(key + ' not generated')
+        missing_golden(key + ' not generated')
     g = np.load(os.path.join(GOLDEN, key + '.npz'))
     w, cfg = synth.make_weights(model)
     cfg = dict(cfg, fixed_subsample=True)
@@ -292,7 +296,7 @@ def test_small_cloud_shuffle_and_pad_matches_reference(model):
     from points2surf_amd import engine, synth
     key = 'ref_rec_%s_small800_grid16' % model
     if not os.path.isfile(os.path.join(GOLDEN, key + '.npz')):
-        pytest.skip(key + ' not generated')
+        missing_golden(key + ' not generated')
     g = np.load(os.path.join(GOLDEN, key + '.npz'))
     pts = np.load(os.path.join(GOLDEN, 'small800.xyz.npy'))
     w, cfg = synth.make_weights(model)
@@ -336,7 +340,7 @@ def test_ablation_models_match_reference(model):
     from points2surf_amd import engine, synth
     key = 'ref_rec_%s_testset_grid32' % model
     if not os.path.isfile(os.path.join(GOLDEN, key + '.npz')):
-        pytest.skip(key + ' not generated')
+        missing_golden(key + ' not generated')
     g = np.load(os.path.join(GOLDEN, key + '.npz'))
     w, cfg = synth.make_weights(model)
     m = engine.Model(w, cfg)

@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import missing_golden
+
 from oracle import p2s_oracle as O
 from points2surf_amd import synth
 
@@ -137,7 +139,7 @@ def test_fixed_radius_gt_query_pass_matches_reference(golden_dir, meta):
     choice and THEN rand(3), both from the data set's first generator"""
     path = os.path.join(golden_dir, 'ref_fulleval_p2s_medium_radius_abc3_grid32.npz')
     if not os.path.isfile(path):
-        pytest.skip('golden not generated')
+        missing_golden(os.path.basename(path), cpu_test=True)
     g = np.load(path)
     fix = os.path.join(golden_dir, 'abc_minimal')
     with open(os.path.join(fix, 'abc3.txt')) as f:

@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import missing_golden
+
 from oracle import p2s_oracle as O
 from oracle import trimesh_restated as T
 
@@ -49,7 +51,7 @@ def test_oracle_gt_query_pass_matches_reference_full_eval(model):
     from points2surf_amd import synth
     path = os.path.join(GOLDEN, 'ref_fulleval_%s_abc3_grid32.npz' % model)
     if not os.path.isfile(path):
-        pytest.skip('golden not generated yet')
+        missing_golden(os.path.basename(path), cpu_test=True)
     g = np.load(path)
     w, cfg = synth.make_weights(model)
     n = 12
@@ -67,7 +69,7 @@ def test_oracle_small_cloud_shuffle_pad_matches_reference():
     from points2surf_amd import synth
     path = os.path.join(GOLDEN, 'ref_rec_p2s_max_small800_grid16.npz')
     if not os.path.isfile(path):
-        pytest.skip('golden not generated yet')
+        missing_golden(os.path.basename(path), cpu_test=True)
     g = np.load(path)
     w, cfg = synth.make_weights('p2s_max')
     pts = np.load(os.path.join(GOLDEN, 'small800.xyz.npy'))
