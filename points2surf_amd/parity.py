@@ -8,12 +8,16 @@ caller from the device's own sign logit (engine.query_logits)."""
 import numpy as np
 
 # |sign logit| below which a flipped sign counts as a tie of the sign decision, per encoder arithmetic:
-#  * IEEE fp32 encoder (cfg.encoder_bf16 = 0): the largest ties seen are 4.0e-6 on the device (p2s_max, 512^3) and 5.0e-6
-#    between two runs of the reference itself on the same inputs (other batch composition / thread count); at 256^3 the
-#    one known tie sits at 2.4e-7.  6e-6 covers those and nothing else.
+#  * IEEE fp32 encoder (cfg.encoder_bf16 = 0): what bounds it is the REFERENCE's own reproducibility -- the same ATen ops on
+#    the same network inputs in another batch composition / thread count (oracle/torch_port.py) answer -7.4e-6 for query
+#    46,971 of the 512^3 grid of the test shape (p2s_max) where the reference's golden run said >= 0 (r06, found when the
+#    parity tests started to demand the CPU port's logit as well as the device's; device: -6.5e-6 with the 16-row tail
+#    tile, -4.0e-6 with r05's summation order); 5.0e-6 for the other tie of that grid; at 256^3 the known ties sit at
+#    2.4e-7 and 1.7e-6.  The logit accuracy of fp32 through the 1024-wide layers is ~1.5e-5.  1e-5 covers what the
+#    reference does to itself and nothing beyond its own noise.  (r02-r05: 6e-6, set from the device's logits alone.)
 #  * split-precision encoders (3 bf16 pieces / fp16 pair, 22-24 mantissa bits per operand and another summation order):
 #    largest tie seen 8e-6 -> 2e-5, the logit accuracy of those modes.
-TIE_LOGIT_FP32 = 6e-6
+TIE_LOGIT_FP32 = 1e-5
 TIE_LOGIT_SPLIT = 2e-5
 
 

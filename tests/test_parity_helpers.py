@@ -22,5 +22,12 @@ def test_tie_threshold():
     assert parity.not_ties([]) == 0
     # the fp32 encoder has its own, tighter threshold than the split-precision modes
     assert parity.tie_logit(0) == parity.TIE_LOGIT_FP32 < parity.TIE_LOGIT_SPLIT == parity.tie_logit(4) == parity.tie_logit(3)
-    assert parity.not_ties([8e-6]) == 1 and parity.not_ties([8e-6], encoder_bf16=4) == 0
+    assert parity.not_ties([1.2e-5]) == 1 and parity.not_ties([1.2e-5], encoder_bf16=4) == 0
     assert parity.not_ties([2.4e-7, -1.4e-7]) == 0        # the one tie of the 256^3 three-cloud dataset
+
+
+def test_two_logit_rule():
+    """parity.is_tie: the device's AND the CPU restatement's sign logit within the mode's threshold"""
+    assert parity.is_tie(-6.5e-6, -7.4e-6)                # query 46,971 of the 512^3 grid: the reference against itself
+    assert not parity.is_tie(2e-6, 3e-5) and not parity.is_tie(3e-5, 2e-6)
+    assert not parity.is_tie(1.5e-5, 1.5e-5) and parity.is_tie(1.5e-5, -1.5e-5, encoder_bf16=4)
