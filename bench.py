@@ -334,11 +334,12 @@ def dropin_leg(shapes, res, encoder, model='p2s_max'):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def golden_check(engine, parity, model, w, cfg, shapes, res, sdfs, tol, bf16):
+def golden_check(engine, parity, model, w, cfg, shapes, res, sdfs, tol, bf16, stride=1):
     """every query of the run ``sdfs`` (one array per shape, one stream from SEED_DATA in dataset order) against the
     goldens the unmodified reference wrote.  Signs: a flipped sign is accepted as a TIE only if BOTH the device's own sign
     logit and the CPU port's sign logit for that query (same inputs) lie within the encoder mode's tie threshold of zero
-    (parity.tie_logit: 1e-5 for the fp32 encoder, 2e-5 for the split-precision modes)."""
+    (parity.tie_logit: 1e-5 for the fp32 encoder, 2e-5 for the split-precision modes).
+    ``stride`` > 1: the golden holds every ``stride``-th query of every shape (the data-path golden's network subset)."""
     rec = {'shapes': [], 'queries': 0, 'max_abs_dsdf': 0.0, 'max_abs_diff_unmasked': 0.0, 'sign_flips': 0,
            'sign_flips_not_ties': 0, 'flipped': [], 'tie_logit': parity.tie_logit(bf16)}
     ok = True
@@ -346,7 +347,7 @@ def golden_check(engine, parity, model, w, cfg, shapes, res, sdfs, tol, bf16):
         if ref is None:
             rec['shapes'].append({'shape': name[:8], 'golden': None})
             continue
-        sdf = sdfs[si]
+        sdf = sdfs[si][::stride]
         if ref.shape != sdf.shape:
             rec['shapes'].append({'shape': name[:8], 'error': 'shape %s vs golden %s' % (sdf.shape, ref.shape)})
             ok = False
@@ -375,17 +376,17 @@ def golden_check(engine, parity, model, w, cfg, shapes, res, sdfs, tol, bf16):
                     c2.close()
                 cloud = engine.Cloud(pts)
                 q_all = cloud.query_grid(res, EPSILON)
-                patch, sub, one = engine.query_inputs(model, cloud, rng, q_all, int(j))
+                patch, sub, one = engine.query_inputs(model, cloud, rng, q_all, int(j) * stride)
                 lg_dev = float(model.forward(patch, sub, one)[0][0, 1])
                 lg_cpu = float(TorchPort(w, cfg).forward(patch.cpu().numpy(), sub.cpu().numpy(), one.cpu().numpy())[0, 1])
                 tie = parity.is_tie(lg_dev, lg_cpu, bf16)
                 not_ties += 0 if tie else 1
-                rec['flipped'].append({'shape': name[:8], 'query': int(j), 'sdf': float(sdf[j]), 'ref': float(ref[j]),
+                rec['flipped'].append({'shape': name[:8], 'query': int(j) * stride, 'sdf': float(sdf[j]), 'ref': float(ref[j]),
                                        'sign_logit_device': lg_dev, 'sign_logit_cpu_port': lg_cpu, 'tie': bool(tie)})
                 cloud.close()
                 rng.close()
         elif fl.size:
-            rec['flipped'] += [{'shape': name[:8], 'query': int(j), 'sdf': float(sdf[j]), 'ref': float(ref[j])} for j in fl[:16]]
+            rec['flipped'] += [{'shape': name[:8], 'query': int(j) * stride, 'sdf': float(sdf[j]), 'ref': float(ref[j])} for j in fl[:16]]
         srec['sign_flips_not_ties'] = not_ties
         rec['sign_flips_not_ties'] += not_ties
         rec['shapes'].append(srec)
@@ -394,6 +395,82 @@ def golden_check(engine, parity, model, w, cfg, shapes, res, sdfs, tol, bf16):
         # two bf16 pieces (modes 1 / 2, outside the contract) are reported only
         if cmp_['max_abs_dsdf'] > tol or (bf16 in (0, 3, 4) and not_ties):
             ok = False
+    return rec, ok
+
+
+def datapath_check(engine, shapes, res, golden, meta, batch=4096, progress=None):
+    """The DATA PATH of a whole data set against the unmodified reference's ``PointcloudPatchDataset.__getitem__``
+    (tests/golden/ref_datapath_<model>_<dataset>_grid<res>.npz, written by oracle/make_golden_datapath.py): the shapes in
+    dataset order from ONE generator, per block of 1024 queries the sha256 of the distance-weighted sub-sample ids
+    (p2s_subsample_weighted: every ``choice(N, 1000, replace=False, p)`` draw of the run, bit for bit), of the kNN patches
+    in patch space and of the radii (p2s_knn_patch), the generator state after every batch (where both sides hold it in
+    the same representation) and, through the next draws, after every shape.  -> (record, ok)"""
+    import hashlib
+    import torch
+    blk = int(meta['block'])
+    assert batch % blk == 0
+    rng = engine.Rng(int(meta['seed']))
+    rec = {'shapes': [], 'queries': 0, 'blocks': 0, 'ids_blocks_differ': 0, 'patch_blocks_differ': 0, 'radius_blocks_differ': 0,
+           'state_checkpoints': 0, 'state_checkpoints_differ': 0, 'state_checkpoints_other_representation': 0,
+           'state_after_shape_equal': []}
+    ok = True
+
+    def digests(a):
+        a = np.ascontiguousarray(a)
+        return [hashlib.sha256(a[i:i + blk].tobytes()).digest() for i in range(0, a.shape[0], blk)]
+
+    for si, (name, pts, _) in enumerate(shapes):
+        ms = meta['shapes'][si]
+        cloud = engine.Cloud(pts)
+        q = cloud.query_grid(res, EPSILON)
+        nq = int(q.shape[0])
+        srec = {'shape': name[:8], 'queries': nq,
+                'query_points_equal': hashlib.sha256(np.ascontiguousarray(q.cpu().numpy()).tobytes()).hexdigest() == ms['query_sha256']
+                and nq == ms['queries'] == ms['queries_run']}
+        ok = ok and srec['query_points_equal']
+        want = {k: [bytes(r) for r in golden['%s_sha_%d' % (k, si)]] for k in ('ids', 'patch', 'radius', 'state')}
+        bad = {'ids': 0, 'patch': 0, 'radius': 0}
+        for a in range(0, nq, batch):
+            b = min(a + batch, nq)
+            qb = q[a:b].contiguous()
+            ids = rng.subsample_weighted(cloud, qb, int(meta.get('sub_sample_size', 1000)), want_pts=False)[0]
+            _, patch, rad = cloud.knn_patch(qb, int(meta.get('points_per_patch', 300)), want_ids=False)
+            got = {'ids': digests(ids.cpu().numpy()), 'patch': digests(patch.cpu().numpy()), 'radius': digests(rad.cpu().numpy())}
+            b0 = a // blk
+            for k in bad:
+                bad[k] += sum(1 for i, d in enumerate(got[k]) if d != want[k][b0 + i])
+            mt, pos = rng.get_state()           # the state after the last block of this batch
+            dg = hashlib.sha256(np.ascontiguousarray(mt, dtype=np.uint32).tobytes() + np.int32(pos).tobytes()).digest()
+            rec['state_checkpoints'] += 1
+            if dg != want['state'][b0 + len(got['ids']) - 1]:
+                if pos in (0, 624):             # numpy twists lazily (pos 624), the device may hold the twisted array (pos 0)
+                    rec['state_checkpoints_other_representation'] += 1
+                else:
+                    rec['state_checkpoints_differ'] += 1
+            if progress:
+                progress(si, b, nq)
+        rng.check()
+        # the generator after the shape, through the next draws (representation-independent): numpy from the golden's
+        # state against the device from a snapshot
+        rs = np.random.RandomState(0)
+        rs.set_state(('MT19937', golden['state_key_%d' % si], int(golden['state_pos_%d' % si]), 0, 0.0))
+        snap = rng.get_state()
+        tail = rng.subsample_uniform(cloud, 1, 64, want_pts=False)[0].cpu().numpy().reshape(-1)
+        rng.set_state(*snap)
+        same = bool(np.array_equal(tail, rs.randint(0, pts.shape[0], 64)))
+        rec['state_after_shape_equal'].append(same)
+        srec.update({k + '_blocks_differ': v for k, v in bad.items()})
+        rec['shapes'].append(srec)
+        rec['queries'] += nq
+        rec['blocks'] += (nq + blk - 1) // blk
+        for k, v in bad.items():
+            rec[k + '_blocks_differ'] += v
+        ok = ok and same and not any(bad.values())
+        cloud.close()
+        torch.cuda.synchronize()
+    rng.close()
+    ok = ok and rec['state_checkpoints_differ'] == 0 and rec['state_checkpoints_other_representation'] <= 8
+    rec['bit_identical'] = bool(ok)
     return rec, ok
 
 
@@ -652,23 +729,36 @@ def main():
         # ---- after the timed region -----------------------------------------------------------------------------
         tol = 0.25 if bf16 == 1 else 1e-4      # north_star: SDF within 1e-4 fp32 of the reference (plain bf16: reported only)
         check = {}
-        # (1) the dataset as ONE stream from a fresh start, every query against the reference's goldens.  No golden for
-        # this (model, dataset, grid) -- p2s_vanilla's three-cloud run at 256^3 was never written (7 h of reference CPU) --:
-        # the test shape alone against its own golden
-        chk_shapes = shapes
+        # (1) the dataset as ONE stream from a fresh start, every query against the reference's goldens.  p2s_vanilla's
+        # three-cloud run at 256^3 has no full golden (7.5 h of reference CPU); it has the DATA-PATH golden instead
+        # (oracle/make_golden_datapath.py: the unmodified reference's dataset iterated over all 1,378,242 queries -- every
+        # weighted-choice draw, every patch, the generator state -- and its network on every 8th query of every shape)
+        chk_shapes, stride, dp = shapes, 1, None
         if golden_file is not None and not os.path.isfile(golden_file) and dataset == 'abc3':
-            gf = os.path.join(GOLDEN, 'ref_rec_%s_testset_grid%d.npz' % (mname, args.res))
+            key = 'ref_datapath_%s_abc3_grid%d' % (mname, args.res)
+            gf = os.path.join(GOLDEN, key + '.npz')
             if os.path.isfile(gf):
                 golden_file = gf
-                chk_shapes = [(shapes[2][0], shapes[2][1], np.load(gf)['rec_0'])]
+                with open(os.path.join(GOLDEN, 'meta_sizes.json')) as f:
+                    dp_meta = json.load(f)[key]
+                dp = (np.load(gf), dp_meta)
+                stride = int(dp_meta['stride'])
+                chk_shapes = [(n, pts, dp[0]['sdf_sub_%d' % i]) for i, (n, pts, _) in enumerate(shapes)]
         reseed(rng)
         sdfs = [complete_shape(engine, model, pts, rng, args.res, args.chunk)[0].numpy() for _, pts, _ in chk_shapes]
         if any(ref is not None for _, _, ref in chk_shapes):
-            rec, ok = golden_check(engine, parity, model, w, cfg, chk_shapes, args.res, sdfs, tol, bf16)
+            rec, ok = golden_check(engine, parity, model, w, cfg, chk_shapes, args.res, sdfs, tol, bf16, stride=stride)
             rec['file'] = os.path.relpath(golden_file, REPO)
+            if stride > 1:
+                rec['every_nth_query'] = stride
             check['vs_reference_golden'] = rec
             if not ok:
                 bail('against the reference golden', check)
+            if dp is not None:
+                drec, dok = datapath_check(engine, shapes, args.res, dp[0], dp[1])
+                rec['datapath'] = drec
+                if not dok:
+                    bail('data path (sub-sample ids / patches / generator state) against the reference', check)
         elif golden_file is not None:
             check['vs_reference_golden'] = {'file': os.path.relpath(golden_file, REPO), 'missing': True}
         # (1b) N > 1: rank 0 replays the WHOLE dataset stream from a fresh start -- every shape's draws consumed by the
@@ -741,7 +831,7 @@ def main():
             if what == 'grid32':           # the reference evaluated the 32^3 grid of the first shape: the device does the same
                 reseed(rng)
                 dev = complete_shape(engine, model, shapes[0][1], rng, 32, args.chunk)[0].numpy()
-            elif chk_shapes is shapes:
+            elif len(chk_shapes) == len(shapes):
                 dev = sdfs[0][:n]
             else:
                 reseed(rng)

@@ -132,7 +132,6 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
             items.push_back({&m->h_qc3, offs->qstn.c3, 128, 1024});
         }
         // fp16 pair mode: the encoder-side head layers (STN fc1..fc3, QSTN fc1 / fc2) run on fp16-pair MFMAs too
-        // (P2S_HEADS_F16=0: keep them fp32, development / A-B)
         m->heads_f16 = cfg->encoder_bf16 == 4;
         if (m->heads_f16) {
             for (int e = 0; e < 2; ++e) {

@@ -183,7 +183,6 @@ struct VolState {
     unsigned long long unknown0[NSHARD];    // zeros of the initial sign field
     int done, final_buf, iters, err;
     int lcount[3][8];                        // entries of the active-tile list of generation k % 3, per XCD slab
-    unsigned long long tiles_run[NSHARD];   // tiles evaluated over the whole run (P2S_VOLUME_STATS), sharded like the counters
 };
 // host-visible mailbox (pinned, coherent): the host reads it while the sweeps run -- no copy, no event in the stream
 struct VolMail {
@@ -436,7 +435,6 @@ __global__ __launch_bounds__(256, 4) void vol_sweep_kernel(unsigned char *__rest
     }
     const int n_act = s_n;
     if (n_act == 0) return;
-    if (tid == 0) atomicAdd(&vs->tiles_run[wg & (NSHARD - 1)], (unsigned long long)n_act);
     cur = vol_tile(s_list[0], tz_n, ty_n);
     vol_tile_load(w, rsrc, cur, res, tid);
     // All sums are kept BIASED: sign + 1 in {0, 1, 2} per byte, so the z / zy / zyx sums are <= 10 / 50 / 250 -- plain

@@ -14,7 +14,8 @@ port); the ranks shard the shapes (points2surf_amd/sharding.py).  ``P2S_GPUS=<n>
 Only scripts whose every stage is rank-aware are ever started as several ranks (``RANK_AWARE_SCRIPTS``: ``full_eval.py``
 -- the drop-in's eval, mesh and comparison stages shard or run on rank 0).  Anything else -- ``full_run.py`` calls the
 reference's own ``points_to_surf_train``, ``make_dataset.py`` writes a data set -- runs in ONE process: N copies of a
-training would all write ``models/<name>_model.pth`` and the logs.  ``P2S_GPUS=<n>`` with such a script is refused.
+training would all write ``models/<name>_model.pth`` and the logs.  ``P2S_GPUS=<n>`` with such a script is refused, and so
+is such a script under torchrun with more than one rank (``WORLD_SIZE`` > 1).
 
 Why a launcher: ``python full_eval.py`` puts the script's directory at ``sys.path[0]``, i.e. BEFORE anything on
 ``PYTHONPATH``, so ``from source import points_to_surf_eval`` would find the reference's own ``source`` package first.
@@ -67,6 +68,11 @@ def main(argv=None):
     script = os.path.abspath(argv[0])
     if not os.path.isfile(script):
         raise SystemExit('points2surf_amd.dropin.run: no such script: %s' % argv[0])
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and os.path.basename(script) not in RANK_AWARE_SCRIPTS:
+        # torchrun --nproc-per-node N -m points2surf_amd.dropin.run full_run.py: N trainings writing the same model files
+        raise SystemExit('points2surf_amd.dropin.run: WORLD_SIZE=%s, but %s is not rank-aware (only %s are): its stages '
+                         'would run once per rank and overwrite each other\'s files -- start it as ONE process'
+                         % (os.environ['WORLD_SIZE'], os.path.basename(script), ', '.join(RANK_AWARE_SCRIPTS)))
     n = ranks_to_spawn(script=script)
     if n:
         import socket

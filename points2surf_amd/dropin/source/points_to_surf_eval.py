@@ -293,21 +293,25 @@ def points_to_surf_eval(eval_opt):
             and reconstruction
         owner, handoff = None, None
         if world > 1 and reconstruction and not shard_queries:
+            if not per_shape_rng and _sharding.stream_handoff_enabled():
+                # keys are written once per store: every call of this function (all ranks make the same calls in the
+                # same order) gets its own key space.  Created BEFORE the count loop below: a rank that fails there (a
+                # missing or corrupt cloud file, out of memory) leaves its failure record, peers raise instead of polling
+                global _HANDOFF_SEQ
+                _HANDOFF_SEQ += 1
+                handoff = _sharding.StreamHandoff('eval%d/%s' % (_HANDOFF_SEQ, model_name), [], rank=rank)
             # ONE policy (sharding.assign_shapes, also bench.py's): LPT over the shapes' query counts -- every rank
             # voxelises every cloud once up front (upload + index + grid: ~1.5 ms per shape) and gets the same list
             counts = []
-            for n in shape_names:
-                c = _engine.Cloud(_load_points(eval_opt.indir, n), device=device)
-                counts.append(c.count_queries(eval_opt.query_grid_resolution, eval_opt.epsilon))
-                c.close()
+            with (handoff.guard(-1) if handoff is not None else contextlib.nullcontext()):
+                for n in shape_names:
+                    c = _engine.Cloud(_load_points(eval_opt.indir, n), device=device)
+                    counts.append(c.count_queries(eval_opt.query_grid_resolution, eval_opt.epsilon))
+                    c.close()
             parts, owner = _sharding.assign_shapes(counts, world)
             mine = set(parts[rank])
-            if not per_shape_rng and _sharding.stream_handoff_enabled():
-                # keys are written once per store: every call of this function (all ranks make the same calls in the
-                # same order) gets its own key space
-                global _HANDOFF_SEQ
-                _HANDOFF_SEQ += 1
-                handoff = _sharding.StreamHandoff('eval%d/%s' % (_HANDOFF_SEQ, model_name), owner, rank=rank)
+            if handoff is not None:
+                handoff.owner = list(owner)
         total_q = 0
         t0 = time.time()
         # result files are written on background threads while the next shape is on the GPU (np.savetxt alone
@@ -381,11 +385,10 @@ def points_to_surf_eval(eval_opt):
                     rng_rot = _engine.Rng((eval_opt.seed + shape_ind) & 0xffffffff, device=device)
             if shape_ind not in mine and handoff is not None:
                 continue                   # exact stream by hand-off: a rank never touches a foreign shape
-            pts_np = _load_points(eval_opt.indir, shape_name)
             if shape_ind not in mine:
                 # no process group (ranks run one after the other) / P2S_STREAM_HANDOFF=replicate: keep the
                 # dataset-wide stream exact on every rank by consuming this shape's draws without inference
-                cloud = _engine.Cloud(pts_np, device=device)
+                cloud = _engine.Cloud(_load_points(eval_opt.indir, shape_name), device=device)
                 try:
                     _sharding.skip_shape_stream(cloud, rng_dev, cfg, eval_opt.query_grid_resolution,
                                                 eval_opt.epsilon, model.sub_sample_size, rng_patch=rng_rot)
@@ -394,6 +397,7 @@ def points_to_surf_eval(eval_opt):
                 continue
             guard = handoff.guard(shape_ind) if handoff is not None else contextlib.nullcontext()
             with guard:                    # an exception here leaves a 'failed' record: waiting ranks raise, not hang
+                pts_np = _load_points(eval_opt.indir, shape_name)      # (inside the guard: a missing / corrupt file too)
                 if handoff is not None:
                     rngs = [rng_dev] + ([rng_rot] if rng_rot is not None else [])
                     handoff.begin(shape_ind, rngs)         # waits until the owner of the shape before has published

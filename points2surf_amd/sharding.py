@@ -136,8 +136,11 @@ def query_range(n_queries, world, rank):
 
 def skip_queries(cloud, rng_dev, cfg, queries, sub_sample_size, chunk=4096, rng_patch=None):
     """advance the RNG stream past ``queries`` ([m,3] device tensor, in order) without inference.  Fixed-radius models:
-    ``rng_patch`` (the data set's first generator) is advanced past the patch choices of the same queries.  (``chunk``: kept for
-    callers of earlier rounds; the library chooses its own batches.)"""
+    ``rng_patch`` (the data set's first generator) is advanced past the patch choices of the same queries.
+    ``chunk``: DEPRECATED and ignored (the library chooses its own batches); passing anything but the default warns."""
+    if chunk != 4096:
+        import warnings
+        warnings.warn('sharding.skip_queries / skip_shape_stream: the chunk argument is ignored', DeprecationWarning, stacklevel=2)
     m = int(queries.shape[0])
     if m == 0:
         return
@@ -247,8 +250,9 @@ class StreamHandoff:
         """tell the ring that shape ``i`` of this rank raised: every rank waiting in ``begin`` raises instead of hanging"""
         try:
             if not self.store.check([self._failed_key()]):          # the first failure stays on record
-                self.store.set(self._failed_key(), ('rank %d failed at shape %d: %s: %s'
-                                                    % (self.rank, i, type(exc).__name__, exc))[:2000])
+                where = 'at shape %d' % i if i >= 0 else 'before its first shape (loading / counting the data set)'
+                self.store.set(self._failed_key(), ('rank %d failed %s: %s: %s'
+                                                    % (self.rank, where, type(exc).__name__, exc))[:2000])
         except Exception:
             pass                         # the store itself is gone: the process group's own timeout takes over
 

@@ -66,13 +66,22 @@ def test_launcher_uses_all_visible_devices_by_default(tmp_path, monkeypatch):
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '4711'
     assert cmd[-5:] == ['-m', 'points2surf_amd.dropin.run', '/x/full_eval.py', '--indir', 'd']
     # end to end: two ranks (P2S_GPUS=2 with a faked device count) run the SCRIPT, each with its own RANK
-    script = tmp_path / 's.py'
+    script = tmp_path / 'full_eval.py'            # (a rank-aware NAME: anything else is refused under WORLD_SIZE > 1)
     script.write_text("import os\nopen(os.path.join(%r, 'rank_' + os.environ['RANK']), 'w').write(os.environ['WORLD_SIZE'])\n" % str(tmp_path))
     monkeypatch.setattr(run, 'ranks_to_spawn', lambda environ=None, device_count=None, script=None: 0 if 'WORLD_SIZE' in os.environ else 2)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
         monkeypatch.delenv(k, raising=False)
     assert run.main([str(script)]) == 0
     assert (tmp_path / 'rank_0').read_text() == '2' and (tmp_path / 'rank_1').read_text() == '2'
+    # torchrun --nproc-per-node N -m points2surf_amd.dropin.run full_run.py -- N trainings into the same files: refused
+    other = tmp_path / 'full_run.py'
+    other.write_text('raise SystemExit("must not run")\n')
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    with pytest.raises(SystemExit, match='not rank-aware'):
+        run.main([str(other)])
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    with pytest.raises(SystemExit, match='must not run'):          # one process: runs
+        run.main([str(other)])
 
 
 def test_clock_sampler_reads_hwmon_files(tmp_path):

@@ -1,0 +1,105 @@
+"""GPU: the workload ``bench.py --model p2s_vanilla`` times (BASELINE configs[3]'s 1-GPU line) pinned to the reference --
+VERDICT r5 item 1.  The three abc_minimal clouds as ONE data set at 256^3: 1,378,242 ``choice(N, 1000, replace=False, p)``
+draws from one generator, the start of every draw depending on every redraw before it.  The golden
+(oracle/make_golden_datapath.py, ~70 min of reference CPU) is the UNMODIFIED reference's ``PointcloudPatchDataset`` iterated
+in evaluation order: per block of 1024 queries the sha256 of the sub-sample ids, of the kNN patches and radii and of the
+generator state; the generator after every shape; and the reference's network + post-processing on every 8th query of
+every shape.  The device side: p2s_subsample_weighted / p2s_knn_patch over all queries (bench.datapath_check), and the
+fused pipeline (p2s_infer_shape, fp32 and fp16-pair encoders) against the network subset."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import missing_golden, flip_logits
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location('p2s_bench', os.path.join(REPO, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def _golden(res):
+    key = 'ref_datapath_p2s_vanilla_abc3_grid%d' % res
+    path = os.path.join(GOLDEN, key + '.npz')
+    if not os.path.isfile(path):
+        missing_golden(key)
+    with open(os.path.join(GOLDEN, 'meta_sizes.json')) as f:
+        return np.load(path), json.load(f)[key]
+
+
+def _shapes(bench):
+    return [(n, np.ascontiguousarray(np.load(bench.cloud_path(n))[:, :3], dtype=np.float32), None) for n in bench.ABC3]
+
+
+@pytest.mark.parametrize('res', [32, 256])
+def test_every_draw_of_the_dataset_stream_matches_the_reference(res):
+    """sub-sample ids, patches, radii of ALL queries (13,550 at 32^3; 1,378,242 at 256^3) and the generator state along the
+    way -- bit for bit what the reference's dataset handed to its network"""
+    from points2surf_amd import engine
+    bench = _bench()
+    g, meta = _golden(res)
+    rec, ok = bench.datapath_check(engine, _shapes(bench), res, g, meta)
+    print(json.dumps({k: v for k, v in rec.items() if k != 'shapes'}))
+    assert ok, rec
+    assert rec['queries'] == meta['queries_total'] == sum(s['queries'] for s in meta['shapes'])
+    assert rec['ids_blocks_differ'] == rec['patch_blocks_differ'] == rec['radius_blocks_differ'] == 0
+    assert rec['state_checkpoints_differ'] == 0 and all(rec['state_after_shape_equal'])
+    # the checkpoints really compared states: nearly all of them in the same representation
+    assert rec['state_checkpoints'] - rec['state_checkpoints_other_representation'] >= 0.9 * rec['state_checkpoints']
+
+
+@pytest.mark.parametrize('encoder', [0, 4])
+@pytest.mark.parametrize('res', [32, 256])
+def test_pipeline_matches_the_reference_network_on_the_strided_subset(res, encoder):
+    """the fused pipeline over the three clouds as one stream (what the bench times) against the reference's network +
+    post-processing on every 8th query of every shape (172,282 queries at 256^3) -- each of them sits at a stream
+    position that depends on all draws before it.  |dSDF| < 1e-4; a flipped sign only as a tie by the two-logit rule."""
+    import torch
+    from points2surf_amd import engine, synth, parity, sharding
+    bench = _bench()
+    g, meta = _golden(res)
+    stride = meta['stride']
+    w, cfg = synth.make_weights('p2s_vanilla')
+    model = engine.Model(w, dict(cfg, encoder_bf16=encoder))
+    rng = engine.Rng(meta['seed'])
+    shapes = _shapes(bench)
+    outs = []
+    for _, pts, _ in shapes:
+        cloud = engine.Cloud(pts)
+        sdf, q = engine.infer_shape(model, cloud, rng, res, 3)
+        torch.cuda.synchronize()
+        outs.append((sdf.cpu().numpy(), q))
+        cloud.close()
+    rng.check()
+    worst, flips, total = 0.0, [], 0
+    for si, (sdf, q) in enumerate(outs):
+        ref = g['sdf_sub_%d' % si]
+        assert sdf[::stride].shape == ref.shape
+        c = parity.compare_sdf(sdf[::stride], ref)
+        worst = max(worst, c['max_abs_dsdf'])
+        flips += [(si, int(j) * stride) for j in c['flipped']]
+        total += ref.size
+    print('encoder %d, grid %d: max|dSDF| %.3g over %d queries, flips %s' % (encoder, res, worst, total, flips))
+    assert total == meta['queries_network'] and worst < 1e-4 and len(flips) <= 8
+    for si, j in flips:                                   # each flip: a tie by device AND CPU-port logit
+        r2 = engine.Rng(meta['seed'])
+        for _, p2, _ in shapes[:si]:
+            c2 = engine.Cloud(p2)
+            sharding.skip_shape_stream(c2, r2, cfg, res, 3, model.sub_sample_size)
+            c2.close()
+        cloud = engine.Cloud(shapes[si][1])
+        lg = flip_logits(model, w, cfg, cloud, r2, outs[si][1], j)
+        print('shape %d query %d: sign logits device %.3g / CPU port %.3g (golden logit %.3g)'
+              % (si, j, lg[0], lg[1], g['logits_sub_%d' % si][j // stride, 1]))
+        assert parity.is_tie(lg[0], lg[1], encoder_bf16=encoder), (si, j, lg)
+        cloud.close()
+    model.close()

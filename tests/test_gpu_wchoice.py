@@ -232,3 +232,32 @@ def test_weighted_at_the_size_cap(torch_cuda):
     big = engine.Cloud(g.uniform(-0.7, 0.7, (480000, 3)).astype(np.float32))
     with pytest.raises(_lib.P2SError):
         engine.Rng(3).subsample_weighted(big, torch_cuda.from_numpy(q).cuda(), 1000, want_pts=False)
+
+
+@pytest.mark.parametrize('n_pts,nq', [(1100, 2300), (2500, 2300), (6000, 4300)])
+def test_skip_path_equals_ids_path_on_collision_heavy_clouds(n_pts, nq, torch_cuda):
+    """the NULL-ids skip (hand-off mode, query-range sharding) trusts the offsets pass -- tentative verdicts, band
+    look-ups, jump tables -- without the ids kernel's ``base + used != next`` cross-check behind it.  Clouds barely larger
+    than the sub-sample make collisions the rule (1000 of 1100 points: hundreds of redraws per query over many rounds, every
+    candidate 'undecided' -> the complete algorithm in place; 2500 / 6000: ~200 / ~80 first-round collisions, the band
+    kernel's territory) over more than one block of 2048 queries: the generator state after the skip must equal the state
+    after the ids path AND numpy's, and the ids numpy's."""
+    from points2surf_amd import engine
+    g = np.random.default_rng(n_pts)
+    pts = (g.normal(0, 0.25, (n_pts, 3)) * np.array([1.0, 0.6, 0.3])).astype(np.float32)
+    q = (pts[g.integers(0, n_pts, nq)] + g.normal(0, 0.03, (nq, 3))).astype(np.float32)
+    cloud = engine.Cloud(pts)
+    qd = torch_cuda.from_numpy(q).cuda()
+    r = engine.Rng(99)
+    ids = r.subsample_weighted(cloud, qd, 1000, want_pts=False)[0].cpu().numpy()
+    r.check()
+    r2 = engine.Rng(99)
+    r2.skip(cloud, 1000, query_ms=qd)
+    r2.check()
+    mt, pos = r.get_state()
+    mt2, pos2 = r2.get_state()
+    assert pos == pos2 and np.array_equal(mt, mt2)
+    ref, rs = _numpy_reference(99, pts, q, 1000)
+    assert np.array_equal(ids, ref)
+    tail = r2.subsample_uniform(cloud, 1, 64, want_pts=False)[0].cpu().numpy().reshape(-1)
+    assert np.array_equal(tail, rs.randint(0, n_pts, 64))

@@ -255,3 +255,48 @@ def test_stream_handoff_finish_raises_on_a_rank_that_failed_after_the_others_wer
     assert out[1][1].startswith('raised ValueError: injected late failure')
     assert out[0][1].startswith('raised RuntimeError: stream hand-off (late): rank 0 is through with its shapes, but rank 1 failed at shape 1'), out[0]
     assert out[0][0] < 30.0
+
+
+def _handoff_early_failure_worker(rank, world, port, outdir):
+    """the drop-in's order of events (points_to_surf_eval): the hand-off object exists BEFORE the per-rank loop that loads
+    and counts every shape; rank 1 fails inside that loop (a corrupt cloud file), rank 0 gets as far as waiting for a token"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    sharding.init_process_group('gloo')
+    a = _FakeRng(7)
+    h = sharding.StreamHandoff('early', [], rank=rank, timeout_s=120.0)
+    t0 = time.time()
+    what = 'finished'
+    try:
+        with h.guard(-1):
+            if rank == 1:
+                raise OSError('cloud file truncated')
+        h.owner = [1, 0]                                   # rank 0 owns shape 1: waits for rank 1's token
+        for i in [k for k, o in enumerate(h.owner) if o == rank]:
+            with h.guard(i):
+                h.begin(i, [a])
+                a.consume(DRAWS[i])
+                h.done(i)
+        h.finish()
+    except OSError as e:
+        what = 'raised OSError: %s' % e
+    except RuntimeError as e:
+        what = 'raised RuntimeError: %s' % e
+    with open(os.path.join(outdir, 'early_%d.txt' % rank), 'w') as f:
+        f.write('%.2f\n%s\n' % (time.time() - t0, what))
+    dist.destroy_process_group()
+
+
+def test_stream_handoff_failure_before_the_first_shape(tmp_path):
+    """ADVICE r5: a rank that fails while it loads / counts the data set (before any shape is its turn) leaves a record too;
+    the rank waiting for its token raises within seconds and says where the other one failed"""
+    port = _free_port()
+    mp.spawn(_handoff_early_failure_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    out = {}
+    for r in range(2):
+        with open(os.path.join(str(tmp_path), 'early_%d.txt' % r)) as f:
+            secs, what = f.read().split('\n')[:2]
+        out[r] = (float(secs), what)
+    assert out[1][1].startswith('raised OSError: cloud file truncated')
+    assert 'rank 1 failed before its first shape' in out[0][1] and 'cloud file truncated' in out[0][1], out[0]
+    assert out[0][0] < 30.0
