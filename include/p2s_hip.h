@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define P2S_ABI_VERSION 4
+#define P2S_ABI_VERSION 5
 
 #define P2S_OK            0
 #define P2S_EINVAL       -1   /* bad argument / unsupported configuration */
@@ -70,8 +70,9 @@ typedef struct {
                                     product, 16 / 24 mantissa bits).  4: fp16 PAIR per operand, x = h0 + h1 * 2^-11 with
                                     the residual scaled into the normal range and a second accumulator (3 fp16 MFMAs per
                                     product, 22 mantissa bits): as exact as fp32 on the reference's goldens at 2.5x its
-                                    throughput; activations beyond the half range (6e4) poison the query AND make the
-                                    next p2s_infer_shape / p2s_infer_queries return P2S_EINVAL.  See DESIGN.md        */
+                                    throughput.  A query with an activation beyond the half range (6e4) is re-run through
+                                    the fp32 kernels inside the same call (p2s_counters.fallback_queries counts them; more
+                                    than 16384 per call: P2S_EINVAL) -- safe for an arbitrary checkpoint.  See DESIGN.md  */
     int32_t fixed_subsample;     /* train --fixed_subsample 1 (ablation): the generator is re-seeded with 42 before every
                                     query's draw (reference source/base/utils.py:210-211)                       */
     int32_t single_transformer;  /* train --single_transformer 1 (p2s_shared_encoder): ONE encoder over cat(patch,
@@ -301,6 +302,13 @@ int p2s_random_rotations(p2s_rng_t r, int64_t n, double *rot_out_dev, void *stre
  *   [n_items][points_per_item][3] (may alias), rot_dev [n_items][9] float64 */
 int p2s_rotate_points(const double *rot_dev, const float *pts_in_dev, int points_per_item, int64_t n_items,
                       float *pts_out_dev, void *stream);
+/* One-shot capture of the decoder's raw logits: the NEXT p2s_infer_shape / p2s_infer_shape_ball / p2s_infer_queries call on
+ * this model also writes logits_out_dev [processed queries][output_dim] (column output_dim - 1 = the sign logit, or the one
+ * signed-distance logit of the regression model) -- what post_process (reference source/points_to_surf_eval.py:174-196)
+ * starts from.  The drop-in's tie report (P2S_TIE_REPORT) lists the queries whose sign logit lies within fp32 noise of the
+ * reference's decision ``logit >= 0`` (source/sdf_nn.py:16-21).  capacity_queries < the queries of that call: the call
+ * returns P2S_ECAPACITY.  capacity_queries = 0 cancels. */
+int p2s_model_capture_logits(p2s_model_t m, float *logits_out_dev, int64_t capacity_queries);
 /* test hook: the next pipeline call on this model fails with P2S_EHIP before chunk `chunk_index` (-1 = off) */
 int p2s_debug_fault_chunk(p2s_model_t m, int chunk_index);
 
@@ -384,7 +392,8 @@ typedef struct {
     int64_t queries;
     int64_t launches_chain;      /* number of point-chain kernel launches (2 per chunk; 3 with a QSTN) */
     double  ms_chain_qstn;       /* QSTN trunk launch (models with use_point_stn); its head layers count under ms_stn_head */
-    double  reserved[7];
+    int64_t fallback_queries;    /* fp16 pair encoder: queries of the call re-run through the fp32 kernels (activation > 6e4) */
+    double  reserved[6];
 } p2s_counters;
 int p2s_set_profiling(p2s_model_t m, int enabled);
 int p2s_get_counters(p2s_model_t m, p2s_counters *out);

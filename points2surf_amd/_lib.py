@@ -22,7 +22,8 @@ class Counters(ctypes.Structure):
                 ('ms_chain_main', ctypes.c_double), ('ms_decoder', ctypes.c_double),
                 ('ms_knn', ctypes.c_double), ('ms_subsample', ctypes.c_double), ('ms_grid', ctypes.c_double),
                 ('queries', ctypes.c_int64), ('launches_chain', ctypes.c_int64),
-                ('ms_chain_qstn', ctypes.c_double), ('reserved', ctypes.c_double * 7)]
+                ('ms_chain_qstn', ctypes.c_double), ('fallback_queries', ctypes.c_int64),
+                ('reserved', ctypes.c_double * 6)]
 
 
 # name -> (restype, argtypes): every symbol include/p2s_hip.h declares
@@ -83,6 +84,7 @@ PROTOTYPES = {
                                       ctypes.POINTER(ctypes.c_double), c_void_p]),
     'p2s_set_profiling': (c_int, [c_void_p, c_int]),
     'p2s_get_counters': (c_int, [c_void_p, ctypes.POINTER(Counters)]),
+    'p2s_model_capture_logits': (c_int, [c_void_p, c_void_p, c_int64]),
     'p2s_write_txt_f32': (c_int, [ctypes.c_char_p, c_void_p, c_int64]),
     'p2s_write_query_vis_ply': (c_int, [ctypes.c_char_p, c_void_p, c_void_p, c_int64]),
     'p2s_write_coff_samples': (c_int, [ctypes.c_char_p, c_void_p, c_void_p, c_int64]),

@@ -166,20 +166,53 @@ int p2s_model_create(const p2s_model_cfg *cfg, const float *blob_host, size_t n_
             p2s_set_error("hipMalloc(bf16 weights) failed");
             return P2S_ENOMEM;
         }
+        int *wflag = nullptr;       // fp16 pair: raised by the packing kernel when a BN-folded weight does not fit the half range
+        if (f16 && (hipMalloc(&wflag, 4) != hipSuccess || hipMemset(wflag, 0, 4) != hipSuccess)) {
+            (void)hipGetLastError();
+            p2s_model_destroy(m);
+            p2s_set_error("hipMalloc(weight range flag) failed");
+            return P2S_ENOMEM;
+        }
         for (int piece = 0; piece < ns; ++piece)
             for (auto &it : items) {
                 const int rc = p2s_launch_pack_bf16(m->blob + it.src, m->blob_h + (size_t)piece * total + *it.dst, it.K, it.N, 0, 0,
-                                                    1, piece, f16, nullptr);
+                                                    1, piece, f16, nullptr, wflag);
                 if (rc) {
+                    if (wflag) (void)hipFree(wflag);
                     p2s_model_destroy(m);
                     return rc;
                 }
             }
         if (f16) {
-            if (hipMalloc(&m->range_flag, 4) != hipSuccess || hipMemset(m->range_flag, 0, 4) != hipSuccess) {
+            int h = 0;
+            const hipError_t e2 = hipMemcpy(&h, wflag, 4, hipMemcpyDeviceToHost);
+            (void)hipFree(wflag);
+            if (e2 != hipSuccess || h) {
+                p2s_model_destroy(m);
+                if (e2 != hipSuccess) {
+                    p2s_set_error("hipMemcpy(weight range flag) failed: %s", hipGetErrorString(e2));
+                    return P2S_EHIP;
+                }
+                p2s_set_error("fp16 pair encoder (encoder_bf16 = 4): a BatchNorm-folded weight of this checkpoint does not fit the half "
+                              "range (|w| > 6e4, or non-finite) -- use encoder_bf16 = 3 (the same accuracy) or 0 for this model");
+                return P2S_EINVAL;
+            }
+            // side buffers of the fp32 fallback: inputs + results of up to 16384 flagged queries per call (256 MB at k = 300,
+            // n = 1000; touched only when a query is flagged)
+            p2s_model_s::Fallback &fb = m->fb;
+            fb.cap = 16384;
+            const size_t k3 = (size_t)cfg->points_per_patch * 3, n3 = (size_t)cfg->sub_sample_size * 3, cap = fb.cap;
+            bool ok = hipMalloc(&fb.flags, (size_t)m->max_chunk * 4) == hipSuccess && hipMalloc(&fb.count, 4) == hipSuccess &&
+                      hipMalloc(&fb.patch, cap * k3 * 4) == hipSuccess && hipMalloc(&fb.sub, cap * n3 * 4) == hipSuccess &&
+                      hipMalloc(&fb.query, cap * 12) == hipSuccess && hipMalloc(&fb.radius, cap * 4) == hipSuccess &&
+                      hipMalloc(&fb.index, cap * 8) == hipSuccess && hipMalloc(&fb.sdf, cap * 4) == hipSuccess &&
+                      hipMalloc(&fb.logits, cap * 8) == hipSuccess;
+            ok = ok && hipMemset(fb.flags, 0, (size_t)m->max_chunk * 4) == hipSuccess && hipMemset(fb.count, 0, 4) == hipSuccess &&
+                 hipMemset(fb.radius, 0, cap * 4) == hipSuccess;
+            if (!ok) {
                 (void)hipGetLastError();
                 p2s_model_destroy(m);
-                p2s_set_error("hipMalloc(range flag) failed");
+                p2s_set_error("hipMalloc(fp32 fallback buffers of the fp16 pair mode) failed");
                 return P2S_ENOMEM;
             }
         }
@@ -196,7 +229,9 @@ int p2s_model_destroy(p2s_model_t m) {
     if (m->ws) (void)hipFree(m->ws);
     if (m->blob) (void)hipFree(m->blob);
     if (m->blob_h) (void)hipFree(m->blob_h);
-    if (m->range_flag) (void)hipFree(m->range_flag);
+    for (void *p : {(void *)m->fb.flags, (void *)m->fb.count, (void *)m->fb.patch, (void *)m->fb.sub, (void *)m->fb.query,
+                    (void *)m->fb.radius, (void *)m->fb.index, (void *)m->fb.sdf, (void *)m->fb.logits})
+        if (p) (void)hipFree(p);
     for (auto &ev : m->evpool)
         if (ev) (void)hipEventDestroy(ev);
     if (m->aux) (void)hipStreamDestroy(m->aux);
@@ -280,10 +315,51 @@ Ws carve(const p2s_model_s *m, int C) {
 
 }  // namespace
 
+// fp16 pair mode: one workgroup per query of the chunk; a flagged query (ChainArgs.bad_items / GemmArgs.bad_rows) takes the
+// next slot of the side buffers and its network inputs are copied there
+__global__ __launch_bounds__(256) void p2s_fb_collect_kernel(int *__restrict__ flags, int *__restrict__ count, int cap,
+                                                             const float *__restrict__ patch, const float *__restrict__ sub,
+                                                             const float *__restrict__ query, const float *__restrict__ radius,
+                                                             int k3, int n3, long long index0, float *__restrict__ fpatch,
+                                                             float *__restrict__ fsub, float *__restrict__ fquery,
+                                                             float *__restrict__ fradius, long long *__restrict__ findex) {
+    __shared__ int s_slot;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int slot = -1;
+        if (flags[q]) {
+            flags[q] = 0;
+            slot = atomicAdd(count, 1);
+        }
+        s_slot = slot;
+    }
+    __syncthreads();
+    const int slot = s_slot;
+    if (slot < 0 || slot >= cap) return;
+    for (int i = tid; i < k3; i += 256) fpatch[(size_t)slot * k3 + i] = patch[(size_t)q * k3 + i];
+    for (int i = tid; i < n3; i += 256) fsub[(size_t)slot * n3 + i] = sub[(size_t)q * n3 + i];
+    if (tid < 3) fquery[(size_t)slot * 3 + tid] = query[(size_t)q * 3 + tid];
+    if (tid == 3) {
+        if (radius) fradius[slot] = radius[q];
+        findex[slot] = index0 + q;
+    }
+}
+
+__global__ void p2s_fb_scatter_kernel(const long long *__restrict__ index, const float *__restrict__ sdf,
+                                      const float *__restrict__ logits, int n, int od, float *__restrict__ sdf_out,
+                                      float *__restrict__ logits_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long d = index[i];
+    if (sdf_out) sdf_out[d] = sdf[i];
+    if (logits_out)
+        for (int j = 0; j < od; ++j) logits_out[d * od + j] = logits[(size_t)i * od + j];
+}
+
 // One chunk (C <= ws_chunk queries) through encoders (+ decoder if want_decode).
 int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const float *query, const float *radius,
                   int C, float *logits_out, float *sdf_out, float *feat_local_out, float *feat_global_out,
-                  hipStream_t s) {
+                  hipStream_t s, long long index0) {
     const p2s_weight_offsets &o = m->offs;
     const float *W = m->blob;
     const int PL = m->cfg.points_per_patch, PG = m->cfg.sub_sample_size;
@@ -302,7 +378,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         memset(&a, 0, sizeof(a));
         a.ns = p2s_enc_pieces(m->cfg);
         a.f16 = p2s_enc_f16(m->cfg);
-        a.range_flag = m->range_flag;
+        a.bad_items = m->fb.flags;
         a.piece_stride = (long long)m->h_total;
         a.w1_piece_stride = (long long)2 * C * 4096;
         ChainBranch &b = a.br[0];
@@ -335,7 +411,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         g.A = w.qg; g.A2 = qstn_shared ? w.qg2 : nullptr; g.a2_z = 0; g.lda = 1024; g.a_z = 0; g.W[0] = g.W[1] = W + o.qstn.f1; g.bias[0] = g.bias[1] = W + o.qstn.fb1;
         g.C = w.qh1; g.ldc = 512; g.c_z = 0; g.M = C; g.N = 512; g.K = 1024; g.Z = 1; g.relu = 1;
         if (m->heads_f16) {
-            g.Wh[0] = g.Wh[1] = m->blob_h + m->h_qf1; g.wh_piece = (long long)m->h_total; g.range_flag = m->range_flag;
+            g.Wh[0] = g.Wh[1] = m->blob_h + m->h_qf1; g.wh_piece = (long long)m->h_total; g.bad_rows = m->fb.flags;
         }
         if ((rc = p2s_launch_gemm(g, s))) return rc;
         g.A = w.qh1; g.A2 = nullptr; g.lda = 512; g.W[0] = g.W[1] = W + o.qstn.f2; g.bias[0] = g.bias[1] = W + o.qstn.fb2;
@@ -352,7 +428,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
     memset(&a, 0, sizeof(a));
     a.ns = p2s_enc_pieces(m->cfg);
     a.f16 = p2s_enc_f16(m->cfg);
-    a.range_flag = m->range_flag;
+    a.bad_items = m->fb.flags;
     a.piece_stride = (long long)m->h_total;
     a.w1_piece_stride = (long long)2 * C * 4096;
     for (int slot = 0; slot < 2; ++slot) {
@@ -391,7 +467,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         g.C = w.h1; g.ldc = 512; g.c_z = (long long)C * 512; g.N = 512; g.K = 1024;
         if (m->heads_f16) {
             g.Wh[0] = m->blob_h + m->h_sf1[0]; g.Wh[1] = m->blob_h + m->h_sf1[1];
-            g.wh_piece = (long long)m->h_total; g.range_flag = m->range_flag;
+            g.wh_piece = (long long)m->h_total; g.bad_rows = m->fb.flags;
         }
         if ((rc = p2s_launch_gemm(g, s))) return rc;
         g.A = w.h1; g.A2 = nullptr; g.lda = 512; g.a_z = (long long)C * 512;
@@ -415,6 +491,7 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
         f.h_piece_stride = (long long)2 * C * 4096;
         f.ns = p2s_enc_pieces(m->cfg);
         f.f16 = p2s_enc_f16(m->cfg);
+        f.bad_items = f.f16 ? m->fb.flags : nullptr;
         f.n_items = C;
         if ((rc = p2s_launch_fold(f, s))) return rc;
     }
@@ -477,19 +554,51 @@ int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const fl
     p2s_prof_span(m, ST_HEAD, ev1, ev2);
     p2s_prof_span(m, ST_CHAIN_MAIN, ev2, ev3);
     p2s_prof_span(m, ST_DECODER, ev3, ev4);
+    if (m->cfg.encoder_bf16 == 4 && m->fb.flags) {
+        // fp16 pair mode: the inputs of the queries the 16-bit kernels flagged are put aside (the chunk buffers are reused
+        // two chunks on); one workgroup per query, all but the flagged ones return at once
+        hipLaunchKernelGGL(p2s_fb_collect_kernel, dim3(C), dim3(256), 0, s, m->fb.flags, m->fb.count, m->fb.cap, patch, sub, query,
+                           radius, PL * 3, PG * 3, index0, m->fb.patch, m->fb.sub, m->fb.query, m->fb.radius, m->fb.index);
+        P2S_LAUNCH_CHECK("p2s_fb_collect_kernel");
+    }
     return P2S_OK;
 }
 
-int p2s_model_check_range(p2s_model_s *m, hipStream_t s) {
-    if (!m->range_flag) return P2S_OK;
+int p2s_model_fallback_finish(p2s_model_s *m, float *logits_out, float *sdf_out, hipStream_t s) {
+    p2s_model_s::Fallback &fb = m->fb;
+    if (!fb.count) return P2S_OK;
     int h = 0;
-    P2S_HIP_CHECK(hipMemcpyAsync(&h, m->range_flag, 4, hipMemcpyDeviceToHost, s));
+    P2S_HIP_CHECK(hipMemcpyAsync(&h, fb.count, 4, hipMemcpyDeviceToHost, s));
     P2S_HIP_CHECK(hipStreamSynchronize(s));
     if (!h) return P2S_OK;
-    P2S_HIP_CHECK(hipMemsetAsync(m->range_flag, 0, 4, s));
-    p2s_set_error("fp16 pair encoder (encoder_bf16 = 4): an activation left the half range (> 6e4); the affected queries "
-                  "came out as 1.0 -- use encoder_bf16 = 3 or 0 for this model");
-    return P2S_EINVAL;
+    P2S_HIP_CHECK(hipMemsetAsync(fb.count, 0, 4, s));
+    if (h > fb.cap || (!logits_out && !sdf_out)) {
+        p2s_set_error("fp16 pair encoder (encoder_bf16 = 4): %d queries of this call have activations beyond the half range (> 6e4)%s "
+                      "-- use encoder_bf16 = 3 or 0 for this model", h,
+                      h > fb.cap ? ", more than the fp32 fallback takes per call (16384)" : " and the call has no output the fp32 fallback could repair");
+        return P2S_EINVAL;
+    }
+    m->counters.fallback_queries += h;
+    // the same queries through the fp32 kernels (the fp32 fragments of every layer are resident in any mode)
+    const p2s_model_cfg saved = m->cfg;
+    const bool saved_heads = m->heads_f16;
+    m->cfg.encoder_bf16 = 0;
+    m->heads_f16 = false;
+    const size_t k3 = (size_t)m->cfg.points_per_patch * 3, n3 = (size_t)m->cfg.sub_sample_size * 3;
+    const int od = m->cfg.output_dim;
+    int rc = P2S_OK;
+    for (int i0 = 0; i0 < h && rc == P2S_OK; i0 += m->ws_chunk) {
+        const int C = std::min(m->ws_chunk, h - i0);
+        rc = p2s_run_chunk(m, fb.patch + i0 * k3, fb.sub + i0 * n3, fb.query + (size_t)i0 * 3, sdf_out ? fb.radius + i0 : nullptr, C,
+                           fb.logits + (size_t)i0 * od, sdf_out ? fb.sdf + i0 : nullptr, nullptr, nullptr, s, 0);
+    }
+    m->cfg = saved;
+    m->heads_f16 = saved_heads;
+    if (rc) return rc;
+    hipLaunchKernelGGL(p2s_fb_scatter_kernel, dim3((h + 255) / 256), dim3(256), 0, s, fb.index, fb.sdf, fb.logits, h, od, sdf_out, logits_out);
+    P2S_LAUNCH_CHECK("p2s_fb_scatter_kernel");
+    P2S_HIP_CHECK(hipStreamSynchronize(s));
+    return P2S_OK;
 }
 
 int p2s_prof_mark(p2s_model_s *m, hipStream_t s) {
@@ -559,16 +668,16 @@ static int run_batched(p2s_model_s *m, const float *patch, const float *sub, con
     for (int q0 = 0; q0 < B; q0 += chunk) {
         const int C = std::min(chunk, B - q0);
         rc = p2s_run_chunk(m, patch + (size_t)q0 * PL * 3, sub + (size_t)q0 * PG * 3, query + (size_t)q0 * 3,
-                           radius ? radius + q0 : nullptr, C, logits ? logits + (size_t)q0 * 2 : nullptr,
+                           radius ? radius + q0 : nullptr, C, logits ? logits + (size_t)q0 * m->cfg.output_dim : nullptr,
                            sdf ? sdf + q0 : nullptr, fl ? fl + (size_t)q0 * 1024 : nullptr,
-                           fg ? fg + (size_t)q0 * 1024 : nullptr, s);
+                           fg ? fg + (size_t)q0 * 1024 : nullptr, s, q0);
         if (rc) return rc;
     }
     p2s_prof_collect(m);
     m->counters.queries += B;
-    // fp16 pair encoder: the sticky range flag is reported (and cleared) by the call that raised it -- not by the next
-    // pipeline call on this model (this synchronises `s` in that mode only)
-    return p2s_model_check_range(m, s);
+    // fp16 pair encoder: queries with activations beyond the half range are repaired by the fp32 kernels now (this
+    // synchronises `s` in that mode only)
+    return p2s_model_fallback_finish(m, logits, sdf, s);
 }
 
 extern "C" {

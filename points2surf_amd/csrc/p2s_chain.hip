@@ -420,6 +420,9 @@ __global__ __launch_bounds__(256) void p2s_fold_kernel(FoldArgs args) {
             const int kg = 4 * jt + g;
             unsigned short *dst = outh + ((ot * 4 + (kg >> 1)) * 64 + (kg & 1) * 32 + (lane & 31)) * 8 + 4 * kk;
             float x[4] = {acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            if (args.f16 && args.bad_items &&
+                !(fabsf(x[0]) <= 6.0e4f && fabsf(x[1]) <= 6.0e4f && fabsf(x[2]) <= 6.0e4f && fabsf(x[3]) <= 6.0e4f))
+                args.bad_items[item] = 1;          // this item's folded weights leave the half range: its query re-runs in fp32
             for (int q = 0; q < args.ns; ++q) {
                 unsigned short h[4];
 #pragma unroll
@@ -456,12 +459,10 @@ int p2s_launch_chain(const ChainArgs &args_in, hipStream_t stream) {
     const int n = args_in.br[0].n_items + args_in.br[1].n_items;
     if (n <= 0) return P2S_OK;
     ChainArgs args = args_in;
-    int padlds = 0;
+    constexpr int padlds = 0;
 #ifdef P2S_DEV_ABLATE
     static const int ablate = getenv("P2S_CHAIN_ABLATE") ? atoi(getenv("P2S_CHAIN_ABLATE")) : 0;
-    static const int pad_env = getenv("P2S_CHAIN_PADLDS") ? atoi(getenv("P2S_CHAIN_PADLDS")) : 0;   // occupancy knob
     args.ablate = ablate;
-    padlds = pad_env;
 #endif
     // both branches of a launch pool alike (pass 2 of a sym_op='sum' model: sum; every other launch: max)
     if (args.br[0].pool_sum || (args.br[1].n_items > 0 && args.br[1].pool_sum))

@@ -24,9 +24,10 @@
 // that it never goes subnormal), and a product = h0 h0' into one fp32 accumulator, (h0 h1' + h1 h0') into a second one
 // that enters with the factor 2^-11 at the end -- THREE v_mfma_f32_32x32x16_f16 per product instead of the six bf16
 // ones of the three-piece mode, for the same deviation from fp32 (relative feature error 5e-7 vs 4e-7 in the CPU model;
-// two bf16 pieces: 1.3e-5).  fp16 ends at 65504: an activation beyond 6e4 poisons its item (NaN -> SDF 1.0, like a
-// non-finite input) AND raises the model's sticky range flag, which p2s_infer_shape / p2s_infer_queries report as an
-// error (the reference's activations stay below 20 with the weights at hand).
+// two bf16 pieces: 1.3e-5).  fp16 ends at 65504: an activation beyond 6e4 poisons its item (NaN) AND flags the item's
+// query (ChainArgs.bad_items); flagged queries are collected per chunk and re-run through the fp32 kernels at the end of
+// the same call (p2s_api.hip: fallback) -- an arbitrary checkpoint cannot turn this mode into wrong values or an error
+// (the reference's activations stay below 20 with the weights at hand: nothing is ever flagged there).
 #include "p2s_common.h"
 #include <cmath>
 
@@ -139,7 +140,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[F16 ? 2 : 1], uns
             v[t] = acc[0][4 * g + t];
             if (F16) v[t] = fmaf(acc[F16 ? 1 : 0][4 * g + t], F16_SCALE, v[t]);
             v[t] = fmaxf(v[t] + b[t], 0.0f);
-            if (F16) range_bad = range_bad || v[t] > F16_LIMIT;
+            if (F16) range_bad = range_bad || !(v[t] <= F16_LIMIT);       // (NaN too: an operand beyond the range made inf * 0)
         }
         unsigned lo[NS], hi[NS];
         split_pair<NS, F16>(v[0], v[1], lo);
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? (S
                     v = fmaf(w0a[128 + o], x2, v);
                     sv[u] = fmaxf(v, 0.0f);
                 }
-                if (F16) range_bad = range_bad || sv[0] > F16_LIMIT || sv[1] > F16_LIMIT;
+                if (F16) range_bad = range_bad || !(sv[0] <= F16_LIMIT) || !(sv[1] <= F16_LIMIT);
                 unsigned u[NS];
                 split_pair<NS, F16>(sv[0], sv[1], u);
 #pragma unroll
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? (S
     if (F16) {
         if (__ballot(range_bad) != 0ull) {
             bad = true;                                   // poison this wave's columns of the item ...
-            if (lane == 0 && args.range_flag) atomicOr(args.range_flag, 1);      // ... and tell the host
+            if (lane == 0 && args.bad_items) args.bad_items[item] = 1;           // ... and queue the query for the fp32 kernels
         }
     }
     if (lane < 32) {
@@ -445,7 +446,8 @@ __global__ __launch_bounds__(256, F16 ? P2S_F16_WG : ((MT == 64 && NS == 1) ? (S
 // fp32 packed B fragments ([N/32][K/8][2][32][4]: k = 8 kg + 4 kk + t, n = 32 nt + j) -> bf16 fragments
 // ([N/32][K/16][64 lanes][8]: k = 16 kb + 8 (lane >> 5) + t, n = 32 nt + (lane & 31)); one thread per output element
 __global__ void p2s_pack_bf16_kernel(const float *__restrict__ src, unsigned short *__restrict__ dst, int K, int N,
-                                     long long src_stride, long long dst_stride, int n_items, int piece, int f16) {
+                                     long long src_stride, long long dst_stride, int n_items, int piece, int f16,
+                                     int *__restrict__ range_flag) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per = (long long)K * N;
     if (e >= per * n_items) return;
@@ -462,6 +464,7 @@ __global__ void p2s_pack_bf16_kernel(const float *__restrict__ src, unsigned sho
     const long long si = ((((long long)nt * (K / 8) + kg) * 2 + kk) * 32 + j) * 4 + ts;
     float x = src[(long long)item * src_stride + si];
     if (f16) {                                        // fp16 pair: h0 = fp16(x); h1 = fp16((x - h0) * 2^11)
+        if (range_flag && !(fabsf(x) <= F16_LIMIT)) atomicOr(range_flag, 1);      // a WEIGHT beyond the half range (or non-finite)
         _Float16 h0 = (_Float16)x;
         if (piece == 1) h0 = (_Float16)((x - (float)h0) * 2048.0f);
         dst[(long long)item * dst_stride + (e % per)] = __builtin_bit_cast(unsigned short, h0);
@@ -516,11 +519,11 @@ int p2s_launch_chain_bf16(const ChainArgs &args, hipStream_t stream) {
 }
 
 int p2s_launch_pack_bf16(const float *src, unsigned short *dst, int K, int N, long long src_stride, long long dst_stride,
-                         int n_items, int piece, int f16, hipStream_t stream) {
+                         int n_items, int piece, int f16, hipStream_t stream, int *range_flag) {
     const long long total = (long long)K * N * n_items;
     if (total <= 0) return P2S_OK;
     hipLaunchKernelGGL(p2s_pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, K, N,
-                       src_stride, dst_stride, n_items, piece, f16);
+                       src_stride, dst_stride, n_items, piece, f16, range_flag);
     P2S_LAUNCH_CHECK("p2s_pack_bf16_kernel");
     return P2S_OK;
 }

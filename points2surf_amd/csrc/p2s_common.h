@@ -74,14 +74,16 @@ struct ChainArgs {
     int ns;
     long long piece_stride, w1_piece_stride;
     int f16;                 // 1: the pieces are an fp16 pair (h0, h1 * 2^11) with two accumulators (ns = 2)
-    int *range_flag;         // fp16 pair mode: device flag raised when an activation leaves the half range
+    int *bad_items;          // fp16 pair mode: [items per branch] flag of every item (= query of the chunk) an activation of
+                             // which left the half range -- the query is re-run through the fp32 kernels (p2s_api.hip: fallback)
 };
 int p2s_launch_chain(const ChainArgs &args, hipStream_t stream);
 // bf16 variant (p2s_chain_bf16.hip): w0b / w1 / w2 / w3 point to bf16 fragment arrays, w1_item_stride counts halfs
 int p2s_launch_chain_bf16(const ChainArgs &args, hipStream_t stream);
 // fp32 packed B fragments -> bf16 fragments, n_items matrices of K x N
+// range_flag (fp16 pair, may be null): raised when a weight does not fit the half range
 int p2s_launch_pack_bf16(const float *src, unsigned short *dst, int K, int N, long long src_stride, long long dst_stride,
-                         int n_items, int piece, int f16, hipStream_t stream);
+                         int n_items, int piece, int f16, hipStream_t stream, int *range_flag = nullptr);
 
 // W1' = (BN-folded conv1) . trans2, written in packed B-fragment order.  grid.y = encoder
 struct FoldArgs {
@@ -95,6 +97,7 @@ struct FoldArgs {
     unsigned short *outh[2];
     long long h_piece_stride;
     int ns, f16;
+    int *bad_items;          // fp16 pair: [n_items] flag of every item whose W1' does not fit the half range (-> fp32 fallback)
 };
 int p2s_launch_fold(const FoldArgs &args, hipStream_t stream);
 
@@ -109,10 +112,10 @@ struct GemmArgs {
     int a2_add;                   // 1: the activation is A + A2 (two partial SUM-pools, sym_op='sum') instead of max(A, A2)
     // fp16 pair variant (p2s_gemm_f16_kernel; the encoder-side head layers of cfg.encoder_bf16 = 4): Wh[z] != NULL = the
     // weights as 16-bit B fragments [N/32][K/16][64 lanes][8], piece 1 wh_piece halfs behind piece 0; the activation is
-    // split into its fp16 pair when it is staged.  range_flag: raised when an activation leaves the half range
+    // split into its fp16 pair when it is staged.  bad_rows [M]: flag of every row with an activation beyond the half range
     const unsigned short *Wh[2];
     long long wh_piece;
-    int *range_flag;
+    int *bad_rows;
     const float *W[2];
     const float *bias[2];
     float *C; long long ldc; long long c_z;

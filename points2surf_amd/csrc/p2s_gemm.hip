@@ -149,7 +149,6 @@ __global__ __launch_bounds__(256) void p2s_gemm_f16_kernel(GemmArgs g) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
-    bool range_bad = false;
     const int aoff = (lane & 31) * HS + 8 * (lane >> 5);
 
     // A[m0:m0+GM][kc:kc+128]: global -> registers (the next chunk's loads are in flight during the MFMAs) -> LDS as its fp16 pair
@@ -174,8 +173,9 @@ __global__ __launch_bounds__(256) void p2s_gemm_f16_kernel(GemmArgs g) {
         for (int i = 0; i < GM / 8; ++i) {
             const int r = (tid >> 5) + 8 * i;
             const f32x4 v = stage[i];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) range_bad = range_bad || fabsf(v[t]) > 6.0e4f;
+            // a row with an activation beyond the half range: its query goes through the fp32 kernels again (fallback)
+            if (g.bad_rows && !(fabsf(v[0]) <= 6.0e4f && fabsf(v[1]) <= 6.0e4f && fabsf(v[2]) <= 6.0e4f && fabsf(v[3]) <= 6.0e4f))
+                g.bad_rows[min(m0 + r, g.M - 1)] = 1;
             uint2 h0, h1;
             h0.x = pack_h2(v[0], v[1]);
             h0.y = pack_h2(v[2], v[3]);
@@ -213,7 +213,6 @@ __global__ __launch_bounds__(256) void p2s_gemm_f16_kernel(GemmArgs g) {
             b1 = n1;
         }
     }
-    if (g.range_flag && __ballot(range_bad) != 0ull && lane == 0) atomicOr(g.range_flag, 1);
     const int col = nt * 32 + (lane & 31);
     const float bv = bias[col];
 #pragma unroll

@@ -35,7 +35,19 @@ struct p2s_model_s {
     // fp16 pair mode: the STN / QSTN head layers as 16-bit fragments too (p2s_gemm_f16_kernel); the decoder stays fp32
     size_t h_sf1[2] = {}, h_sf2[2] = {}, h_sf3[2] = {}, h_qf1 = 0, h_qf2 = 0;
     bool heads_f16 = false;
-    int *range_flag = nullptr;             // device: raised by the fp16 pair mode when an activation leaves the half range
+    // fp16 pair mode: queries with an activation beyond the half range are flagged by the 16-bit kernels, collected per
+    // chunk (inputs copied aside) and re-run through the fp32 kernels at the end of the same call (p2s_model_fallback_finish)
+    struct Fallback {
+        int *flags = nullptr;              // [max_chunk] per query of the chunk in flight
+        int *count = nullptr;              // queries collected since the last finish (may run past cap: overflow)
+        float *patch = nullptr, *sub = nullptr, *query = nullptr, *radius = nullptr;   // [cap] inputs of the collected queries
+        long long *index = nullptr;        // [cap] position in the call's output arrays
+        float *sdf = nullptr, *logits = nullptr;                                       // [cap] results of the fp32 run
+        int cap = 0;
+    } fb;
+    // one-shot capture of the decoder logits of the next pipeline call (p2s_model_capture_logits; the drop-in's tie report)
+    float *logits_capture = nullptr;
+    int64_t logits_capacity = 0;
     float *ws = nullptr;      // per-chunk workspace, grown on demand
     int ws_chunk = 0;
     int max_chunk = 8192;     // queries per internal batch (r03: 4096 -> 8192: 180.4 -> 182.0 k queries/s, the launch boundaries
@@ -59,8 +71,11 @@ void p2s_pipe_free(p2s_model_s *m);
 // cfg.encoder_bf16: 0 fp32, 1 bf16, 2 / 3 split bf16, 4 fp16 pair (2 pieces, two accumulators)
 inline int p2s_enc_pieces(const p2s_model_cfg &c) { return c.encoder_bf16 == 4 ? 2 : c.encoder_bf16; }
 inline int p2s_enc_f16(const p2s_model_cfg &c) { return c.encoder_bf16 == 4 ? 1 : 0; }
-// sticky range flag of the fp16 pair mode: P2S_EINVAL (and cleared) if it was raised; synchronises `s`
-int p2s_model_check_range(p2s_model_s *m, hipStream_t s);
+// fp16 pair mode, at the end of every call: the queries the 16-bit kernels flagged (an activation beyond the half range) run
+// through the fp32 kernels and their results replace the poisoned ones in logits_out [.][output_dim] / sdf_out (either
+// may be null).  Synchronises `s` in that mode.  More flagged queries than the side buffers hold (16384 per call), or a
+// call without either output (p2s_encode_features): P2S_EINVAL.
+int p2s_model_fallback_finish(p2s_model_s *m, float *logits_out, float *sdf_out, hipStream_t s);
 
 enum P2SStage { ST_CHAIN_STN = 0, ST_HEAD, ST_CHAIN_MAIN, ST_DECODER, ST_KNN, ST_SUB, ST_GRID, ST_CHAIN_QSTN };
 int p2s_prof_mark(p2s_model_s *m, hipStream_t s);                 // event index or -1
@@ -69,9 +84,10 @@ void p2s_prof_reset(p2s_model_s *m);
 void p2s_prof_collect(p2s_model_s *m);                            // synchronises the last event
 
 int p2s_model_reserve(p2s_model_s *m, int chunk);
+// index0: position of the chunk's first query in the CALL's output arrays (what the fp32 fallback scatters to)
 int p2s_run_chunk(p2s_model_s *m, const float *patch, const float *sub, const float *query, const float *radius,
                   int C, float *logits_out, float *sdf_out, float *feat_local_out, float *feat_global_out,
-                  hipStream_t s);
+                  hipStream_t s, long long index0 = 0);
 
 // ---------------------------------------------------------------------------------------------
 // cloud / rng handles (p2s_cloud.hip, p2s_rng.hip)

@@ -195,6 +195,13 @@ extern "C" int p2s_rotate_points(const double *rot_dev, const float *pts_in_dev,
     return P2S_OK;
 }
 
+extern "C" int p2s_model_capture_logits(p2s_model_t m, float *logits_out_dev, int64_t capacity_queries) {
+    if (!m || capacity_queries < 0 || (capacity_queries > 0 && !logits_out_dev)) return P2S_EINVAL;
+    m->logits_capture = capacity_queries > 0 ? logits_out_dev : nullptr;
+    m->logits_capacity = capacity_queries;
+    return P2S_OK;
+}
+
 extern "C" int p2s_debug_fault_chunk(p2s_model_t m, int chunk_index) {
     if (!m) return P2S_EINVAL;
     m->fault_chunk = chunk_index;
@@ -203,8 +210,21 @@ extern "C" int p2s_debug_fault_chunk(p2s_model_t m, int chunk_index) {
 
 // queries q_all[q_begin, q_end) through the double-buffered pipeline.  r_rot != NULL: GT-query pass (rotation).
 // r_patch: fixed-radius models only (the generator of the patch choice; in the GT-query pass the same handle as r_rot).
+// one-shot logits capture (p2s_model_capture_logits): taken off the model at the top of the call that consumes it, whatever
+// the call's outcome
+struct LogitsCapture {
+    float *dev;
+    int64_t room;
+    explicit LogitsCapture(p2s_model_s *m) : dev(m ? m->logits_capture : nullptr), room(m ? m->logits_capacity : 0) {
+        if (m) {
+            m->logits_capture = nullptr;
+            m->logits_capacity = 0;
+        }
+    }
+};
+
 static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s *r_rot, p2s_rng_s *r_patch, const float *q_all,
-                        int64_t q_begin, int64_t q_end, int chunk, float *sdf_out_dev, hipStream_t s) {
+                        int64_t q_begin, int64_t q_end, int chunk, float *sdf_out_dev, hipStream_t s, const LogitsCapture &cap) {
     const bool weighted = m->cfg.weighted_subsample != 0;   // p2s_vanilla: choice(p, replace=False) per query
     const double ball_r = m->cfg.patch_radius;
     const bool ball = ball_r > 0.0;                         // patch = points within a fixed radius (p2s_ball.hip)
@@ -240,6 +260,12 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
     // synchronise, a stream of a model that may be destroyed before it
     p2s_cloud_note_stream(c, s);
     const int64_t nq = q_end - q_begin;
+    float *const logits_cap = cap.dev;
+    const int64_t logits_room = cap.room;
+    if (logits_cap && logits_room < nq) {
+        p2s_set_error("p2s pipeline: logits capture buffer holds %lld queries, the call processes %lld", (long long)logits_room, (long long)nq);
+        return P2S_ECAPACITY;
+    }
     if (nq <= 0) return P2S_OK;
     struct QuietGuard {
         p2s_cloud_s *c;
@@ -390,8 +416,9 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
             if ((rc = p2s_rotate_points(b.rot[bi], qc, 1, cur, b.qrot[bi], s))) return fail(rc);
             qc = b.qrot[bi];
         }
-        rc = p2s_run_chunk(m, b.patch[bi], b.sub[bi], qc, b.radius[bi], cur, nullptr, sdf_out_dev + (q0 - q_begin),
-                           nullptr, nullptr, s);
+        rc = p2s_run_chunk(m, b.patch[bi], b.sub[bi], qc, b.radius[bi], cur,
+                           logits_cap ? logits_cap + (size_t)(q0 - q_begin) * m->cfg.output_dim : nullptr,
+                           sdf_out_dev + (q0 - q_begin), nullptr, nullptr, s, q0 - q_begin);
         if (rc) return fail(rc);
         if (use_done) PIPE_HIP(hipEventRecord(b.done[bi], s));
         if (ci + nbuf < nchunks) {
@@ -400,7 +427,9 @@ static int run_pipeline(p2s_model_s *m, p2s_cloud_s *c, p2s_rng_s *r, p2s_rng_s 
     }
 #undef PIPE_HIP
     m->counters.queries += nq;
-    return fail(P2S_OK);
+    if ((rc = fail(P2S_OK))) return rc;
+    // fp16 pair encoder: the queries it flagged (activations beyond the half range) through the fp32 kernels, now
+    return p2s_model_fallback_finish(m, logits_cap, sdf_out_dev, s);
 }
 
 extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int res, int eps, int64_t q_begin,
@@ -417,6 +446,7 @@ extern "C" int p2s_infer_shape(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, int re
 extern "C" int p2s_infer_shape_ball(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, p2s_rng_t r_patch, int res, int eps,
                                     int64_t q_begin, int64_t q_end, int chunk, float *sdf_out_dev, float *q_out_dev,
                                     int64_t *n_done, void *stream) {
+    const LogitsCapture cap(m);
     if (!m || !c || !r || !sdf_out_dev || r_patch == r) {
         p2s_set_error("p2s_infer_shape: null argument (or one generator handle passed twice)");
         return P2S_EINVAL;
@@ -440,7 +470,7 @@ extern "C" int p2s_infer_shape_ball(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, p
     if (n_done) *n_done = 0;
     const int64_t nq = q_end - q_begin;
     if (nq == 0) return P2S_OK;
-    rc = run_pipeline(m, c, r, nullptr, r_patch, q_all, q_begin, q_end, chunk, sdf_out_dev, s);
+    rc = run_pipeline(m, c, r, nullptr, r_patch, q_all, q_begin, q_end, chunk, sdf_out_dev, s, cap);
     if (rc) return rc;
     if (q_out_dev) {
         P2S_HIP_CHECK(hipMemcpyAsync(q_out_dev, q_all + (size_t)q_begin * 3, (size_t)nq * 12, hipMemcpyDeviceToDevice, s));
@@ -450,13 +480,13 @@ extern "C" int p2s_infer_shape_ball(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r, p
     rc = p2s_rng_check(r, s);
     if (rc) return rc;
     if (r_patch && (rc = p2s_rng_check(r_patch, s))) return rc;
-    if ((rc = p2s_model_check_range(m, s))) return rc;
     if (n_done) *n_done = nq;
     return P2S_OK;
 }
 
 extern "C" int p2s_infer_queries(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r_sub, p2s_rng_t r_rot, const float *q_dev,
                                  int64_t n_queries, int chunk, float *sdf_out_dev, void *stream) {
+    const LogitsCapture cap(m);
     if (!m || !c || !r_sub || (n_queries > 0 && (!q_dev || !sdf_out_dev)) || n_queries < 0 || r_rot == r_sub) {
         p2s_set_error("p2s_infer_queries: bad argument (the rotation generator must be a second handle)");
         return P2S_EINVAL;
@@ -465,10 +495,9 @@ extern "C" int p2s_infer_queries(p2s_model_t m, p2s_cloud_t c, p2s_rng_t r_sub, 
     hipStream_t s = (hipStream_t)stream;
     p2s_prof_reset(m);
     if (n_queries == 0) return P2S_OK;
-    int rc = run_pipeline(m, c, r_sub, r_rot, m->cfg.patch_radius > 0.0 ? r_rot : nullptr, q_dev, 0, n_queries, chunk, sdf_out_dev, s);
+    int rc = run_pipeline(m, c, r_sub, r_rot, m->cfg.patch_radius > 0.0 ? r_rot : nullptr, q_dev, 0, n_queries, chunk, sdf_out_dev, s, cap);
     if (rc) return rc;
     p2s_prof_collect(m);
-    if ((rc = p2s_model_check_range(m, s))) return rc;
     if ((rc = p2s_rng_check(r_sub, s))) return rc;
     if (r_rot && (rc = p2s_rng_check(r_rot, s))) return rc;
     return P2S_OK;

@@ -28,6 +28,11 @@ import sys
 
 
 RANK_AWARE_SCRIPTS = ('full_eval.py',)      # every stage shards over the ranks or runs on rank 0 only
+# the reference's other top-level scripts: training, data-set generation, conversion -- every rank would do ALL the work and
+# write the same files.  Refused under torchrun with more than one rank (a user's own script that calls the drop-in's
+# rank-aware functions is the user's business and runs)
+SINGLE_PROCESS_SCRIPTS = ('full_run.py', 'full_train.py', 'make_dataset.py', 'make_pc_dataset.py', 'eval_dataset.py',
+                          'dataset_for_deepsdf.py', 'blensor_script_template.py')
 
 
 def ranks_to_spawn(environ=None, device_count=None, script=None):
@@ -68,11 +73,11 @@ def main(argv=None):
     script = os.path.abspath(argv[0])
     if not os.path.isfile(script):
         raise SystemExit('points2surf_amd.dropin.run: no such script: %s' % argv[0])
-    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and os.path.basename(script) not in RANK_AWARE_SCRIPTS:
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and os.path.basename(script) in SINGLE_PROCESS_SCRIPTS:
         # torchrun --nproc-per-node N -m points2surf_amd.dropin.run full_run.py: N trainings writing the same model files
-        raise SystemExit('points2surf_amd.dropin.run: WORLD_SIZE=%s, but %s is not rank-aware (only %s are): its stages '
-                         'would run once per rank and overwrite each other\'s files -- start it as ONE process'
-                         % (os.environ['WORLD_SIZE'], os.path.basename(script), ', '.join(RANK_AWARE_SCRIPTS)))
+        raise SystemExit('points2surf_amd.dropin.run: WORLD_SIZE=%s, but %s is not rank-aware (of the reference\'s scripts only '
+                         '%s are): its stages would run once per rank and overwrite each other\'s files -- start it as ONE '
+                         'process' % (os.environ['WORLD_SIZE'], os.path.basename(script), ', '.join(RANK_AWARE_SCRIPTS)))
     n = ranks_to_spawn(script=script)
     if n:
         import socket

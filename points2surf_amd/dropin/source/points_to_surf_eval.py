@@ -142,11 +142,28 @@ def _load_points(indir, shape_name):
     return np.ascontiguousarray(pts)
 
 
-def _infer_one_shape(model, cloud, rng_dev, res, eps, chunk, rng_patch=None):
+def _infer_one_shape(model, cloud, rng_dev, res, eps, chunk, rng_patch=None, want_logits=False):
     """the reference's batch loop for one shape (:358-404).  Both sub-sample modes run on the device:
     randint (p2s_max) and the distance-weighted choice without replacement (p2s_vanilla); fixed-radius models draw
     their patch choice from ``rng_patch``, the data set's first generator."""
-    return _engine.infer_shape(model, cloud, rng_dev, res, eps, chunk=chunk, rng_patch=rng_patch)
+    return _engine.infer_shape(model, cloud, rng_dev, res, eps, chunk=chunk, rng_patch=rng_patch, want_logits=want_logits)
+
+
+def _tie_report(path, shape_name, encoder_bf16, logits, sdf_np, q_np):
+    """P2S_TIE_REPORT: the queries of a shape whose sign logit lies within the noise of the reference's sign decision
+    ``logit >= 0`` (reference source/sdf_nn.py:16-21) -- the only queries whose sign can differ from a reference run, each
+    worth one voxel of the volume.  One JSON line per query, appended."""
+    import json
+    from points2surf_amd import parity
+    sign = logits[:, logits.shape[1] - 1]
+    idx = torch.nonzero(sign.abs() < parity.tie_logit(encoder_bf16)).reshape(-1).cpu().numpy()
+    vals = sign.cpu().numpy()
+    with open(path, 'a') as f:
+        for j in idx:
+            f.write(json.dumps({'shape': shape_name, 'query': int(j), 'query_point_ms': [float(x) for x in q_np[j]],
+                                'sign_logit': float(vals[j]), 'sdf': float(sdf_np[j]),
+                                'tie_logit': parity.tie_logit(encoder_bf16)}) + '\n')
+    return int(idx.size)
 
 
 def _visualize_query_points(query_pts_ms, query_dist_ms, file_out):
@@ -313,6 +330,11 @@ def points_to_surf_eval(eval_opt):
             if handoff is not None:
                 handoff.owner = list(owner)
         total_q = 0
+        # opt-in list of the queries whose sign is a tie of the reference's own decision
+        tie_file = os.environ.get('P2S_TIE_REPORT') if reconstruction else None
+        if tie_file and world > 1:
+            tie_file += '.rank%d' % rank
+        ties_listed = 0
         t0 = time.time()
         # result files are written on background threads while the next shape is on the GPU (np.savetxt alone
         # costs ~0.27 s per 300k values -- a quarter of a shape's inference time)
@@ -413,10 +435,13 @@ def points_to_surf_eval(eval_opt):
                                 c2.close()
                         handoff.publish_after(shape_ind, rngs, _advance)
                 cloud = _engine.Cloud(pts_np, device=device)
-                sdf, q = _infer_one_shape(model, cloud, rng_dev, eval_opt.query_grid_resolution, eval_opt.epsilon, chunk,
-                                          rng_patch=rng_rot)
+                res_ = _infer_one_shape(model, cloud, rng_dev, eval_opt.query_grid_resolution, eval_opt.epsilon, chunk,
+                                        rng_patch=rng_rot, want_logits=tie_file is not None)
+                sdf, q = res_[0], res_[1]
                 sdf_np = sdf.cpu().numpy()
                 q_np = q.cpu().numpy()
+                if tie_file is not None:
+                    ties_listed += _tie_report(tie_file, shape_name, cfg['encoder_bf16'], res_[2], sdf_np, q_np)
                 total_q += sdf_np.shape[0]
                 pending.append(writers.submit(_save_shape, model_out_dir, shape_name, sdf_np, q_np))
                 cloud.close()
@@ -450,7 +475,8 @@ def points_to_surf_eval(eval_opt):
                 raise RuntimeError('points_to_surf_eval: outputs missing after the run: %s' % missing[:4])
         last_run_stats.update(model=model_name, queries=int(total_q), shapes=len(mine), seconds_shapes=dt,
                               seconds_model_create=t_model, rank=rank, world=world,
-                              stream_wait_s=None if handoff is None else handoff.waited_s)
+                              stream_wait_s=None if handoff is None else handoff.waited_s,
+                              ties_listed=ties_listed if tie_file else None)
         print('evaluated %d patches of %d shapes in %.2f s (%.0f queries/s on rank %d)'
               % (total_q, len(mine), dt, total_q / max(dt, 1e-9), rank))
         model.close()

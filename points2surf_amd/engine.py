@@ -433,10 +433,11 @@ def ball_skip(cloud, rng, queries, radius, points_per_patch, with_rotation=False
 
 
 def infer_shape(model, cloud, rng, grid_resolution, epsilon, q_begin=0, q_end=-1, chunk=0, want_queries=True,
-                n_queries=None, rng_patch=None):
+                n_queries=None, rng_patch=None, want_logits=False):
     """Fused per-shape pipeline (p2s_infer_shape).  Returns (sdf [n] device tensor, q [n,3] or None).
     ``n_queries``: the size of the query grid if the caller already asked for it (Cloud.count_queries).
-    ``rng_patch``: fixed-radius models -- the data set's first generator (patch choice)."""
+    ``rng_patch``: fixed-radius models -- the data set's first generator (patch choice).
+    ``want_logits``: also return the decoder's raw logits [n, output_dim] as a third value (p2s_model_capture_logits)."""
     dev = model.device
     lib = model.lib
     with torch.cuda.device(dev):
@@ -446,10 +447,16 @@ def infer_shape(model, cloud, rng, grid_resolution, epsilon, q_begin=0, q_end=-1
         sdf = torch.empty((max(nq, 1),), dtype=torch.float32, device=dev)
         q = torch.empty((max(nq, 1), 3), dtype=torch.float32, device=dev) if want_queries else None
         done = ctypes.c_int64(0)
+        logits = None
+        if want_logits:
+            logits = torch.empty((max(nq, 1), model.output_dim), dtype=torch.float32, device=dev)
+            _lib.check(lib.p2s_model_capture_logits(model.handle, _ptr(logits), nq))
         _lib.check(lib.p2s_infer_shape_ball(model.handle, cloud.handle, rng.handle,
                                             rng_patch.handle if rng_patch is not None else None, int(grid_resolution),
                                             int(epsilon), int(q_begin), int(qe), int(chunk), _ptr(sdf), _ptr(q),
                                             ctypes.byref(done), _stream_ptr(dev)))
+    if want_logits:
+        return sdf[:nq], (q[:nq] if q is not None else None), logits[:nq]
     return sdf[:nq], (q[:nq] if q is not None else None)
 
 

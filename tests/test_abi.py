@@ -32,7 +32,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.p2s_abi_version() == 4
+    assert lib.p2s_abi_version() == 5
     assert isinstance(lib.p2s_last_error(), bytes)
     assert lib.p2s_device_count() >= 0
 

@@ -66,7 +66,7 @@ def test_launcher_uses_all_visible_devices_by_default(tmp_path, monkeypatch):
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '4711'
     assert cmd[-5:] == ['-m', 'points2surf_amd.dropin.run', '/x/full_eval.py', '--indir', 'd']
     # end to end: two ranks (P2S_GPUS=2 with a faked device count) run the SCRIPT, each with its own RANK
-    script = tmp_path / 'full_eval.py'            # (a rank-aware NAME: anything else is refused under WORLD_SIZE > 1)
+    script = tmp_path / 's.py'
     script.write_text("import os\nopen(os.path.join(%r, 'rank_' + os.environ['RANK']), 'w').write(os.environ['WORLD_SIZE'])\n" % str(tmp_path))
     monkeypatch.setattr(run, 'ranks_to_spawn', lambda environ=None, device_count=None, script=None: 0 if 'WORLD_SIZE' in os.environ else 2)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):

@@ -126,25 +126,27 @@ def test_split_bf16_against_the_reference(pieces, name, golden_dir, torch_cuda):
         assert 0.3 < float((ref > 0).mean()) < 0.7
 
 
-def test_fp16_pair_mode_reports_activations_beyond_the_half_range(fixture_cloud, torch_cuda):
-    """encoder_bf16 = 4 carries activations as fp16 pairs (max 65504): a model whose activations leave that range must
-    not pass silently -- the affected queries come out as 1.0 (like NaN inputs) AND the call fails loudly"""
+def test_fp16_pair_mode_repairs_activations_beyond_the_half_range(fixture_cloud, torch_cuda):
+    """encoder_bf16 = 4 carries activations as fp16 pairs (max 65504): a model whose activations leave that range must not
+    pass silently.  r05: the affected queries came out as 1.0 and the call failed; r06: they are re-run through the fp32
+    kernels inside the same call (tests/test_gpu_fp16_fallback.py) -- here EVERY query of the shape (first layer times 1e6,
+    not compensated: another function, but the same one in every mode) and the result equals the fp32 encoders' bit for bit"""
     import torch
-    from points2surf_amd import engine, synth, _lib
+    from points2surf_amd import engine, synth
     w, cfg = synth.make_weights('p2s_max')
     w = dict(w)
     w['feat_local.conv0a.weight'] = (w['feat_local.conv0a.weight'] * np.float32(1e6)).astype(np.float32)
-    m = engine.Model(w, dict(cfg, encoder_bf16=4))
     cloud = engine.Cloud(fixture_cloud)
-    with pytest.raises(_lib.P2SError) as e:
-        engine.infer_shape(m, cloud, engine.Rng(40938661), 16, 3)
-    assert e.value.code == -1 and 'half range' in str(e.value)
-    # the same weights are fine in fp32 and in the bf16 split (bf16 has the fp32 exponent range)
-    for mode in (0, 3):
-        m2 = engine.Model(w, dict(cfg, encoder_bf16=mode))
-        sdf, _ = engine.infer_shape(m2, cloud, engine.Rng(40938661), 16, 3)
+    out = {}
+    for mode in (4, 0, 3):   # the same weights are fine in fp32 and in the bf16 split (bf16 has the fp32 exponent range)
+        m = engine.Model(w, dict(cfg, encoder_bf16=mode))
+        sdf, _ = engine.infer_shape(m, cloud, engine.Rng(40938661), 16, 3)
         torch.cuda.synchronize()
         assert torch.isfinite(sdf).all()
+        out[mode] = (sdf.clone(), int(m.counters()['fallback_queries']))
+        m.close()
+    assert out[4][1] == out[4][0].shape[0] and out[0][1] == 0 and out[3][1] == 0
+    assert torch.equal(out[4][0], out[0][0])
 
 
 @pytest.mark.parametrize('name', ['p2s_max', 'p2s_vanilla'])

@@ -380,3 +380,51 @@ def test_random_patch_sampling_matches_the_reference(dropin_source, tmp_path, go
     with pytest.raises(ValueError):
         opt.sampling = 'random'
         ev.points_to_surf_eval(opt)
+
+
+def test_tie_report_lists_the_queries_near_the_sign_decision(dropin_source, tmp_path, fixture_cloud, monkeypatch):
+    """P2S_TIE_REPORT=<file>: the reconstruction pass appends one JSON line per query whose sign logit
+    lies within parity.tie_logit(mode) of zero -- the queries whose sign the reference itself does not reproduce.  With the
+    real threshold (1e-5) a 32^3 grid has none (about one query in 400,000); the threshold is raised here to the 2 % quantile
+    of |sign logit| so that the list is not empty, and compared with the logits of an independent engine run"""
+    import json
+    import torch
+    from points2surf_amd import engine, synth, parity
+    ev, _ = dropin_source
+    root = str(tmp_path / 'ds')
+    names = _make_dataset(root, fixture_cloud, n_shapes=2)
+    modeldir = str(tmp_path / 'models')
+    _write_model_files(modeldir, 'p2s_max')
+    w, cfg = synth.make_weights('p2s_max')
+    m = engine.Model(w, cfg)
+    cloud = engine.Cloud(fixture_cloud)
+    rng = engine.Rng(40938661)
+    want = []
+    lg_all = []
+    for n in names:
+        sdf, q, lg = engine.infer_shape(m, cloud, rng, 32, 3, want_logits=True)
+        torch.cuda.synchronize()
+        lg_all.append(lg[:, 1].cpu().numpy())
+    thr = float(np.quantile(np.abs(np.concatenate(lg_all)), 0.02))
+    for n, lg in zip(names, lg_all):
+        want += [(n, int(j)) for j in np.nonzero(np.abs(lg) < thr)[0]]
+    assert len(want) >= 20
+    monkeypatch.setattr(parity, 'TIE_LOGIT_FP32', thr)
+    report = str(tmp_path / 'ties.jsonl')
+    monkeypatch.setenv('P2S_TIE_REPORT', report)
+    opt = ev.parse_arguments(['--indir', root, '--outdir', str(tmp_path / 'results'), '--dataset', 'testset.txt', '--modeldir',
+                              modeldir, '--models', 'p2s_max', '--query_grid_resolution', '32', '--epsilon', '3'])
+    opt.reconstruction = True
+    ev.points_to_surf_eval(opt)
+    lines = [json.loads(l) for l in open(report)]
+    assert [(d['shape'], d['query']) for d in lines] == want and ev.last_run_stats['ties_listed'] == len(want)
+    sdf0 = np.load(os.path.join(str(tmp_path / 'results'), 'rec', 'dist_ms', names[0] + '.xyz.npy'))
+    q0 = np.load(os.path.join(str(tmp_path / 'results'), 'rec', 'query_pts_ms', names[0] + '.xyz.npy'))
+    d = lines[0]
+    assert d['sdf'] == float(sdf0[d['query']]) and np.allclose(d['query_point_ms'], q0[d['query']]) and abs(d['sign_logit']) < thr
+    assert (d['sign_logit'] >= 0) == (d['sdf'] > 0) and d['tie_logit'] == thr
+    # without the variable nothing is written and no logits are captured
+    monkeypatch.delenv('P2S_TIE_REPORT')
+    os.remove(report)
+    ev.points_to_surf_eval(opt)
+    assert not os.path.exists(report) and ev.last_run_stats['ties_listed'] is None

@@ -8,8 +8,6 @@ d = json.loads(sys.stdin.read())
 print(round(d["ms"], 2), "ms; chain_stn", round(d["stages_ms"]["ms_chain_stn"], 2), "chain_main", round(d["stages_ms"]["ms_chain_main"], 2))'
 }
 for ab in ${ABL:-0 1 2}; do
-  for pad in ${PADS:-0}; do
-    echo -n "ablate=$ab padlds=$pad: "
-    P2S_CHAIN_ABLATE=$ab P2S_CHAIN_PADLDS=$pad run
-  done
+  echo -n "ablate=$ab: "
+  P2S_CHAIN_ABLATE=$ab run
 done
