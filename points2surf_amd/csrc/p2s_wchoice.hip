@@ -684,7 +684,7 @@ struct WcArgs {
 //                    an earlier draw prev(e) in the same bin adds 1 to the starts in (e - nsel, prev(e)] -- a difference
 //                    array + scan; draws sharing a bin are found through an LDS hash.  255 = undecided.  It also writes
 //                    level 0 of the jump tables.
-//   wc_jumpk_kernel  levels 1.. of the jump tables (below)
+//   wc_jumpm_kernel  levels 1.. of the jump tables (below), four levels per launch
 //   wc_chain_kernel  one workgroup: the walk s -> s + 2 (nsel + R_q(s)) through the tables; the (now very rare) undecided
 //                    candidate runs the complete algorithm in place (wc_full_query); a start outside the window ends the
 //                    block early, the next (spec, chain) pair resumes there; the LAST launch of a request takes whatever
@@ -727,25 +727,46 @@ struct WcSpec {
     unsigned char *scratch;   // wc_lds_bytes(n) bytes: the arrays of the complete algorithm for the chain kernel
 };
 
-// level k from level k - 1, rows i = 0 mod 2^k
-__global__ __launch_bounds__(256) void wc_jumpk_kernel(WcArgs a, WcSpec sp, int k) {
+// levels k0 + 1 .. min(k0 + JM_LEV, kmax) from level k0 in ONE launch (r05: one launch per level -- ten dependent launches
+// between the spec / band kernel and the walk, each waiting ~50 us for a free workgroup slot next to the encoders).  A
+// workgroup takes JM_ROWS consecutive rows of level k0 into LDS (32 KB: fits the slot one retiring encoder workgroup frees)
+// and composes upwards in place: level k0 + t lives in the rows j * 2^t of the tile,
+//     J_k[i] = J_(k-1)[i + 2^(k-1)] o J_(k-1)[i]          (rows i = 0 mod 2^k; invalid unless i + 2^k lands on a query of the block)
+// -- the element (row, d) is read only by the lane that overwrites it, the other operand row (j * 2^t + 2^(t-1)) is never
+// written at that level, so one barrier per level is all the ordering there is.
+constexpr int JM_LEV = 4;
+constexpr int JM_ROWS = 1 << JM_LEV;
+__global__ __launch_bounds__(256) void wc_jumpm_kernel(WcArgs a, WcSpec sp, int k0, int kmax) {
+    __shared__ __attribute__((aligned(16))) unsigned short jm[JM_ROWS * SP_W];
     if (a.meta[1] != 0) return;
     const long long qb = sp.ctl[0];
     if (qb >= a.nq) return;
     const int lim = (int)(a.nq - qb < SP_B ? a.nq - qb : SP_B);
-    const int i = (int)blockIdx.x << k, half = 1 << (k - 1);
-    if (i >= lim) return;
-    const unsigned short *Ja = sp.jump + sp_lev_row(k - 1, i) * SP_W;
-    const unsigned short *Jb = sp.jump + sp_lev_row(k - 1, i + half) * SP_W;
-    unsigned short *Jk = sp.jump + sp_lev_row(k, i) * SP_W;
-    const bool reach = i + 2 * half <= lim - 1;          // lands on a query of the block
-    for (int d = threadIdx.x; d < SP_W; d += 256) {
-        unsigned short v = SP_INV;
-        if (reach) {
-            const unsigned short m = Ja[d];
-            if (m != SP_INV) v = Jb[m];
+    const int i0 = ((int)blockIdx.x * JM_ROWS) << k0;            // first query of this tile
+    if (i0 >= lim) return;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < JM_ROWS * SP_W / 8; c += 256) {        // 16 bytes per lane and step
+        const int r = c / (SP_W / 8), i = i0 + (r << k0);
+        uint4 v = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);      // SP_INV: no such row
+        if (i < lim) v = *(const uint4 *)(sp.jump + sp_lev_row(k0, i) * SP_W + 8 * (c % (SP_W / 8)));
+        *(uint4 *)(jm + 8 * c) = v;
+    }
+    __syncthreads();
+    for (int t = 1; t <= JM_LEV && k0 + t <= kmax; ++t) {
+        const int k = k0 + t, nrow = JM_ROWS >> t, hs = 1 << (t - 1);
+        for (int e = tid; e < nrow * SP_W; e += 256) {
+            const int slot = (e / SP_W) << t, d = e % SP_W;
+            const int i = i0 + (slot << k0);
+            if (i >= lim) continue;
+            unsigned short v = SP_INV;
+            if (i + (1 << k) <= lim - 1) {                       // lands on a query of the block
+                const unsigned short m = jm[slot * SP_W + d];
+                if (m != SP_INV) v = jm[(slot + hs) * SP_W + m];
+            }
+            jm[slot * SP_W + d] = v;
+            sp.jump[sp_lev_row(k, i) * SP_W + d] = v;
         }
-        Jk[d] = v;
+        __syncthreads();
     }
 }
 
@@ -1856,9 +1877,13 @@ static int wc_subsample(p2s_rng_s *r, p2s_cloud_s *c, const float *q_dev, int64_
             hipLaunchKernelGGL(wc_ctl_init_kernel, dim3(1), dim3(1), 0, s, sp.ctl, meta);
             const int blk = std::min(cur, SP_B);
             const int rounds = (cur + SP_B - 1) / SP_B + (cur > SP_B / 2 ? 1 : 0);
-            auto jumps = [&]() {
-                for (int k = 1; k < SP_LEV && (1 << k) < blk; ++k)
-                    hipLaunchKernelGGL(wc_jumpk_kernel, dim3((blk + (1 << k) - 1) >> k), dim3(256), 0, s, a, sp, k);
+            int kmax = 0;
+            for (int k = 1; k < SP_LEV && (1 << k) < blk; ++k) kmax = k;
+            auto jumps = [&]() {        // levels 1 .. kmax of the jump tables, JM_LEV per launch: 3 launches for a full block
+                for (int k0 = 0; k0 < kmax; k0 += JM_LEV) {
+                    const int rows = (blk + (1 << k0) - 1) >> k0;
+                    hipLaunchKernelGGL(wc_jumpm_kernel, dim3((rows + JM_ROWS - 1) / JM_ROWS), dim3(256), 0, s, a, sp, k0, kmax);
+                }
             };
             for (int pr = 0; pr < rounds; ++pr) {
                 hipLaunchKernelGGL(wc_spec_kernel, dim3(blk), dim3(256), 0, s, a, sp);

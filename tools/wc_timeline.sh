@@ -5,7 +5,7 @@ OUT=$ROOT/gpurun_out/wctl
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$ROOT
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o wc -- python $ROOT/tools/vanilla_fixture.py > $OUT/stdout.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o wc -- python $ROOT/tools/vanilla_fixture.py ${WC_ARGS:-} > $OUT/stdout.log 2>&1
 python - <<PY > $OUT/timeline.txt
 import csv, glob
 f = glob.glob('$OUT/**/*kernel_trace.csv', recursive=True)[0]
@@ -17,7 +17,7 @@ t0 = int(rows[i0]['Start_Timestamp'])
 for r in rows[i0:i1 + 1]:
     nm = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0][:24]
     s, e = int(r['Start_Timestamp']) - t0, int(r['End_Timestamp']) - t0
-    if (e - s) < 20000 and ('jumpk' in nm or 'gemm' in nm):
+    if (e - s) < 20000 and 'gemm' in nm:
         continue
     print('%-24s q%-3s start %8.3f  end %8.3f  dur %7.3f ms' % (nm, r.get('Queue_Id', '?')[-3:], s / 1e6, e / 1e6, (e - s) / 1e6))
 PY
