@@ -300,3 +300,41 @@ def test_stream_handoff_failure_before_the_first_shape(tmp_path):
     assert out[1][1].startswith('raised OSError: cloud file truncated')
     assert 'rank 1 failed before its first shape' in out[0][1] and 'cloud file truncated' in out[0][1], out[0]
     assert out[0][0] < 30.0
+
+
+def _range_split_worker(rank, world, port, outdir):
+    """three ranks skip ONE shape -- each walks every candidate start of a window around the predicted
+    start of its query range (tests/wchoice_model.py: range_map), publishes the map through the rendezvous store, rank 0
+    composes the maps"""
+    import pickle
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    sharding.init_process_group('gloo')
+    from torch.distributed.distributed_c10d import _get_default_store
+    from tests import wchoice_model as wm
+    from tests import test_wchoice_algorithm as T
+    nsel, W = 40, 64
+    pts, qs, tbs, st, xs = T._split_fixture(nsel=nsel)          # every rank has the cloud, the queries and the stream
+    nq = len(tbs)
+    a, b = sharding.query_range(nq, world, rank)
+    pred = T._predicted_start(tbs, a, nsel)
+    starts = range(max(0, pred - W // 2), pred + W // 2) if rank else [0]
+    mp_, evals, _ = wm.range_map(tbs[a:b], xs, starts, nsel)
+    store = _get_default_store()
+    store.set('p2s/split/%d' % rank, pickle.dumps(mp_))
+    if rank == 0:
+        s = 0
+        for r in range(world):
+            s = pickle.loads(store.get('p2s/split/%d' % r))[s]           # KeyError = the window missed the true start
+        path = T._single_stream(pts, qs, tbs, st, xs, nsel)              # numpy-checked single stream
+        with open(os.path.join(outdir, 'split.txt'), 'w') as f:
+            f.write('%d %d\n' % (s, path[-1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_range_split_skip_world3_equals_the_single_stream(tmp_path):
+    port = _free_port()
+    mp.spawn(_range_split_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    got, want = open(os.path.join(str(tmp_path), 'split.txt')).read().split()
+    assert got == want and int(got) > 3 * 30 * 40

@@ -303,3 +303,44 @@ def spec_redraws_exact(tb, xs, nsel, W, look=64):
             if all(abs(x3[j] - x3[j2]) > wmax for j in range(m3) for j2 in range(j)):
                 out[d] = m2 + m3
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Range-split stream skip ("what would lift the 16-bit figure at 8 GPUs"): N ranks skip ONE shape.
+#
+# The only serial quantity of the weighted sub-sample is where every query's draws start: s_(q+1) = s_q + nsel + R_q(s_q),
+# R_q(s) = redraws of ``choice`` for query q when its first double is the s-th of the stream -- a function of q and s alone.
+# A rank that owns the queries [a, b) of a shape does not know s_a (it depends on every redraw before a), but it can walk
+# EVERY candidate start of a window around the predicted one: walks from neighbouring starts meet within tens of queries
+# (a start shifted by one double loses one first-round draw and gains one; the redraw count absorbs the difference with a
+# few per cent probability per query) and a walk that has met another one costs nothing more.  The rank publishes the map
+# {candidate start at a -> start at b}; the true path is the composition of the N maps, bit for bit the single stream.
+# ---------------------------------------------------------------------------------------------------------------------
+def redraws_at(tb, xs, s, nsel):
+    """R_q(s) by the complete algorithm: doubles consumed beyond the first nsel when the query's first double is xs[s]"""
+    pos = [s]
+
+    def rand(m):
+        a = xs[pos[0]:pos[0] + m]
+        assert a.size == m, 'stream exhausted'
+        pos[0] += m
+        return a
+    choice_noreplace(tb, rand, nsel)
+    return pos[0] - s - nsel
+
+
+def range_map(tbs, xs, starts, nsel):
+    """walk every candidate start through the queries of a range.  tbs: the Tables of the range's queries in order;
+    starts: candidate stream positions (doubles) of the range's first query.  Returns ({start: end}, evaluations of R,
+    number of queries after which all walks had merged into one (None: never))."""
+    cur = {int(s): int(s) for s in starts}           # start -> where its walk stands
+    evals, merged_at = 0, None
+    for j, tb in enumerate(tbs):
+        step = {}
+        for p in set(cur.values()):                  # walks that met share every later step
+            step[p] = p + nsel + redraws_at(tb, xs, p, nsel)
+            evals += 1
+        cur = {s: step[p] for s, p in cur.items()}
+        if merged_at is None and len(set(cur.values())) == 1:
+            merged_at = j + 1
+    return cur, evals, merged_at
