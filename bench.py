@@ -673,7 +673,7 @@ def main():
         # committed under profiles/; they cannot be collected from inside this process
         traffic, traffic_src = None, None
         if not bf16 and mname == 'p2s_max':
-            for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
+            for rnd in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
                 try:
                     with open(os.path.join(REPO, 'profiles', rnd, 'pmc_summary.json')) as f:
                         ck = json.load(f)['chain_kernel']
