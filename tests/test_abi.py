@@ -67,7 +67,7 @@ def test_integration_stub_uses_only_declared_entry_points():
     """the reference-side ctypes stub in INTEGRATION.md binds symbols that include/p2s_hip.h declares"""
     text = open(os.path.join(REPO, 'INTEGRATION.md')).read()
     used = set(re.findall(r'\b(p2s_[a-z0-9_]+)\b', text))
-    declared = set(_declared_symbols()) | {'p2s_hip', 'p2s_model_cfg', 'p2s_mi355x', 'p2s_max', 'p2s_vanilla', 'p2s_uniform',
+    declared = set(_declared_symbols()) | {'p2s_hip', 'p2s_model_cfg', 'p2s_counters', 'p2s_mi355x', 'p2s_max', 'p2s_vanilla', 'p2s_uniform',
                                           'p2s_no_qstn', 'p2s_small_knn', 'p2s_large_knn', 'p2s_regression', 'p2s_shared_encoder',
                                           'p2s_shared_transformer', 'p2s_vanilla_ablation', 'p2s_vanilla_lower_lr',
                                           'p2s_vanilla_uniform_subsample', 'p2s_'}   # + non-symbols (model names)
