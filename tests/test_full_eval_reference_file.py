@@ -49,7 +49,9 @@ def _install_cpu_engine(monkeypatch):
     def fake_sdf(q):          # any deterministic field with both signs: a sphere around the cloud centre
         return (0.45 - np.linalg.norm(q, axis=1)).astype(np.float32)
 
-    def infer_shape(model, cloud, rng, res, eps, q_begin=0, q_end=-1, chunk=0, want_queries=True, n_queries=None, rng_patch=None):
+    def infer_shape(model, cloud, rng, res, eps, q_begin=0, q_end=-1, chunk=0, want_queries=True, n_queries=None, rng_patch=None,
+                    want_logits=False):
+        assert not want_logits                           # only with P2S_TIE_REPORT
         q = O.query_grid(cloud.pts_np, res, eps)[0]
         q = q[q_begin:(q.shape[0] if q_end < 0 else q_end)]
         return torch.from_numpy(fake_sdf(q)), torch.from_numpy(q)
