@@ -34,10 +34,10 @@ def _rescaled(w, site, c, s):
     return w2
 
 
-def _run(engine, w, cfg, cloud, enc, res=32):
+def _run(engine, w, cfg, cloud, enc, res=32, chunk=0):
     import torch
     m = engine.Model(w, dict(cfg, encoder_bf16=enc))
-    sdf, _ = engine.infer_shape(m, cloud, engine.Rng(SEED), res, 3)
+    sdf, _ = engine.infer_shape(m, cloud, engine.Rng(SEED), res, 3, chunk=chunk)
     torch.cuda.synchronize()
     n = int(m.counters()['fallback_queries'])
     m.close()
@@ -82,6 +82,18 @@ def test_queries_beyond_the_half_range_are_rerun_in_fp32(model, site, fixture_cl
     g = np.load(os.path.join(golden_dir, 'ref_%s_grid32.npz' % model))['sdf_full']
     cg = parity.compare_sdf(got, g)
     assert cg['max_abs_dsdf'] < 1e-4 and cg['flipped'].size == 0
+    # the same through several chunks (flagged queries of every chunk land at their own place of the call's output), and
+    # through a query range that does not start at 0
+    got7, n7 = _run(engine, w2, cfg, cloud, 4, chunk=700)
+    assert n7 == n and np.array_equal(got7, got)
+    import torch
+    m = engine.Model(w2, dict(cfg, encoder_bf16=4))
+    rng = engine.Rng(SEED)
+    part, _ = engine.infer_shape(m, cloud, rng, 32, 3, q_begin=0, q_end=1000, chunk=300)
+    rest, _ = engine.infer_shape(m, cloud, rng, 32, 3, q_begin=1000, q_end=nq, chunk=650)
+    torch.cuda.synchronize()
+    assert np.array_equal(np.concatenate([part.cpu().numpy(), rest.cpu().numpy()]), got)
+    m.close()
 
 
 def test_fallback_through_the_model_forward_boundary_and_its_capacity(fixture_cloud):
@@ -143,3 +155,27 @@ def test_logits_capture_of_the_pipeline(fixture_cloud):
     torch.cuda.synchronize()
     assert torch.equal(keep, lg)
     m.close()
+
+
+def test_fallback_in_the_gt_query_pass_with_rotations(fixture_cloud):
+    """the evaluation pass (p2s_infer_queries with the per-query random rotation, reference source/data_loader.py:381-393):
+    the flagged queries' ROTATED inputs are what is put aside and re-run"""
+    import torch
+    from points2surf_amd import engine, synth
+    w, cfg = synth.make_weights('p2s_max')
+    w2 = w
+    for c in range(2):
+        w2 = _rescaled(w2, 'first', c, float(2 ** 22))
+    cloud = engine.Cloud(fixture_cloud)
+    g = np.random.default_rng(3)
+    q = torch.from_numpy((fixture_cloud[g.integers(0, fixture_cloud.shape[0], 900)] + g.normal(0, 0.02, (900, 3))).astype(np.float32)).cuda()
+    out = {}
+    for enc in (4, 0):
+        m = engine.Model(w2, dict(cfg, encoder_bf16=enc))
+        sdf = engine.infer_queries(m, cloud, engine.Rng(SEED), engine.Rng(SEED), q, chunk=256)
+        torch.cuda.synchronize()
+        out[enc] = (sdf.cpu().numpy(), int(m.counters()['fallback_queries']))
+        m.close()
+    assert out[0][1] == 0 and out[4][1] > 100
+    same = int((out[4][0] == out[0][0]).sum())
+    assert same >= out[4][1] and float(np.abs(out[4][0] - out[0][0]).max()) < 1e-4
