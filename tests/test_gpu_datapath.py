@@ -75,21 +75,29 @@ def test_pipeline_matches_the_reference_network_on_the_strided_subset(res, encod
     outs = []
     for _, pts, _ in shapes:
         cloud = engine.Cloud(pts)
-        sdf, q = engine.infer_shape(model, cloud, rng, res, 3)
+        sdf, q, lg = engine.infer_shape(model, cloud, rng, res, 3, want_logits=True)
         torch.cuda.synchronize()
-        outs.append((sdf.cpu().numpy(), q))
+        outs.append((sdf.cpu().numpy(), q, lg.cpu().numpy()))
         cloud.close()
     rng.check()
-    worst, flips, total = 0.0, [], 0
-    for si, (sdf, q) in enumerate(outs):
+    worst, flips, total, worst_lg, undecided = 0.0, [], 0, 0.0, 0
+    for si, (sdf, q, lg) in enumerate(outs):
         ref = g['sdf_sub_%d' % si]
         assert sdf[::stride].shape == ref.shape
         c = parity.compare_sdf(sdf[::stride], ref)
         worst = max(worst, c['max_abs_dsdf'])
         flips += [(si, int(j) * stride) for j in c['flipped']]
         total += ref.size
-    print('encoder %d, grid %d: max|dSDF| %.3g over %d queries, flips %s' % (encoder, res, worst, total, flips))
+        # the raw logits against the reference's: the synthetic p2s_vanilla weights decide 'negative' for 90-99.8 % of these
+        # queries, so "0 flips" alone says little -- the sign of ANY model that differs from this one in the sign bias
+        # can only differ where the reference's sign logit + shift lies within |d logit| of zero
+        dl = np.abs(lg[::stride] - g['logits_sub_%d' % si])
+        worst_lg = max(worst_lg, float(dl.max()))
+        undecided = max(undecided, int((dl[:, 1] > 2e-5).sum()))
+    print('encoder %d, grid %d: max|dSDF| %.3g, max|d logit| %.3g over %d queries, flips %s'
+          % (encoder, res, worst, worst_lg, total, flips))
     assert total == meta['queries_network'] and worst < 1e-4 and len(flips) <= 8
+    assert worst_lg < 1e-4 and undecided <= total // 2000      # logits to ~2e-5 (the fp32 noise of 1024-wide layers)
     for si, j in flips:                                   # each flip: a tie by device AND CPU-port logit
         r2 = engine.Rng(meta['seed'])
         for _, p2, _ in shapes[:si]:
