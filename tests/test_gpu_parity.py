@@ -197,6 +197,33 @@ def test_forward_matches_oracle_ragged_batches(name, B, fixture_cloud, torch_cud
     assert np.abs(sdf.cpu().numpy() - O.post_process(ref, r)).max() < SDF_TOL_TIGHT
 
 
+@pytest.mark.parametrize('encoder', [0, 4])
+@pytest.mark.parametrize('k,n_sub', [(20, 1000), (40, 1000), (48, 1008), (49, 1009), (64, 1024), (100, 960), (112, 976), (113, 977)])
+def test_max_pool_at_every_kind_of_last_tile(k, n_sub, encoder, fixture_cloud, torch_cuda):
+    """r06: the fp32 chain kernel runs the last 64-point tile of an item with at most 48 points as 32 + 16 rows (the 16 on
+    the 4-block MFMA, two k partial sums added before the pool; p2s_chain_conv3.inl).  Patch / sub-sample sizes on both
+    sides of that switch -- 20 and 40 points (ONE tile, tail), 48 | 49 points in the last tile (tail | full), 64 (no
+    padding), 100 -> 36 and 112 -> 48 (tail), 113 -> 49 (full); sub-samples ending with 40, 48, 49, 64, 0 (960 = 15 full
+    tiles), 16 and 17 points -- against the numpy restatement of the reference's forward, fp32 and fp16-pair encoders."""
+    from oracle import p2s_oracle as O
+    from points2surf_amd import engine, synth
+    w, cfg = synth.make_weights('p2s_max')
+    cfg = dict(cfg, points_per_patch=k, sub_sample_size=n_sub)
+    model = engine.Model(w, dict(cfg, encoder_bf16=encoder))
+    B = 29
+    rng = np.random.default_rng(1000 * k + n_sub)
+    q = (fixture_cloud[rng.integers(0, fixture_cloud.shape[0], B)] + rng.normal(0, 0.01, (B, 3))).astype(np.float32)
+    ids = O.knn_ids(fixture_cloud, q, k)
+    r, ps = O.patch_radius_and_ps(fixture_cloud, ids, q)
+    sub = fixture_cloud[rng.integers(0, fixture_cloud.shape[0], (B, n_sub))]
+    ref = O.model_forward(w, cfg, ps, sub, q)
+    t = lambda a: torch_cuda.from_numpy(np.ascontiguousarray(a)).cuda()
+    logits, sdf = model.forward(t(ps), t(sub), t(q), t(r), want_logits=True, want_sdf=True)
+    assert np.abs(logits.cpu().numpy() - ref).max() < LOGIT_TOL, np.abs(logits.cpu().numpy() - ref).max()
+    assert np.abs(sdf.cpu().numpy() - O.post_process(ref, r)).max() < SDF_TOL_TIGHT
+    model.close()
+
+
 @pytest.mark.parametrize('k', [64, 75, 96, 300])
 def test_sum_pool_masks_the_padded_rows_of_the_last_point_tile(k, fixture_cloud, torch_cuda):
     """sym_op='sum' (reference source/points_to_surf_model.py:213-214): the last 64-point tile of an item is padded with
